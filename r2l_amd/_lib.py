@@ -1,0 +1,57 @@
+"""ctypes binding of libr2l_hip.so (C ABI declared in include/r2l_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or an export is absent the import of the
+HIP path fails loudly (RuntimeError), so a GPU run can never silently route through PyTorch ops or the oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libr2l_hip.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_f = ctypes.c_float
+
+# name -> (restype, argtypes); one row per declaration in include/r2l_hip.h
+SIGNATURES = {
+    "r2l_last_error": (ctypes.c_char_p, []),
+    "r2l_param_count": (_l, [_i]),
+    "r2l_fwd_stream_floats": (_l, [_i]),
+    "r2l_bwd_stream_floats": (_l, [_i]),
+    "r2l_pack_forward": (_i, [_p, _i, _p, _p]),
+    "r2l_pack_backward": (_i, [_p, _i, _p, _p]),
+    "r2l_forward_rays": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _p]),
+    "r2l_forward_pose": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
+    "r2l_forward_emb": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once and bind every export; raises RuntimeError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libr2l_hip.so not found at %s — build it with `python -m r2l_amd.build` "
+            "(or __graft_entry__.build()); there is no non-HIP fallback for the R2L hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError("libr2l_hip.so lacks export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().r2l_last_error()
+        raise RuntimeError("%s failed: hip error %d: %s" % (what, code, msg.decode() if msg else "?"))

@@ -1,0 +1,160 @@
+// r2l_common.h — shared device-side building blocks for the R2L ResMLP chain kernels (gfx950 only).
+//
+// Register-resident activation chain
+// ----------------------------------
+// One wavefront owns a tile of 32 rays for the WHOLE network.  A [256 features x 32 rays] activation
+// is held as 8 x f32x16 = 128 VGPR/AGPRs in the C/D fragment layout of v_mfma_f32_32x32x2_f32:
+//
+//     reg (T, c) of lane l  <->  feature 32*T + 8*(c>>2) + 4*(l>>5) + (c&3),   ray (l & 31)
+//
+// Computing  out^T[256 x 32] = W[256 x 256] . in^T[256 x 32]  with the weights as the MFMA A operand
+// makes the output fragment of layer n directly usable as the B operand of layer n+1 (B wants
+// B[k = l>>5][j = l&31]: register (T,c) supplies k-pair {f_lo, f_lo+4}), so activations never leave
+// the register file: no LDS round trip, no transposes, no barriers.  The weights are re-packed on the
+// device (r2l_pack.hip) into the exact per-lane A-operand order, as ONE contiguous stream in
+// consumption order, so every wave streams them with fully coalesced 1 KiB global_load_dwordx4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define R2L_W 256             // network width (features)
+#define R2L_NT 8              // 32-feature row tiles per activation
+#define R2L_TILE_RAYS 32      // rays per wavefront tile
+#define R2L_NSAMPLE 16        // sample points per ray
+#define R2L_L 10              // positional-encoding frequencies
+#define R2L_IN (R2L_NSAMPLE * 3 * (2 * R2L_L + 1))  // 1008
+#define R2L_GROUP_FLOATS (R2L_NT * 64 * 4)           // one weight "group": 8 tiles x 64 lanes x float4 = 2048 floats
+#define R2L_LAYER_GROUPS 32                          // groups per 256x256 layer
+#define R2L_LAYER_FLOATS (R2L_LAYER_GROUPS * R2L_GROUP_FLOATS)  // 65536
+#define R2L_HEAD_TRIG_GROUPS 120                     // 8 samples x 3 axes x 5 groups of 4 trig features
+#define R2L_HEAD_ID_GROUPS 6                         // 24 identity features per half-wave
+#define R2L_HEAD_GROUPS (R2L_HEAD_TRIG_GROUPS + R2L_HEAD_ID_GROUPS)
+#define R2L_HEAD_FLOATS (R2L_HEAD_GROUPS * R2L_GROUP_FLOATS)    // 258048 = 1008*256
+#define R2L_STREAM_PAD (2 * R2L_GROUP_FLOATS)        // the prefetcher runs up to two groups past the end
+
+// feature index held by fragment register (T, c) in lane-half h
+__device__ __forceinline__ int r2l_feat(int T, int c, int h) { return 32 * T + 8 * (c >> 2) + 4 * h + (c & 3); }
+
+// ---------------------------------------------------------------------------------------------
+// Weight stream reader: a wave walks the packed stream one group (8 x float4 per lane) at a time,
+// always holding the NEXT group in registers so that the loads are a full group (32 MFMAs = 2048
+// cycles) ahead of their use.  Fully unrolled call sites turn the cur/nxt swap into pure renaming.
+// ---------------------------------------------------------------------------------------------
+struct WStream {
+    const f32x4* p;  // lane-adjusted pointer to the next group to LOAD
+    f32x4 nxt[R2L_NT];
+    __device__ __forceinline__ void init(const float* stream, int lane) {
+        p = reinterpret_cast<const f32x4*>(stream) + lane;
+#pragma unroll
+        for (int t = 0; t < R2L_NT; ++t) nxt[t] = p[t * 64];
+        p += R2L_NT * 64;
+    }
+    // returns the current group and starts loading the following one
+    __device__ __forceinline__ void advance(f32x4 (&cur)[R2L_NT]) {
+#pragma unroll
+        for (int t = 0; t < R2L_NT; ++t) cur[t] = nxt[t];
+#pragma unroll
+        for (int t = 0; t < R2L_NT; ++t) nxt[t] = p[t * 64];
+        p += R2L_NT * 64;
+    }
+};
+
+// acc[256x32] += W_group . b  for the four k-pairs of one group.  b0..b3 are B-operand registers.
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], const f32x4 (&w)[R2L_NT], float b0, float b1,
+                                           float b2, float b3) {
+#pragma unroll
+    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][0], b0, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][1], b1, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][2], b2, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][3], b3, acc[t], 0, 0, 0);
+}
+
+// Pin the issue order of one group: the 8 prefetch loads of the NEXT group are spread one per 4 MFMAs of the
+// current group and may not sink below it (hipcc otherwise sinks them next to their use and the wave then
+// eats the full L2 latency with nothing else resident on the SIMD to hide it).
+__device__ __forceinline__ void r2l_pin_group_schedule() {
+#pragma unroll
+    for (int i = 0; i < R2L_NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc += W[256x256] . in   (one full layer, 32 groups, 1024 MFMAs)
+__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws) {
+#pragma unroll
+    for (int G = 0; G < R2L_LAYER_GROUPS; ++G) {
+        f32x4 w[R2L_NT];
+        ws.advance(w);
+        const int T = G >> 2, q = (G & 3) * 4;
+        mfma_group(acc, w, in[T][q + 0], in[T][q + 1], in[T][q + 2], in[T][q + 3]);
+        r2l_pin_group_schedule();
+    }
+}
+
+// acc[T][c] (+)= bias[feat(T,c,h)] read from the natural [256] bias vector as float4s
+template <bool ACCUM>
+__device__ __forceinline__ void add_bias(f32x16 (&acc)[R2L_NT], const float* __restrict__ bias, int h) {
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[T][4 * q + j] = ACCUM ? acc[T][4 * q + j] + b[j] : b[j];
+        }
+}
+
+__device__ __forceinline__ void relu_inplace(f32x16 (&a)[R2L_NT]) {
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[T][c] = fmaxf(a[T][c], 0.0f);
+}
+
+// Store / load a fragment to a row-major [N][256] fp32 tensor (saved activations / gradients).
+// Lane (ray j, half h) writes 16 B at row*1 KiB + (32T + 8q + 4h)*4: lanes j and j+32 complete a
+// 32-byte sector; the 32 (T,q) stores of one call complete every 128-byte line of the 32 rows.
+__device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t row, bool valid, int h,
+                                           const f32x16 (&a)[R2L_NT]) {
+    if (!valid) return;
+    float* r = base + row * R2L_W + 4 * h;
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {a[T][4 * q + 0], a[T][4 * q + 1], a[T][4 * q + 2], a[T][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(r + 32 * T + 8 * q) = v;
+        }
+}
+
+__device__ __forceinline__ void load_frag(const float* __restrict__ base, int64_t row, int h, f32x16 (&a)[R2L_NT]) {
+    const float* r = base + row * R2L_W + 4 * h;
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(r + 32 * T + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[T][4 * q + j] = v[j];
+        }
+}
+
+// error plumbing shared by the C-ABI translation units
+extern "C" const char* r2l_last_error(void);
+void r2l_set_error(const char* what, hipError_t e);
+#define R2L_CHECK(expr)                        \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) {                \
+            r2l_set_error(#expr, _e);          \
+            return (int)_e;                    \
+        }                                      \
+    } while (0)

@@ -1,0 +1,11 @@
+// r2l_error.hip — last-error plumbing for the C ABI (include/r2l_hip.h: r2l_last_error).
+#include "r2l_common.h"
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void r2l_set_error(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s -> %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+extern "C" const char* r2l_last_error(void) { return g_err; }

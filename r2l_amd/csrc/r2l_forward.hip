@@ -1,0 +1,281 @@
+// r2l_forward.hip — fused R2L student forward for gfx950 (MI355X):
+//   ray -> 16 sample points -> positional encoding (1008-d, never materialised) -> Linear(1008,256)+ReLU
+//   -> n_block x [Linear+ReLU+Linear + residual] -> outer residual -> Linear(256,3)+Sigmoid
+// replacing the op sequence of /root/reference/model/nerf_raybased.py:94-126 (PointSampler),
+// :198-208 (PositionalEmbedder.__call__), :461-465 (ResMLP.forward), :539-544 (NeRF_v3_2.forward).
+//
+// One wavefront = 32 rays for the whole network, activations register-resident in MFMA fragment layout
+// (see r2l_common.h); exact-fp32 v_mfma_f32_32x32x2_f32; 4 independent waves per 256-thread block, one per SIMD.
+#include "r2l_common.h"
+
+struct R2LFwdArgs {
+    // inputs (exactly one of {rays_o/rays_d}, {pose}, {emb} is used, selected by the MODE template argument)
+    const float* rays_o;   // [N,3]
+    const float* rays_d;   // [N,3]
+    const float* t_rand;   // [N,16] stratified jitter U[0,1) or nullptr (perturb == 0)
+    const float* emb;      // [N,1008] pre-embedded input (module-boundary compatibility path)
+    const float* ztab;     // [32]: z_lower[16], z_span[16]  (z = z_lower + z_span * t_rand ; z = z_lower if !t_rand)
+    float c2w[12];         // row-major [3,4] camera-to-world (pose mode)
+    int H, Wimg;
+    float focal;
+    // parameters
+    const float* wstream;  // packed head+body weight stream (r2l_pack.hip)
+    const float* params;   // flat fp32 parameter buffer in state_dict order (biases and tail are read from here)
+    int n_block;
+    // outputs
+    float* rgb;            // [N,3]
+    float* save_x;         // [(n_block+1)][N][256]  X_0 (=relu(head)), X_1 .. X_n   or nullptr
+    float* save_t;         // [n_block][N][256]      relu(hidden) of each block      or nullptr
+    int64_t N;
+};
+
+// ---- flat parameter buffer offsets (state_dict order: head.0.{weight,bias}, body.b.body.{0,2}.{weight,bias}, tail.0.*)
+__host__ __device__ __forceinline__ int64_t off_head_b() { return (int64_t)R2L_IN * R2L_W; }
+__host__ __device__ __forceinline__ int64_t off_body_w(int layer) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
+}
+__host__ __device__ __forceinline__ int64_t off_body_b(int layer) { return off_body_w(layer) + R2L_W * R2L_W; }
+__host__ __device__ __forceinline__ int64_t off_tail_w(int n_block) { return off_body_w(2 * n_block); }
+__host__ __device__ __forceinline__ int64_t off_tail_b(int n_block) { return off_tail_w(n_block) + 3 * R2L_W; }
+
+// ---- accurate sin & cos for |x| < ~8e3 (the encoder's arguments are 2^k * x, |x| < ~8, k <= 9) ---------------
+// Cody-Waite reduction by pi/2 with a 3-term fp32 split and FMAs, then the classic degree-7/8 minimax kernels on
+// [-pi/4, pi/4].  Max error vs fp64 sin/cos over |x| <= 4096: < 1.5 ulp (tests/test_sincos_gpu).  Branch free.
+__device__ __forceinline__ void r2l_sincos(float x, float& s_out, float& c_out) {
+    const float n = rintf(x * 0.63661977236758134f);  // round(x * 2/pi)
+    float r = __builtin_fmaf(-n, 1.57079637050628662109375f, x);
+    r = __builtin_fmaf(-n, -4.37113900018624283e-8f, r);
+    r = __builtin_fmaf(-n, -1.71512449512872556e-15f, r);
+    const float r2 = r * r;
+    // sin(r) ~ r + r^3 * (S1 + r2*(S2 + r2*(S3 + r2*S4)))
+    float ps = __builtin_fmaf(r2, 2.718311493989822e-6f, -1.9839334836096632e-4f);
+    ps = __builtin_fmaf(ps, r2, 8.3333293858894632e-3f);
+    ps = __builtin_fmaf(ps, r2, -1.6666666641626524e-1f);
+    const float sr = __builtin_fmaf(ps * r2, r, r);
+    // cos(r) ~ 1 - r2/2 + r2^2 * (C1 + r2*(C2 + r2*C3))
+    float pc = __builtin_fmaf(r2, 2.439044879627741e-5f, -1.388676377460993e-3f);
+    pc = __builtin_fmaf(pc, r2, 4.1666623323739063e-2f);
+    pc = __builtin_fmaf(pc, r2, -0.5f);
+    const float cr = __builtin_fmaf(pc, r2, 1.0f);
+    const int q = (int)n;
+    const float s1 = (q & 1) ? cr : sr;
+    const float c1 = (q & 1) ? sr : cr;
+    s_out = (q & 2) ? -s1 : s1;
+    c_out = ((q + 1) & 2) ? -c1 : c1;
+}
+
+enum { MODE_RAYS = 0, MODE_POSE = 1, MODE_EMB = 2 };
+
+template <int MODE, bool SAVE>
+__global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
+    __shared__ float stash[4][R2L_NT * 16][64];  // X_0 of each wave's tile, needed again for the outer residual
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int64_t ray = ((int64_t)blockIdx.x * 4 + wave) * R2L_TILE_RAYS + (lane & 31);
+    if ((int64_t)(blockIdx.x * 4 + wave) * R2L_TILE_RAYS >= a.N) return;  // whole wave idle (wave-uniform)
+    const bool valid = ray < a.N;
+    const int64_t rc = valid ? ray : a.N - 1;
+
+    WStream ws;
+    ws.init(a.wstream, lane);
+
+    f32x16 x[R2L_NT], t[R2L_NT];
+    add_bias<false>(x, a.params + off_head_b(), h);
+
+    if constexpr (MODE == MODE_EMB) {
+        // B operand straight from the embedded input: stream step s of half h reads emb[ray][s + 504 h]
+        const float* e = a.emb + rc * R2L_IN + 504 * h;
+        // same step order as the fused path: trig steps (sample it, axis, f) then identity steps
+        for (int it = 0; it < 8; ++it) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const float* ec = e + (it * 3 + ax) * 21;
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    f32x4 w[R2L_NT];
+                    ws.advance(w);
+                    mfma_group(x, w, ec[4 * g + 0], ec[4 * g + 1], ec[4 * g + 2], ec[4 * g + 3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < R2L_HEAD_ID_GROUPS; ++g) {
+            f32x4 w[R2L_NT];
+            ws.advance(w);
+            mfma_group(x, w, e[(4 * g + 0) * 21 + 20], e[(4 * g + 1) * 21 + 20], e[(4 * g + 2) * 21 + 20],
+                       e[(4 * g + 3) * 21 + 20]);
+        }
+    } else {
+        float o[3], d[3];
+        if constexpr (MODE == MODE_RAYS) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o[k] = a.rays_o[rc * 3 + k];
+                d[k] = a.rays_d[rc * 3 + k];
+            }
+        } else {
+            // PointSampler.__init__/sample_test (nerf_raybased.py:80-99): dirs = [(i-W/2)/f, -(j-H/2)/f, -1],
+            // rays_d[k] = sum_b dirs[b] * c2w[k][b], rays_o = c2w[:,3]
+            const int pj = (int)(rc / a.Wimg), pi = (int)(rc % a.Wimg);
+            const float dx = ((float)pi - (float)a.Wimg * 0.5f) / a.focal;
+            const float dy = -(((float)pj - (float)a.H * 0.5f) / a.focal);
+            const float dz = -1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = (dx * a.c2w[4 * k + 0] + dy * a.c2w[4 * k + 1]) + dz * a.c2w[4 * k + 2];
+                o[k] = a.c2w[4 * k + 3];
+            }
+        }
+        // the 8 sample depths of this half-wave (samples 8h .. 8h+7)
+        float z[8];
+        {
+            const f32x4 lo0 = *reinterpret_cast<const f32x4*>(a.ztab + 8 * h);
+            const f32x4 lo1 = *reinterpret_cast<const f32x4*>(a.ztab + 8 * h + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                z[k] = lo0[k];
+                z[4 + k] = lo1[k];
+            }
+            if (a.t_rand != nullptr) {  // z = lower + (upper-lower) * t_rand   (nerf_raybased.py:119-123)
+                const f32x4 sp0 = *reinterpret_cast<const f32x4*>(a.ztab + 16 + 8 * h);
+                const f32x4 sp1 = *reinterpret_cast<const f32x4*>(a.ztab + 16 + 8 * h + 4);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.t_rand + rc * 16 + 8 * h);
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(a.t_rand + rc * 16 + 8 * h + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    z[k] = lo0[k] + sp0[k] * u0[k];
+                    z[4 + k] = lo1[k] + sp1[k] * u1[k];
+                }
+            }
+        }
+        // trig features: per coordinate [sin(2^0 x) .. sin(2^9 x), cos(2^0 x) .. cos(2^9 x)]   (nerf_raybased.py:199-203)
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+            float zz = z[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) zz = (it == k) ? z[k] : zz;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const float xc = o[ax] + d[ax] * zz;  // pts = o + d*z, mul and add rounded separately (-ffp-contract=off)
+                float f[20];
+#pragma unroll
+                for (int k = 0; k < R2L_L; ++k) r2l_sincos(xc * (float)(1 << k), f[k], f[R2L_L + k]);
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    f32x4 w[R2L_NT];
+                    ws.advance(w);
+                    mfma_group(x, w, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+                }
+            }
+        }
+        // identity features (the trailing x of each coordinate's 21)
+        {
+            float id[24];
+#pragma unroll
+            for (int e = 0; e < 24; ++e) id[e] = o[e % 3] + d[e % 3] * z[e / 3];
+#pragma unroll
+            for (int g = 0; g < R2L_HEAD_ID_GROUPS; ++g) {
+                f32x4 w[R2L_NT];
+                ws.advance(w);
+                mfma_group(x, w, id[4 * g + 0], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
+            }
+        }
+    }
+    relu_inplace(x);
+
+    // stash X_0 for the outer residual  (NeRF_v3_2.forward: body(x) + x, nerf_raybased.py:543)
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = x[T][c];
+    if constexpr (SAVE) store_frag(a.save_x, ray, valid, h, x);
+
+    // body: x <- x + W2 relu(W1 x + b1) + b2     (ResMLP.forward with res_scale 1, nerf_raybased.py:461-465)
+    const float* bias = a.params + off_body_b(0);
+#pragma unroll 1
+    for (int b = 0; b < a.n_block; ++b) {
+        add_bias<false>(t, bias, h);
+        gemm256(t, x, ws);
+        relu_inplace(t);
+        if constexpr (SAVE) store_frag(a.save_t + (int64_t)b * a.N * R2L_W, ray, valid, h, t);
+        add_bias<true>(x, bias + (R2L_W * R2L_W + R2L_W), h);
+        gemm256(x, t, ws);
+        if constexpr (SAVE) store_frag(a.save_x + (int64_t)(b + 1) * a.N * R2L_W, ray, valid, h, x);
+        bias += 2 * (R2L_W * R2L_W + R2L_W);
+    }
+
+    // tail: rgb = sigmoid(Wt (x + X_0) + bt)
+    const float* tw = a.params + off_tail_w(a.n_block);
+    float acc3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 wv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = x[T][4 * q + j] + stash[wave][T * 16 + 4 * q + j][lane];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc3[c] = __builtin_fmaf(wv[c][j], y, acc3[c]);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        acc3[c] += __shfl_xor(acc3[c], 32);
+        const float v = acc3[c] + a.params[off_tail_b(a.n_block) + c];
+        acc3[c] = 1.0f / (1.0f + expf(-v));
+    }
+    if (valid && h == 0) {
+        a.rgb[ray * 3 + 0] = acc3[0];
+        a.rgb[ray * 3 + 1] = acc3[1];
+        a.rgb[ray * 3 + 2] = acc3[2];
+    }
+}
+
+template <int MODE>
+static int launch_fwd(const R2LFwdArgs& a, hipStream_t stream) {
+    if (a.N <= 0) return 0;
+    const int64_t tiles = (a.N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    if (a.save_x != nullptr)
+        hipLaunchKernelGGL((r2l_fwd_kernel<MODE, true>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((r2l_fwd_kernel<MODE, false>), grid, block, 0, stream, a);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI (declared in include/r2l_hip.h)
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                                const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
+                                float* save_t, int64_t N, void* stream) {
+    R2LFwdArgs a{};
+    a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
+    a.wstream = wstream; a.params = params; a.n_block = n_block;
+    a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N;
+    return launch_fwd<MODE_RAYS>(a, (hipStream_t)stream);
+}
+
+extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float focal, const float* ztab,
+                                const float* wstream, const float* params, int n_block, float* rgb, void* stream) {
+    R2LFwdArgs a{};
+    for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
+    a.H = H; a.Wimg = W; a.focal = focal; a.ztab = ztab;
+    a.wstream = wstream; a.params = params; a.n_block = n_block;
+    a.rgb = rgb; a.N = (int64_t)H * W;
+    return launch_fwd<MODE_POSE>(a, (hipStream_t)stream);
+}
+
+extern "C" int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,
+                               float* save_x, float* save_t, int64_t N, void* stream) {
+    R2LFwdArgs a{};
+    a.emb = emb; a.wstream = wstream; a.params = params; a.n_block = n_block;
+    a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N;
+    return launch_fwd<MODE_EMB>(a, (hipStream_t)stream);
+}

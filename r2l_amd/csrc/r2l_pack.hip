@@ -1,0 +1,78 @@
+// r2l_pack.hip — re-pack the nn.Linear weights of NeRF_v3_2 (flat state_dict-order fp32 buffer; layer shapes from
+// /root/reference/model/nerf_raybased.py:500-537) into the per-lane MFMA A-operand weight streams that the chain
+// kernels consume sequentially (layout contract: r2l_common.h).  Runs once per optimizer step (23.7 MB gather).
+#include "r2l_common.h"
+
+__host__ __device__ static inline int64_t pk_off_body_w(int layer) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
+}
+
+// forward stream: head trig groups (sample it, axis, g) | head identity groups | body layers in execution order
+__global__ void r2l_pack_fwd_kernel(const float* __restrict__ params, float* __restrict__ out, int n_block) {
+    const int64_t total = (int64_t)R2L_HEAD_FLOATS + (int64_t)2 * n_block * R2L_LAYER_FLOATS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + R2L_STREAM_PAD;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= total) { out[i] = 0.f; continue; }
+        const int64_t gidx = i / R2L_GROUP_FLOATS;
+        const int rem = (int)(i % R2L_GROUP_FLOATS);
+        const int tile = rem >> 8, lane = (rem & 255) >> 2, j = rem & 3;
+        const int h = lane >> 5, o = 32 * tile + (lane & 31);
+        int64_t src;
+        if (gidx < R2L_HEAD_TRIG_GROUPS) {
+            const int it = (int)gidx / 15, ax = ((int)gidx % 15) / 5, g = (int)gidx % 5;
+            const int k = ((8 * h + it) * 3 + ax) * 21 + 4 * g + j;
+            src = (int64_t)o * R2L_IN + k;
+        } else if (gidx < R2L_HEAD_GROUPS) {
+            const int e = 4 * ((int)gidx - R2L_HEAD_TRIG_GROUPS) + j;
+            const int k = (24 * h + e) * 21 + 20;
+            src = (int64_t)o * R2L_IN + k;
+        } else {
+            const int64_t gb = gidx - R2L_HEAD_GROUPS;
+            const int layer = (int)(gb / R2L_LAYER_GROUPS), G = (int)(gb % R2L_LAYER_GROUPS);
+            const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
+            src = pk_off_body_w(layer) + (int64_t)o * R2L_W + in;
+        }
+        out[i] = params[src];
+    }
+}
+
+// backward (dX) stream: transposed body layers in reverse execution order: (n-1,2)^T, (n-1,0)^T, ..., (0,2)^T, (0,0)^T
+__global__ void r2l_pack_bwd_kernel(const float* __restrict__ params, float* __restrict__ out, int n_block) {
+    const int64_t total = (int64_t)2 * n_block * R2L_LAYER_FLOATS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + R2L_STREAM_PAD;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= total) { out[i] = 0.f; continue; }
+        const int64_t gidx = i / R2L_GROUP_FLOATS;
+        const int rem = (int)(i % R2L_GROUP_FLOATS);
+        const int tile = rem >> 8, lane = (rem & 255) >> 2, j = rem & 3;
+        const int h = lane >> 5, o = 32 * tile + (lane & 31);
+        const int slot = (int)(gidx / R2L_LAYER_GROUPS), G = (int)(gidx % R2L_LAYER_GROUPS);
+        const int layer = 2 * n_block - 1 - slot;
+        const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
+        out[i] = params[pk_off_body_w(layer) + (int64_t)in * R2L_W + o];  // (W^T)[o][in] = W[in][o]
+    }
+}
+
+extern "C" int64_t r2l_param_count(int n_block) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)2 * n_block * (R2L_W * R2L_W + R2L_W) + 3 * R2L_W + 3;
+}
+
+extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
+    return (int64_t)R2L_HEAD_FLOATS + (int64_t)2 * n_block * R2L_LAYER_FLOATS + R2L_STREAM_PAD;
+}
+
+extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
+    return (int64_t)2 * n_block * R2L_LAYER_FLOATS + R2L_STREAM_PAD;
+}
+
+extern "C" int r2l_pack_forward(const float* params, int n_block, float* wstream, void* stream) {
+    hipLaunchKernelGGL(r2l_pack_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int r2l_pack_backward(const float* params, int n_block, float* wstream, void* stream) {
+    hipLaunchKernelGGL(r2l_pack_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
