@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py — rays/sec of the R2L W256D88 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): BASELINE.json configs[1] — render 400x400 frames (160 000 rays each, 16 samples/ray,
+L=10, W256 D88, seeded weights, synthetic pose_spherical poses).  One "step" = one frame per GPU through the fused
+HIP forward (ray sampling + positional encoding + 88-layer ResMLP + RGB head).  Inputs (pose, weights) are resident
+before the timed region.  Frames shard across ranks with no collective -> "scaling": "weak".
+When the training path is built the same JSON line carries a "train" object (distillation step: forward + backward
++ Adam, RCCL all-reduce of the flat gradient at N>1), timed by the same barrier-bracketed recipe.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_FLOP_PER_RAY = 2 * (1008 * 256 + 86 * 256 * 256 + 256 * 3)  # 11 789 824
+TRAIN_FLOP_PER_RAY = 2 * (3 * 5894912 - 258048)  # 34 853 376: fwd + dX + dW, no dX for the head
+PEAK_FP32_MFMA = 157.3  # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md chip table (exact-fp32 MFMA)
+H = W = 400
+FOCAL = 555.5555155968841
+
+
+def make_model(device):
+    from oracle import r2l_oracle as O  # only to reproduce the seeded reference weights (test infrastructure)
+    from model.nerf_raybased import NeRF_v3_2, PointSampler
+    trial = argparse.Namespace(ON=True, body_arch="resmlp", inact="relu", outact="none", res_scale=1., n_learnable=2,
+                               n_block=-1, near=-1, far=-1)
+    args = argparse.Namespace(netdepth=88, netwidth=256, layerwise_netwidths="", act="relu", linear_tail=False,
+                              use_residual=True, trial=trial)
+    sd = O.make_state_dict(n_block=43, seed=0)
+    net = NeRF_v3_2(args, 1008, 3)
+    net.load_state_dict(sd)
+    net = net.to(device)
+    ps = PointSampler(H, W, FOCAL, 16, 2., 6., device=device)
+    return net, ps, sd, O
+
+
+def barrier_sync(distributed):
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed(fn, steps, warmup, distributed, device):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.
+    Also returns the mean device time per step from HIP events recorded on the launch stream."""
+    for i in range(warmup):
+        fn(i)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier_sync(distributed)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        fn(warmup + i)
+        ev[i][1].record()
+    barrier_sync(distributed)
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    return dt, kernel_ms
+
+
+def cpu_baseline(O, sd, n_rays=16384, repeats=2):
+    """The oracle (CPU restatement of the reference op sequence) timed on the host cores: reported, not a target."""
+    import numpy as np
+    from oracle import r2l_oracle as Or
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(0)
+    dirs = Or.pixel_dirs(H, W, FOCAL)
+    c2w = torch.from_numpy(Or.pose_spherical(30., -30., 4.)[:3, :4])
+    z = Or.z_vals(16, 2., 6.)
+    rows = torch.randperm(H * W, generator=g)[:n_rays]
+    with torch.no_grad():
+        best = None
+        for _ in range(repeats + 1):  # first pass is a warm-up
+            t0 = time.perf_counter()
+            pts = Or.sample_test(dirs, z, c2w)[rows]
+            rgb = Or.r2l_forward(sd, Or.positional_embed(pts, 10))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n_rays / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d rays of one 400x400 frame, sample+encode+W256D88 forward, fp32 torch CPU ops, best of %d; %s"
+                      % (n_rays, repeats, cpu_model)}, rgb, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--train-rays", type=int, default=98304,
+                    help="rays per GPU per training step (README: N_rand 20 x 4096 + 20%% hard rays)")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if a.gpus != world and distributed:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    net, ps, sd, O = make_model(device)
+    # synthetic test poses: pose_spherical(theta, -30, 4), theta = linspace(-180,180,41)[:-1]  (load_blender.py:84-86)
+    thetas = [-180.0 + 9.0 * i for i in range(40)]
+    poses = [torch.from_numpy(O.pose_spherical(t, -30., 4.)[:3, :4]) for t in thetas]
+    frames = {}
+
+    def render_step(i):
+        with torch.no_grad():
+            frames["rgb"] = net.render_pose(poses[(i * world + rank) % len(poses)], ps)
+
+    dt, kernel_ms = timed(render_step, a.steps, a.warmup, distributed, device)
+    rays = H * W * a.steps * world
+    value = rays / dt
+    achieved = H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "rays/sec (train+render) W256D88 lego@400x400", "value": value, "unit": "rays/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "R2L W256D88 render_test 400x400 testskip=1: 1 frame (160000 rays, 16 samples/ray, "
+                               "L=10) per GPU per step, fused sample+encode+ResMLP forward; seeded weights, "
+                               "pose_spherical poses",
+                   "rays_per_step_per_gpu": H * W, "parallelism": "frames sharded across %d rank(s), no collective"
+                                                               % world},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA, "traffic": None,
+                     "kernel": "r2l_fwd_kernel<MODE_POSE>", "kernel_ms": kernel_ms,
+                     "flop_per_ray": FWD_FLOP_PER_RAY},
+    }
+
+    train_mod = None
+    if not a.no_train:
+        try:
+            from r2l_amd import train_step as train_mod
+        except ImportError:
+            train_mod = None
+    if train_mod is not None:
+        out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                       PEAK_FP32_MFMA)
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cb, rgb_cpu, rows = cpu_baseline(O, sd)
+        out["cpu_baseline"] = cb
+        # parity spot check of the benchmarked frame against the CPU baseline output (same pose as the sample)
+        with torch.no_grad():
+            rgb_gpu = net.render_pose(torch.from_numpy(O.pose_spherical(30., -30., 4.)[:3, :4]), ps).cpu()
+        out["parity_max_abs_err_vs_cpu"] = (rgb_gpu[rows] - rgb_cpu).abs().max().item()
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
