@@ -50,6 +50,31 @@ int r2l_forward_pose(const float* c2w_host12, int H, int W, float focal, const f
 int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,
                     float* save_x, float* save_t, int64_t N, void* stream);
 
+/* ---- student backward + optimizer ------------------------------------------------------------------------------
+ * Replaces loss.backward() of main.py:1377-1404 for the R2L branch (autograd over the ops above, anomaly mode on in the
+ * reference: model/nerf_raybased.py:4) by three hand-written stages: the dX chain through the transposed layers, the
+ * per-layer weight-gradient GEMMs (reduction over rays) and the head gradient with the encoding recomputed.
+ *   MSE mode  (target != NULL): dL/drgb = grad_scale * (rgb - target)   [grad_scale = 2*lw_rgb / (3*N_global)];
+ *                               sqerr_partial[r2l_num_tiles(N)] receives per-32-ray sums of (rgb-target)^2.
+ *   generic   (target == NULL): dL/drgb = drgb[N,3] supplied by the caller (autograd bridge).
+ * Head input: emb[N,1008] if given, else recomputed from (rays_o, rays_d, t_rand, ztab) exactly as the forward did.
+ * save_x/save_t: the stash written by the forward.  Scratch owned by the caller: dpre[N,3], gx[(n_block+1),N,256],
+ * gt[n_block,N,256].  Gradients are ACCUMULATED (fp32 atomics) into `grads` (flat, same layout as params): zero it
+ * first unless accumulation is wanted. */
+int64_t r2l_num_tiles(int64_t N);
+int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* emb,
+                 const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                 const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                 float* gt, float* sqerr_partial, float* grads, int64_t N, void* stream);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay 0) on flat buffers (main.py:465-467, 1406); `step` counts from 1;
+ * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* out2[0] = inv_denom * sum(sqerr_partial) (= img2mse * lw_rgb, helpers:19), out2[1] = psnr (helpers:20). */
+int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_denom, float* out2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

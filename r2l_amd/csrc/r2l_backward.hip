@@ -1,0 +1,484 @@
+// r2l_backward.hip — hand-written backward of the R2L student for gfx950 (replaces the autograd graph the reference
+// builds at /root/reference/main.py:1374-1404: loss = mean((rgb-target)^2) * lw_rgb, loss.backward()).
+//
+//   1. r2l_bwd_chain_kernel : dL/drgb -> sigmoid' -> tail^T -> the 2*n_block transposed layers, register-resident
+//                             exactly like the forward (W^T streams packed by r2l_pack_backward); writes the
+//                             per-layer output gradients G (row-major [N,256]) that the weight-gradient GEMMs need.
+//   2. r2l_dw_body_kernel   : dW[l] = G[l]^T A[l] (reduction over rays) for the 2*n_block 256x256 layers + db,
+//                             fp32 MFMA, operands streamed straight from HBM with coalesced 16-byte loads.
+//   3. r2l_dw_head_kernel   : dW_head = G_head^T PE(rays) with the 1008-d positional encoding recomputed on the fly.
+//   4. r2l_dw_tail_kernel   : tail weight/bias gradients (3x256) by plain reduction.
+#include "r2l_common.h"
+
+// ---- flat parameter offsets (same as r2l_forward.hip) ---------------------------------------------------------
+__host__ __device__ static inline int64_t b_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
+__host__ __device__ static inline int64_t b_off_body_w(int layer) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
+}
+__host__ __device__ static inline int64_t b_off_body_b(int layer) { return b_off_body_w(layer) + R2L_W * R2L_W; }
+__host__ __device__ static inline int64_t b_off_tail_w(int n_block) { return b_off_body_w(2 * n_block); }
+__host__ __device__ static inline int64_t b_off_tail_b(int n_block) { return b_off_tail_w(n_block) + 3 * R2L_W; }
+
+struct R2LBwdArgs {
+    const float* rgb;      // [N,3] forward output
+    const float* target;   // [N,3]  MSE mode: dL/drgb = grad_scale*(rgb-target)            (or nullptr)
+    const float* drgb;     // [N,3]  generic mode (target == nullptr): dL/drgb given by the caller
+    const float* save_x;   // [(n_block+1),N,256]
+    const float* save_t;   // [n_block,N,256]
+    const float* wstream;  // packed transposed weight stream
+    const float* params;   // flat params (tail weights)
+    int n_block;
+    float grad_scale;      // dL/drgb = grad_scale * (rgb - target);  = 2*lw_rgb / (3*N_global)
+    float* dpre;           // [N,3]   dL/d(tail pre-activation)
+    float* gx;             // [(n_block+1),N,256]  gx[b] = dL/dx_b ; gx[0] already includes the outer-residual branch and
+                           //                      is masked by relu'(head) i.e. it is dL/d(head pre-activation)
+    float* gt;             // [n_block,N,256]      dL/d(hidden pre-activation) of each block
+    float* sqerr_partial;  // [ceil(N/32)] per-tile sums of (rgb-target)^2
+    int64_t N;
+};
+
+__global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs a) {
+    __shared__ float stash[4][R2L_NT * 16][64];  // dy of each wave's tile (outer residual branch), re-added at the head
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile * R2L_TILE_RAYS >= a.N) return;
+    const int64_t ray = tile * R2L_TILE_RAYS + (lane & 31);
+    const bool valid = ray < a.N;
+    const int64_t rc = valid ? ray : a.N - 1;
+
+    WStream ws;
+    ws.init(a.wstream, lane);
+
+    // loss gradient through the sigmoid: dpre = grad_scale*(rgb-target) * rgb*(1-rgb)
+    float dp[3], se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float r = a.rgb[rc * 3 + c];
+        float dl;
+        if (a.target != nullptr) {
+            const float e = r - a.target[rc * 3 + c];
+            se += e * e;
+            dl = a.grad_scale * e;
+        } else {
+            dl = a.drgb[rc * 3 + c];
+        }
+        dp[c] = valid ? dl * (r * (1.0f - r)) : 0.f;
+    }
+    if (!valid) se = 0.f;
+    if (valid && h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.dpre[ray * 3 + c] = dp[c];
+    }
+    // per-tile squared error (lanes 0..31 hold the 32 rays)
+    if (a.sqerr_partial != nullptr) {
+        float s = (h == 0) ? se : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) a.sqerr_partial[tile] = s;
+    }
+
+    // g = dy = Wt^T dpre   (tail Linear(256,3))
+    f32x16 g[R2L_NT], u[R2L_NT];
+    const float* tw = a.params + b_off_tail_w(a.n_block);
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 wv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = wv[0][j] * dp[0];
+                v = __builtin_fmaf(wv[1][j], dp[1], v);
+                v = __builtin_fmaf(wv[2][j], dp[2], v);
+                g[T][4 * q + j] = v;
+            }
+        }
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = g[T][c];
+    store_frag(a.gx + (int64_t)a.n_block * a.N * R2L_W, ray, valid, h, g);
+
+#pragma unroll 1
+    for (int b = a.n_block - 1; b >= 0; --b) {
+        // u = W2^T g, masked by relu'(hidden) = (t_b > 0)
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) u[T][c] = 0.f;
+        gemm256(u, g, ws);
+        {
+            const float* r = a.save_t + ((int64_t)b * a.N + rc) * R2L_W + 4 * h;
+#pragma unroll
+            for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(r + 32 * T + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[T][4 * q + j] = tv[j] > 0.f ? u[T][4 * q + j] : 0.f;
+                }
+        }
+        store_frag(a.gt + (int64_t)b * a.N * R2L_W, ray, valid, h, u);
+        // g += W1^T u
+        gemm256(g, u, ws);
+        if (b > 0) store_frag(a.gx + (int64_t)b * a.N * R2L_W, ray, valid, h, g);
+    }
+
+    // head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0)
+    {
+        const float* r = a.save_x + rc * R2L_W + 4 * h;
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(r + 32 * T + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = g[T][4 * q + j] + stash[wave][T * 16 + 4 * q + j][lane];
+                    g[T][4 * q + j] = xv[j] > 0.f ? v : 0.f;
+                }
+            }
+    }
+    store_frag(a.gx, ray, valid, h, g);
+}
+
+// =================================================================================================================
+// Weight gradients of the 2*n_block body layers:   dW[l][o][i] = sum_r G_l[r][o] * A_l[r][i],   db[l][o] = sum_r G_l[r][o]
+//   layer (b,0): G = gt[b]   , A = x_b    ;   layer (b,2): G = gx[b+1] , A = t_b
+// One workgroup (4 waves, one per SIMD) accumulates a full 256x256 tile set: wave (wo,wi) owns output rows
+// wo*128 + 4*i + e (e = 0..3: four 32-row MFMA tiles) x input columns wi*128 + 4*i' + e'.  An MFMA k-step consumes two
+// rays (lanes 0-31 ray 2s, lanes 32-63 ray 2s+1); each lane feeds its 4 tiles from ONE 16-byte load per operand:
+// 512 contiguous bytes per half-wave.  The (layer, ray-chunk) work list is cut into equal contiguous ranges, one per
+// workgroup; a workgroup flushes with fp32 atomics whenever its range crosses a layer boundary (grad buffer is
+// zeroed by the caller, which also gives gradient accumulation for free).
+// =================================================================================================================
+#define DW_CHUNK 64  // rays per work unit
+
+struct R2LDwArgs {
+    const float* save_x;
+    const float* save_t;
+    const float* gx;
+    const float* gt;
+    float* grads;  // flat gradient buffer (state_dict order)
+    int n_block;
+    int64_t N;
+    int64_t units_per_layer;  // ceil(N / DW_CHUNK)
+    int64_t units_per_wg;
+};
+
+__device__ __forceinline__ void dw_flush(f32x16 (&acc)[4][4], f32x4& bsum, float* __restrict__ gw, float* __restrict__ gb,
+                                         int wo, int wi, int lane) {
+    const int jl = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+        for (int ei = 0; ei < 4; ++ei)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                // D[row][col]: row = (c&3) + 8*(c>>2) + 4*hh -> output feature index within the tile, col = jl -> input
+                const int ro = (c & 3) + 8 * (c >> 2) + 4 * hh;
+                const int o = wo * 128 + 4 * ro + eo;
+                const int i = wi * 128 + 4 * jl + ei;
+                atomicAdd(gw + o * R2L_W + i, acc[eo][ei][c]);
+                acc[eo][ei][c] = 0.f;
+            }
+    if (wi == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = bsum[e] + __shfl_xor(bsum[e], 32);
+            if (hh == 0) atomicAdd(gb + wo * 128 + 4 * jl + e, s);
+        }
+    }
+    bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+__global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wo = wave >> 1, wi = wave & 1;
+    const int hh = lane >> 5, jl = lane & 31;
+    const int64_t total = a.units_per_layer * 2 * a.n_block;
+    int64_t u0 = (int64_t)blockIdx.x * a.units_per_wg;
+    int64_t u1 = u0 + a.units_per_wg;
+    if (u1 > total) u1 = total;
+    if (u0 >= u1) return;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+        for (int ei = 0; ei < 4; ++ei)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[eo][ei][c] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    int64_t u = u0;
+    while (u < u1) {
+        const int layer = (int)(u / a.units_per_layer);
+        const int64_t cu = u % a.units_per_layer;
+        int64_t cend = cu + (u1 - u);
+        if (cend > a.units_per_layer) cend = a.units_per_layer;
+        const int b = layer >> 1;
+        const float* G = (layer & 1) ? a.gx + (int64_t)(b + 1) * a.N * R2L_W : a.gt + (int64_t)b * a.N * R2L_W;
+        const float* A = (layer & 1) ? a.save_t + (int64_t)b * a.N * R2L_W : a.save_x + (int64_t)b * a.N * R2L_W;
+        const int64_t r0 = cu * DW_CHUNK;
+        int64_t r1 = cend * DW_CHUNK;
+        if (r1 > a.N) r1 = a.N;
+        const float* gp = G + (int64_t)wo * 128 + 4 * jl;
+        const float* ap = A + (int64_t)wi * 128 + 4 * jl;
+        // software pipeline: operands of k-step s+2 are loaded while k-step s computes
+        const int64_t nsteps = (r1 - r0 + 1) / 2;
+        f32x4 gq[3], aq[3];
+        auto ld = [&](int64_t s, f32x4& gv, f32x4& av) {
+            const int64_t r = r0 + 2 * s + hh;
+            if (s < nsteps && r < r1) {
+                gv = *reinterpret_cast<const f32x4*>(gp + r * R2L_W);
+                av = *reinterpret_cast<const f32x4*>(ap + r * R2L_W);
+            } else {
+                gv = f32x4{0.f, 0.f, 0.f, 0.f};
+                av = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        ld(0, gq[0], aq[0]);
+        ld(1, gq[1], aq[1]);
+        for (int64_t s = 0; s < nsteps; s += 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ld(s + k + 2, gq[(k + 2) % 3], aq[(k + 2) % 3]);
+                const f32x4 gv = gq[k], av = aq[k];
+#pragma unroll
+                for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+                    for (int ei = 0; ei < 4; ++ei)
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[eo], av[ei], acc[eo][ei], 0, 0, 0);
+                bsum += gv;
+            }
+        }
+        float* gw = a.grads + b_off_body_w(layer);
+        float* gb = a.grads + b_off_body_b(layer);
+        dw_flush(acc, bsum, gw, gb, wo, wi, lane);
+        u += cend - cu;
+    }
+}
+
+// =================================================================================================================
+// Head weight gradient:  dWh[o][k] = sum_r Gh[r][o] * PE[r][k]   (k in 1008, padded to 1024), dbh[o] = sum_r Gh[r][o]
+// The encoding is recomputed from the rays (never stored: 4 KB/ray).  Workgroup (kq, slice): kq selects 256 encoding
+// columns; wave w of it owns columns kq*256 + w*64 .. +63 (two 32-column tiles) x all 256 output rows (8 tiles).
+// Lane (i, h) evaluates encoding column k = base + i (+32) for ray 2s+h: one sin or cos (or the identity) per tile.
+// =================================================================================================================
+struct R2LDwHeadArgs {
+    const float* rays_o;
+    const float* rays_d;
+    const float* t_rand;
+    const float* ztab;
+    const float* emb;  // [N,1008] given encoding (module-boundary path) or nullptr -> recompute from the rays
+    const float* gh;   // [N,256] = gx[0]
+    float* grads;
+    int64_t N;
+    int64_t rays_per_wg;
+};
+
+__device__ __forceinline__ float pe_feature(int k, const float* __restrict__ o, const float* __restrict__ d,
+                                            const float* __restrict__ tr, const float* __restrict__ ztab, bool jitter) {
+    // column k of PositionalEmbedder's output for one ray: coord c = k/21 (sample c/3, axis c%3), slot f = k%21
+    if (k >= R2L_IN) return 0.f;
+    const int c = k / 21, f = k - 21 * c;
+    const int smp = c / 3, ax = c - 3 * smp;
+    float z = ztab[smp];
+    if (jitter) z = z + ztab[16 + smp] * tr[smp];
+    const float x = o[ax] + d[ax] * z;
+    if (f == 20) return x;
+    const int kk = f < 10 ? f : f - 10;
+    float s, co;
+    r2l_sincos(x * (float)(1 << kk), s, co);
+    return f < 10 ? s : co;
+}
+
+__global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hh = lane >> 5, jl = lane & 31;
+    const int kq = blockIdx.x & 3;
+    const int64_t slice = blockIdx.x >> 2;
+    const int64_t r0 = slice * a.rays_per_wg;
+    int64_t r1 = r0 + a.rays_per_wg;
+    if (r1 > a.N) r1 = a.N;
+    if (r0 >= r1) return;
+    const int kbase = kq * 256 + wave * 64;
+    const bool jitter = a.t_rand != nullptr && a.emb == nullptr;
+
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int eo = 0; eo < 8; ++eo)
+#pragma unroll
+        for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[eo][ei][c] = 0.f;
+    f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f};
+
+    const int64_t nsteps = (r1 - r0 + 1) / 2;
+    for (int64_t s = 0; s < nsteps; ++s) {
+        const int64_t r = r0 + 2 * s + hh;
+        const bool ok = r < r1;
+        const int64_t rr = ok ? r : r1 - 1;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gh + rr * R2L_W + 4 * jl);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gh + rr * R2L_W + 128 + 4 * jl);
+        const float* o = a.rays_o + (a.emb ? 0 : rr * 3);
+        const float* d = a.rays_d + (a.emb ? 0 : rr * 3);
+        const float* tr = jitter ? a.t_rand + rr * 16 : nullptr;
+        float p0, p1;
+        if (a.emb != nullptr) {
+            const int k0 = kbase + jl, k1 = kbase + 32 + jl;
+            p0 = k0 < R2L_IN ? a.emb[rr * R2L_IN + k0] : 0.f;
+            p1 = k1 < R2L_IN ? a.emb[rr * R2L_IN + k1] : 0.f;
+        } else {
+            p0 = pe_feature(kbase + jl, o, d, tr, a.ztab, jitter);
+            p1 = pe_feature(kbase + 32 + jl, o, d, tr, a.ztab, jitter);
+        }
+        f32x4 gg0 = g0, gg1 = g1;
+        if (!ok) {
+            gg0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            gg1 = gg0;
+            p0 = 0.f;
+            p1 = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg0[e], p0, acc[e][0], 0, 0, 0);
+            acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg0[e], p1, acc[e][1], 0, 0, 0);
+            acc[4 + e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg1[e], p0, acc[4 + e][0], 0, 0, 0);
+            acc[4 + e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg1[e], p1, acc[4 + e][1], 0, 0, 0);
+        }
+        bs0 += gg0;
+        bs1 += gg1;
+    }
+    // flush: output row o = half*128 + 4*ro + e, encoding column k = kbase + ei*32 + jl
+    float* gw = a.grads;  // head.0.weight is first in the flat buffer, [256][1008]
+#pragma unroll
+    for (int eo = 0; eo < 8; ++eo)
+#pragma unroll
+        for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int ro = (c & 3) + 8 * (c >> 2) + 4 * hh;
+                const int o = (eo >> 2) * 128 + 4 * ro + (eo & 3);
+                const int k = kbase + ei * 32 + jl;
+                if (k < R2L_IN) atomicAdd(gw + (int64_t)o * R2L_IN + k, acc[eo][ei][c]);
+            }
+    if (kq == 0 && wave == 0) {
+        float* gb = a.grads + b_off_head_b();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s0 = bs0[e] + __shfl_xor(bs0[e], 32);
+            const float s1 = bs1[e] + __shfl_xor(bs1[e], 32);
+            if (hh == 0) {
+                atomicAdd(gb + 4 * jl + e, s0);
+                atomicAdd(gb + 128 + 4 * jl + e, s1);
+            }
+        }
+    }
+}
+
+// =================================================================================================================
+// Tail gradients: dWt[c][f] = sum_r dpre[r][c] * (x_n[r][f] + x_0[r][f]),  dbt[c] = sum_r dpre[r][c]
+// =================================================================================================================
+__global__ __launch_bounds__(256) void r2l_dw_tail_kernel(const float* __restrict__ dpre, const float* __restrict__ x0,
+                                                          const float* __restrict__ xn, float* __restrict__ grads,
+                                                          int n_block, int64_t N, int64_t rays_per_wg) {
+    const int f = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rays_per_wg;
+    int64_t r1 = r0 + rays_per_wg;
+    if (r1 > N) r1 = N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float y = xn[r * R2L_W + f] + x0[r * R2L_W + f];
+        const float d0 = dpre[r * 3 + 0], d1 = dpre[r * 3 + 1], d2 = dpre[r * 3 + 2];
+        s0 = __builtin_fmaf(d0, y, s0);
+        s1 = __builtin_fmaf(d1, y, s1);
+        s2 = __builtin_fmaf(d2, y, s2);
+        b0 += d0; b1 += d1; b2 += d2;
+    }
+    float* gw = grads + b_off_tail_w(n_block);
+    atomicAdd(gw + 0 * R2L_W + f, s0);
+    atomicAdd(gw + 1 * R2L_W + f, s1);
+    atomicAdd(gw + 2 * R2L_W + f, s2);
+    if (f == 0 && r0 < r1) {
+        float* gb = grads + b_off_tail_b(n_block);
+        atomicAdd(gb + 0, b0);
+        atomicAdd(gb + 1, b1);
+        atomicAdd(gb + 2, b2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
+
+extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                            const float* emb, const float* rgb, const float* target, const float* drgb,
+                            const float* save_x, const float* save_t,
+                            const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
+                            float* gx, float* gt, float* sqerr_partial, float* grads, int64_t N, void* stream_) {
+    if (N <= 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+    }
+    // 1. dX chain
+    {
+        R2LBwdArgs a{};
+        a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t; a.wstream = wstream_bwd;
+        a.params = params; a.n_block = n_block; a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt;
+        a.sqerr_partial = sqerr_partial; a.N = N;
+        const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+        hipLaunchKernelGGL(r2l_bwd_chain_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+        R2L_CHECK(hipGetLastError());
+    }
+    // 2. body weight gradients
+    if (n_block > 0) {
+        R2LDwArgs a{};
+        a.save_x = save_x; a.save_t = save_t; a.gx = gx; a.gt = gt; a.grads = grads; a.n_block = n_block; a.N = N;
+        a.units_per_layer = (N + DW_CHUNK - 1) / DW_CHUNK;
+        const int64_t total = a.units_per_layer * 2 * n_block;
+        int64_t wgs = n_cu;
+        if (wgs > total) wgs = total;
+        a.units_per_wg = (total + wgs - 1) / wgs;
+        wgs = (total + a.units_per_wg - 1) / a.units_per_wg;
+        hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        R2L_CHECK(hipGetLastError());
+    }
+    // 3. head weight gradient
+    {
+        R2LDwHeadArgs a{};
+        a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab; a.emb = emb; a.gh = gx; a.grads = grads; a.N = N;
+        int64_t slices = n_cu / 4;
+        if (slices < 1) slices = 1;
+        int64_t per = (N + slices - 1) / slices;
+        per = (per + 1) & ~(int64_t)1;  // even: a k-step pairs rays 2s, 2s+1
+        if (per < 2) per = 2;
+        slices = (N + per - 1) / per;
+        a.rays_per_wg = per;
+        hipLaunchKernelGGL(r2l_dw_head_kernel, dim3((unsigned)(slices * 4)), dim3(256), 0, stream, a);
+        R2L_CHECK(hipGetLastError());
+    }
+    // 4. tail gradients
+    {
+        int64_t wgs = 2 * n_cu;
+        int64_t per = (N + wgs - 1) / wgs;
+        if (per < 1) per = 1;
+        wgs = (N + per - 1) / per;
+        hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, save_x,
+                           save_x + (int64_t)n_block * N * R2L_W, grads, n_block, N, per);
+        R2L_CHECK(hipGetLastError());
+    }
+    return 0;
+}

@@ -1,0 +1,213 @@
+"""Distillation training step of the R2L student on one GPU per process (reference loop: main.py:1175-1425).
+
+    rgb = model(embed(sample_train(o, d, perturb)));  loss = mean((rgb - target)^2) * lw_rgb
+    optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+becomes four HIP stages on flat fp32 buffers (include/r2l_hip.h): fused forward with activation stash ->
+r2l_backward (dX chain, dW GEMMs, head/tail gradients) -> [one RCCL all-reduce of the flat 23.67 MB gradient when
+world_size > 1] -> fused Adam -> re-pack of the MFMA weight streams.  No autograd graph, no anomaly mode.
+"""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .engine import N_SAMPLE, W, _ptr, _stream, get_engine
+
+
+class R2LTrainer:
+    """Owns gradient / Adam-moment / activation-stash buffers for one NeRF_v3_2 and runs fused training steps.
+
+    Data parallel: every rank holds identical parameters, calls step() on its own ray shard (equal sizes), and the
+    flat gradient is summed across ranks with ONE all-reduce (RCCL over xGMI on GPUs; gloo on CPU tensors in tests),
+    then averaged inside the Adam kernel — identical to the reference's single global mean (main.py:1377) that
+    nn.DataParallel computed on GPU 0.
+    """
+
+    def __init__(self, module, point_sampler, betas=(0.9, 0.999), eps=1e-8, lw_rgb=1.0, process_group=None):
+        self.module = module
+        self.ps = point_sampler
+        self.eng = get_engine(module)
+        self.lib = self.eng.lib
+        self.betas, self.eps, self.lw_rgb = betas, eps, lw_rgb
+        self.pg = process_group
+        self.step_count = 0
+        self.cap = 0
+        self._alloc_state()
+
+    # ---- buffers --------------------------------------------------------------------------------------------------
+    def _alloc_state(self):
+        eng = self.eng
+        eng.ensure_packed()
+        dev, n = eng.device, eng.n_param
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.wstream_bwd = torch.empty(self.lib.r2l_bwd_stream_floats(eng.n_block), dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._bwd_packed = None
+
+    def _ensure_capacity(self, n):
+        if n <= self.cap:
+            return
+        dev, nb = self.eng.device, self.eng.n_block
+        self.cap = n
+        f = dict(dtype=torch.float32, device=dev)
+        self.save_x = torch.empty((nb + 1) * n * W, **f)
+        self.save_t = torch.empty(max(nb, 1) * n * W, **f)
+        self.gx = torch.empty((nb + 1) * n * W, **f)
+        self.gt = torch.empty(max(nb, 1) * n * W, **f)
+        self.dpre = torch.empty(n * 3, **f)
+        self.sqerr = torch.empty(int(self.lib.r2l_num_tiles(n)), **f)
+
+    def _pack_bwd(self):
+        key = self.eng._packed_version
+        if self._bwd_packed != key:
+            _lib.check(self.lib.r2l_pack_backward(_ptr(self.eng.flat), self.eng.n_block, _ptr(self.wstream_bwd),
+                                                  _stream()), "r2l_pack_backward")
+            self._bwd_packed = key
+
+    # ---- one optimisation step --------------------------------------------------------------------------------------
+    def forward_backward(self, rays_o, rays_d, target, perturb=0., t_rand=None, zero_grad=True):
+        """Forward + backward on this rank's rays; leaves d(loss)/d(params) in self.grads. Returns rgb [N,3]."""
+        eng = self.eng
+        eng.ensure_packed()
+        self._pack_bwd()
+        n = rays_o.shape[0]
+        self._ensure_capacity(n)
+        rays_o = rays_o.contiguous().float()
+        rays_d = rays_d.contiguous().float()
+        target = target.contiguous().float()
+        if perturb > 0 and t_rand is None:
+            t_rand = torch.rand(n, N_SAMPLE, device=eng.device)
+        if perturb <= 0:
+            t_rand = None
+        ztab = eng.ztab(self.ps.z_vals, perturb)
+        rgb = eng.forward_rays(rays_o, rays_d, self.ps.z_vals, perturb, t_rand, save=(self.save_x, self.save_t))
+        if zero_grad:
+            self.grads.zero_()
+        grad_scale = 2.0 * self.lw_rgb / (3.0 * n)
+        _lib.check(
+            self.lib.r2l_backward(_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target),
+                                  None, _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat),
+                                  eng.n_block, grad_scale, _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt),
+                                  _ptr(self.sqerr), _ptr(self.grads), n, _stream()), "r2l_backward")
+        _lib.check(
+            self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
+                                     _ptr(self.loss_out), _stream()), "r2l_loss_finish")
+        return rgb
+
+    def world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.pg)
+        return 1
+
+    def allreduce_grads(self):
+        """ONE collective per step: sum of the flat fp32 gradient over ranks."""
+        if self.world() > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def adam(self, lr):
+        self.step_count += 1
+        eng = self.eng
+        _lib.check(
+            self.lib.r2l_adam_step(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                   eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                   1.0 / self.world(), _stream()), "r2l_adam_step")
+        eng.mark_dirty()
+
+    def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None):
+        """zero_grad + forward + backward + all-reduce + Adam.  Returns (rgb[N,3], loss_out[2] = [loss, psnr]) on
+        the device (no host sync)."""
+        rgb = self.forward_backward(rays_o, rays_d, target, perturb, t_rand)
+        self.allreduce_grads()
+        self.adam(lr)
+        return rgb, self.loss_out
+
+    # ---- torch.optim.Adam-compatible state (checkpoint surface: 'optimizer_state_dict', main.py:1528-1529) --------------
+    def optimizer_state_dict(self, lr):
+        state, off = {}, 0
+        for i, p in enumerate(self.eng.params):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {"lr": lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(self.eng.params)))}
+        return {"state": state if self.step_count > 0 else {}, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        off = 0
+        steps = [0]
+        for i, p in enumerate(self.eng.params):
+            n = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.append(int(float(st["step"])))
+            off += n
+        self.step_count = max(steps)
+
+
+def lr_schedule(step, lrate, lrate_decay, warmup_lr=""):
+    """Learning rate of iteration `step` (1-based): linear warm-up 'start_lr,end_iter' then
+    lrate * 0.1^((step-end_iter)/(lrate_decay*1000))  — the reference's schedule, main.py:1181-1193."""
+    decay_steps = lrate_decay * 1000
+    if warmup_lr:
+        start_lr, end_iter = [float(v) for v in warmup_lr.split(",")]
+        if step < end_iter:
+            return (lrate - start_lr) / end_iter * step + start_lr
+        return lrate * (0.1**((step - end_iter) / decay_steps))
+    return lrate * (0.1**(step / decay_steps))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hooks used by __graft_entry__.smoke() and bench.py
+# ---------------------------------------------------------------------------------------------------------------
+def smoke_check(net, ps, sd, O):
+    """One tiny fused training step on cuda:0 checked against the oracle's autograd + Adam."""
+    g = torch.Generator().manual_seed(1)
+    n = 300
+    o = torch.randn(n, 3, generator=g) * 1.5
+    d = torch.randn(n, 3, generator=g)
+    tgt = torch.rand(n, 3, generator=g)
+    tr = R2LTrainer(net, ps)
+    emb = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
+    loss_ref, _, grads_ref = O.r2l_loss_and_grads(sd, emb, tgt)
+    tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda())
+    flat_ref = torch.cat([grads_ref[k].reshape(-1) for k in sd])
+    gerr = (tr.grads.cpu() - flat_ref).abs().max().item() / flat_ref.abs().max().item()
+    lerr = abs(tr.loss_out[0].item() - loss_ref.item())
+    print("[smoke] train step %d rays: |loss-oracle| = %.2e, max|grad-oracle|/max|grad| = %.2e" % (n, lerr, gerr))
+    assert lerr < 1e-6 and gerr < 1e-3, (lerr, gerr)
+
+
+def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak):
+    """Training leg of bench.py: K fused steps of `a.train_rays` rays per GPU (synthetic [o,d,rgb] rows as in the
+    `.npy` shards, main.py:1305-1311), RCCL all-reduce when world > 1."""
+    n = a.train_rays
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(device)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(device)
+    tgt = torch.rand(n, 3, generator=g).to(device)
+    tr = R2LTrainer(net, ps)
+    steps = max(2, min(a.steps, 10))
+    warm = max(1, min(a.warmup, 2))
+
+    def train_step(i):
+        tr.step(o, d, tgt, lr_schedule(i + 1, 5e-4, 500, "0.0001,200"), perturb=1.0)
+
+    dt, step_ms = timed(train_step, steps, warm, distributed, device)
+    achieved = n * flop_per_ray / (step_ms * 1e-3) / 1e12
+    return {"value": n * steps * world / dt, "unit": "rays/s", "steps": steps, "warmup": warm,
+            "ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": n,
+            "workload": "distillation step (fwd + bwd + Adam + weight re-pack), %d rays/GPU/step, perturb=1; "
+                        "grad all-reduce over %d rank(s)" % (n, world),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "flop_per_ray": flop_per_ray, "step_ms_device": step_ms},
+            "final_loss": tr.loss_out[0].item()}
