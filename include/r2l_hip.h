@@ -75,6 +75,37 @@ int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 /* out2[0] = inv_denom * sum(sqerr_partial) (= img2mse * lw_rgb, helpers:19), out2[1] = psnr (helpers:20). */
 int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_denom, float* out2, void* stream);
 
+/* ---- NeRF teacher (pseudo-data generation) --------------------------------------------------------------------------
+ * tparams: flat fp32 state_dict-order buffer of NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+ * (model/nerf_raybased.py:357-375, built at utils/create_data.py:251-265): pts_linears.{0..7}, views_linears.0,
+ * feature_linear, alpha_linear, rgb_linear. */
+int64_t r2l_teacher_param_count(void);     /* 593 924 */
+int64_t r2l_teacher_stream_floats(void);
+int r2l_pack_teacher(const float* tparams, float* wstream, void* stream);
+
+/* raw[R,S,4] = network_query_fn(pts = o + d*z, viewdirs, NeRF): run_network (create_data.py:55-77: embed xyz L=10 and
+ * dirs L=4, helpers:24-74; the netchunk loop disappears) + NeRF.forward (model/nerf_raybased.py:377-401), fused. */
+int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
+                    const float* wstream, const float* tparams, float* raw, int64_t R, int S, void* stream);
+
+/* z_out[R,S] = near*(1-t)+far*t, with stratified jitter when t_rand[R,S] != NULL (create_data.py:457-482).
+ * near/far: per-ray values read at near[r*nf_stride], far[r*nf_stride]; ttab[2S] = t_vals ++ (1 - t_vals). */
+int r2l_stratified_z(const float* near, const float* far, int nf_stride, const float* ttab, const float* t_rand,
+                     float* z_out, int64_t R, int S, void* stream);
+
+/* raw2outputs (create_data.py:335-402 == main.py:556-621 == model/nerf_raybased.py:226-295).  noise[R,S] (already
+ * scaled by raw_noise_std) and weights[R,S] are optional (NULL).  1 <= S <= 256. */
+int r2l_raw2outputs(const float* raw, const float* z, const float* rays_d, const float* noise, int white_bkgd,
+                    float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map, int64_t R, int S,
+                    void* stream);
+
+/* Hierarchical sampling on the GPU (the reference round-trips through the CPU, create_data.py:505-515):
+ *   z_samples[R,NI] = sample_pdf(.5*(z[1:]+z[:-1]), weights[:,1:-1], NI, u)     (helpers:283-330)
+ *   z_all[R,S+NI]   = sort(cat[z, z_samples])  ;  z_std[R] = std(z_samples, unbiased=False)  (optional)
+ * u: the uniforms, read at u[r*u_stride + i] (u_stride = 0: one shared row, e.g. det=True's linspace(0,1,NI)). */
+int r2l_sample_pdf_sort(const float* z, const float* weights, const float* u, int64_t u_stride, float* z_samples,
+                        float* z_all, float* z_std, int64_t R, int S, int NI, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

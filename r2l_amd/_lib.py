@@ -29,6 +29,13 @@ SIGNATURES = {
     "r2l_backward": (_i, [_p] * 12 + [_i, _f] + [_p] * 5 + [_l, _p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
     "r2l_loss_finish": (_i, [_p, _l, _f, _p, _p]),
+    "r2l_teacher_param_count": (_l, []),
+    "r2l_teacher_stream_floats": (_l, []),
+    "r2l_pack_teacher": (_i, [_p, _p, _p]),
+    "r2l_teacher_mlp": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
+    "r2l_stratified_z": (_i, [_p, _p, _i, _p, _p, _p, _l, _i, _p]),
+    "r2l_raw2outputs": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p]),
+    "r2l_sample_pdf_sort": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
 }
 
 _lib = None

@@ -1,0 +1,254 @@
+// r2l_render.hip — the volumetric-render glue of the NeRF teacher for gfx950: HBM-bound, one wavefront per ray,
+// wave shuffles for the scans/reductions, no host round trip (the reference moves sample_pdf to the CPU:
+// /root/reference/utils/create_data.py:506-511).
+//   r2l_stratified_z   : z_vals = near(1-t)+far t, stratified jitter            (create_data.py:457-482)
+//   r2l_raw2outputs    : alpha compositing                                       (create_data.py:335-402)
+//   r2l_sample_pdf_sort: inverse-CDF importance sampling + merge-sort of depths  (helpers:283-330, create_data.py:505-515)
+#include "r2l_common.h"
+#include <math.h>
+
+#define MAX_CH 4  // samples per lane: supports S <= 256
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void r2l_stratified_z_kernel(const float* __restrict__ near, const float* __restrict__ far, int nf_stride,
+                                        const float* __restrict__ ttab, const float* __restrict__ t_rand,
+                                        float* __restrict__ z_out, int64_t R, int S) {
+    // ttab[0..S) = t_vals, ttab[S..2S) = 1 - t_vals (both computed by the host exactly as torch does)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R * S; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / S;
+        const int s = (int)(i % S);
+        const float n = near[r * nf_stride], f = far[r * nf_stride];
+        auto zv = [&](int k) { return n * ttab[S + k] + f * ttab[k]; };
+        float z = zv(s);
+        if (t_rand != nullptr) {
+            const float lo = s == 0 ? z : .5f * (z + zv(s - 1));
+            const float up = s == S - 1 ? z : .5f * (zv(s + 1) + z);
+            z = lo + (up - lo) * t_rand[i];
+        }
+        z_out[i] = z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// raw2outputs: one wave per ray, lane l owns samples [l*CH, l*CH+CH).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void r2l_raw2outputs_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                              const float* __restrict__ rays_d,
+                                                              const float* __restrict__ noise, int white_bkgd,
+                                                              float* __restrict__ rgb_map, float* __restrict__ disp_map,
+                                                              float* __restrict__ acc_map, float* __restrict__ weights,
+                                                              float* __restrict__ depth_map, int64_t R, int S) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const int CH = (S + 63) / 64;
+    const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);  // torch.norm(rays_d[..., None, :], dim=-1)
+    const float* zr = z + ray * S;
+    const float* rr = raw + ray * (int64_t)S * 4;
+
+    float al[MAX_CH], col[MAX_CH][3], zz[MAX_CH], pl = 1.0f;  // pl = product of (1-alpha+1e-10) over this lane's chunk
+#pragma unroll
+    for (int c = 0; c < MAX_CH; ++c) {
+        const int s = lane * CH + c;
+        al[c] = 0.f; zz[c] = 0.f; col[c][0] = col[c][1] = col[c][2] = 0.f;
+        if (c < CH && s < S) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rr + 4 * s);
+            const float z0 = zr[s];
+            float dist = (s + 1 < S) ? zr[s + 1] - z0 : 1e10f;
+            dist = dist * dn;
+            float sg = v[3];
+            if (noise != nullptr) sg += noise[ray * S + s];
+            al[c] = 1.0f - expf(-fmaxf(sg, 0.f) * dist);
+            zz[c] = z0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) col[c][k] = 1.0f / (1.0f + expf(-v[k]));
+            pl *= (1.0f - al[c]) + 1e-10f;
+        }
+    }
+    // exclusive product scan across lanes
+    float incl = pl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off);
+        if (lane >= off) incl *= o;
+    }
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.0f;
+    float sr = 0.f, sg_ = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAX_CH; ++c) {
+        const int s = lane * CH + c;
+        if (c < CH && s < S) {
+            const float w = al[c] * T;
+            if (weights != nullptr) weights[ray * S + s] = w;
+            sr += w * col[c][0]; sg_ += w * col[c][1]; sb += w * col[c][2];
+            sd += w * zz[c]; sa += w;
+            T *= (1.0f - al[c]) + 1e-10f;
+        }
+    }
+    sr = wave_sum(sr); sg_ = wave_sum(sg_); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+    if (lane == 0) {
+        const float q = sd / sa;
+        const float m = (q != q) ? q : fmaxf(1e-10f, q);  // torch.max propagates NaN (empty ray: 0/0)
+        disp_map[ray] = 1.0f / m;
+        acc_map[ray] = sa;
+        depth_map[ray] = sd;
+        const float bg = white_bkgd ? (1.0f - sa) : 0.f;
+        rgb_map[ray * 3 + 0] = sr + bg;
+        rgb_map[ray * 3 + 1] = sg_ + bg;
+        rgb_map[ray * 3 + 2] = sb + bg;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sample_pdf + sort-merge.  One wave per ray.  S coarse samples (S <= 64), NI new samples (NI <= 192, S+NI <= 256).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* __restrict__ z, const float* __restrict__ wts,
+                                                                  const float* __restrict__ u, int64_t u_stride,
+                                                                  float* __restrict__ z_samples, float* __restrict__ z_all,
+                                                                  float* __restrict__ z_std, int64_t R, int S, int NI) {
+    __shared__ float s_cdf[4][64];
+    __shared__ float s_bins[4][64];
+    __shared__ float s_sort[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    const bool live = ray < R;  // idle waves of the last block keep hitting the block barriers on a clamped ray
+    if (!live) ray = R - 1;
+    const float* zr = z + ray * S;
+    const int nb = S - 1;   // bins = z_mid (S-1 edges)
+    const int nw = S - 2;   // weights[..., 1:-1]
+    float* cdf = s_cdf[wv];
+    float* bins = s_bins[wv];
+    // bins and (weights + 1e-5)
+    float wl = 0.f;
+    if (lane < nb) bins[lane] = .5f * (zr[lane + 1] + zr[lane]);
+    if (lane < nw) wl = wts[ray * S + lane + 1] + 1e-5f;
+    const float total = wave_sum(wl);
+    cdf[lane] = wl / total;  // pdf, staged
+    __syncthreads();
+    if (lane == 0) {  // torch.cumsum is a left-to-right fp32 sum; keep that order (cdf[0] = 0)
+        float run = 0.f, prev = 0.f;
+        for (int k = 0; k < nw; ++k) {
+            const float pk = cdf[k];
+            cdf[k] = prev;
+            run += pk;
+            prev = run;
+        }
+        cdf[nw] = prev;
+    }
+    __syncthreads();
+    // inverse CDF for this lane's u's
+    float sum1 = 0.f;
+    float samp[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int i = lane + 64 * m;
+        samp[m] = 0.f;
+        if (i < NI) {
+            const float uu = u[ray * u_stride + i];
+            // searchsorted(cdf[0..nb), uu, right=True): number of entries <= uu
+            int lo = 0, hi = nb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+            }
+            const int below = lo - 1 > 0 ? lo - 1 : 0;
+            const int above = lo < nb - 1 ? lo : nb - 1;
+            const float c0 = cdf[below], c1 = cdf[above];
+            const float b0 = bins[below], b1 = bins[above];
+            float denom = c1 - c0;
+            denom = denom < 1e-5f ? 1.0f : denom;
+            const float t = (uu - c0) / denom;
+            samp[m] = b0 + t * (b1 - b0);
+            if (live) z_samples[ray * NI + i] = samp[m];
+            sum1 += samp[m];
+        }
+    }
+    // z_std = std(z_samples, unbiased=False)
+    const float mean = wave_sum(sum1) / (float)NI;
+    float sq = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+        if (lane + 64 * m < NI) sq += (samp[m] - mean) * (samp[m] - mean);
+    sq = wave_sum(sq);
+    if (live && lane == 0 && z_std != nullptr) z_std[ray] = sqrtf(sq / (float)NI);
+    // bitonic sort of [z (S), samples (NI), +inf padding] in LDS
+    float* ss = s_sort[wv];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = lane + 64 * m;
+        ss[i] = i < S ? zr[i] : INFINITY;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int i = lane + 64 * m;
+        if (i < NI) ss[S + i] = samp[m];
+    }
+    __syncthreads();
+    for (int k = 2; k <= 256; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int tix = lane + 64 * m;                  // 128 compare-exchange pairs
+                const int i = ((tix & ~(j - 1)) << 1) | (tix & (j - 1));
+                const int p = i | j;
+                const float a0 = ss[i], a1 = ss[p];
+                const bool up = (i & k) == 0;
+                if ((a0 > a1) == up) { ss[i] = a1; ss[p] = a0; }
+            }
+            __syncthreads();
+        }
+    const int tot = S + NI;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = lane + 64 * m;
+        if (live && i < tot) z_all[ray * tot + i] = ss[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int r2l_stratified_z(const float* near, const float* far, int nf_stride, const float* ttab,
+                                const float* t_rand, float* z_out, int64_t R, int S, void* stream) {
+    if (R <= 0) return 0;
+    int64_t blocks = (R * S + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(r2l_stratified_z_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, near, far,
+                       nf_stride, ttab, t_rand, z_out, R, S);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int r2l_raw2outputs(const float* raw, const float* z, const float* rays_d, const float* noise, int white_bkgd,
+                               float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                               int64_t R, int S, void* stream) {
+    if (R <= 0) return 0;
+    if (S < 1 || S > 64 * MAX_CH) { r2l_set_error("r2l_raw2outputs: S out of range [1,256]", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
+    hipLaunchKernelGGL(r2l_raw2outputs_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z,
+                       rays_d, noise, white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map, R, S);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int r2l_sample_pdf_sort(const float* z, const float* weights, const float* u, int64_t u_stride,
+                                   float* z_samples, float* z_all, float* z_std, int64_t R, int S, int NI,
+                                   void* stream) {
+    if (R <= 0) return 0;
+    if (S < 3 || S > 64 || NI < 1 || NI > 192 || S + NI > 256) {
+        r2l_set_error("r2l_sample_pdf_sort: need 3<=S<=64, 1<=NI<=192, S+NI<=256", hipErrorInvalidValue);
+        return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(r2l_sample_pdf_sort_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z,
+                       weights, u, u_stride, z_samples, z_all, z_std, R, S, NI);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}

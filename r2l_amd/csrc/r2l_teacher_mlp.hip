@@ -1,0 +1,302 @@
+// r2l_teacher_mlp.hip — fused NeRF-teacher point network for gfx950, replacing run_network + NeRF.forward
+// (/root/reference/utils/create_data.py:55-77, model/nerf_raybased.py:377-401; embedder helpers:24-74):
+//   pts = o + d*z  ->  embed xyz (63) , embed viewdir (27)  ->  8 x Linear(.,256)+ReLU with the input re-concatenated
+//   after layer 4 (K = 319)  ->  alpha = Linear(256,1), feature = Linear(256,256)
+//   ->  Linear(283,128)+ReLU on [feature, dir-embedding]  ->  rgb = Linear(128,3)   ->  raw[point] = (r,g,b,sigma)
+// Same register-resident chain as the student (r2l_common.h): one wavefront = 32 consecutive sample points, exact-fp32
+// MFMA, weights pre-packed into ONE stream in consumption order (r2l_pack_teacher below).
+#include "r2l_common.h"
+
+#define T_W 256
+#define T_XYZ 63
+#define T_DIR 27
+#define T_PE_STEPS 36   // xyz embedding k-steps per half-wave (30 trig + 3 identity + 3 pad)  -> 9 groups
+#define T_PE_GROUPS 9
+#define T_DIR_STEPS 16  // dir embedding k-steps per half-wave (12 trig + 3 identity + 1 pad)  -> 4 groups of 4 tiles
+
+// ---- flat parameter offsets, state_dict order of NeRF(D=8,W=256,63,27,use_viewdirs=True) ------------------------------
+struct TOff {
+    int64_t w[8], b[8], views_w, views_b, feat_w, feat_b, alpha_w, alpha_b, rgb_w, rgb_b, total;
+};
+__host__ __device__ static inline TOff t_offsets() {
+    TOff o;
+    int64_t p = 0;
+    for (int i = 0; i < 8; ++i) {
+        const int fin = i == 0 ? T_XYZ : (i == 5 ? T_W + T_XYZ : T_W);
+        o.w[i] = p; p += (int64_t)T_W * fin;
+        o.b[i] = p; p += T_W;
+    }
+    o.views_w = p; p += (int64_t)128 * (T_W + T_DIR);
+    o.views_b = p; p += 128;
+    o.feat_w = p; p += (int64_t)T_W * T_W;
+    o.feat_b = p; p += T_W;
+    o.alpha_w = p; p += T_W;
+    o.alpha_b = p; p += 1;
+    o.rgb_w = p; p += 3 * 128;
+    o.rgb_b = p; p += 3;
+    o.total = p;
+    return o;
+}
+
+// xyz-embedding column fed by k-step s of half-wave h (or -1 = zero padding):
+//   s < 30 : frequency 5h + s/6, slot s%6 (0..2 sin x,y,z ; 3..5 cos x,y,z);  s = 30..32 : identity (half 0 only)
+__host__ __device__ static inline int t_xyz_col(int s, int h) {
+    if (s < 30) return 3 + (5 * h + s / 6) * 6 + (s % 6);
+    if (s < 33) return h == 0 ? s - 30 : -1;
+    return -1;
+}
+__host__ __device__ static inline int t_dir_col(int s, int h) {
+    if (s < 12) return 3 + (2 * h + s / 6) * 6 + (s % 6);
+    if (s < 15) return h == 0 ? s - 12 : -1;
+    return -1;
+}
+
+// stream layout (units: load-groups of 8 float4 per lane = 2048 floats)
+#define TG_L0 0
+#define TG_BODY (TG_L0 + T_PE_GROUPS)                 // layers 1..4: 4 x 32
+#define TG_L5PE (TG_BODY + 4 * 32)
+#define TG_L5H (TG_L5PE + T_PE_GROUPS)
+#define TG_L67F (TG_L5H + 32)                         // layers 6, 7, feature: 3 x 32
+#define TG_VIEWS (TG_L67F + 3 * 32)                   // 32 k-groups x 4 tiles = 16 load-groups
+#define TG_VDIR (TG_VIEWS + 16)                       // 4 k-groups x 4 tiles = 2 load-groups
+#define TG_TOTAL (TG_VDIR + 2)
+
+__global__ void r2l_pack_teacher_kernel(const float* __restrict__ params, float* __restrict__ out) {
+    const TOff off = t_offsets();
+    const int64_t total = (int64_t)TG_TOTAL * R2L_GROUP_FLOATS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + R2L_STREAM_PAD;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= total) { out[i] = 0.f; continue; }
+        const int gidx = (int)(i / R2L_GROUP_FLOATS);
+        const int rem = (int)(i % R2L_GROUP_FLOATS);
+        const int slot = rem >> 8, lane = (rem & 255) >> 2, j = rem & 3;
+        const int h = lane >> 5, jl = lane & 31;
+        float v = 0.f;
+        if (gidx < TG_BODY || (gidx >= TG_L5PE && gidx < TG_L5H)) {  // xyz-embedding part of layer 0 / layer 5
+            const bool l5 = gidx >= TG_L5PE;
+            const int g = l5 ? gidx - TG_L5PE : gidx;
+            const int col = t_xyz_col(4 * g + j, h);
+            const int o = 32 * slot + jl;
+            if (col >= 0) v = l5 ? params[off.w[5] + (int64_t)o * (T_W + T_XYZ) + col] : params[off.w[0] + (int64_t)o * T_XYZ + col];
+        } else if (gidx < TG_VIEWS) {  // 256 -> 256 layers
+            int layer, G;
+            bool l5h = false;
+            if (gidx < TG_L5PE) { layer = 1 + (gidx - TG_BODY) / 32; G = (gidx - TG_BODY) % 32; }
+            else if (gidx < TG_L67F) { layer = 5; G = gidx - TG_L5H; l5h = true; }
+            else { layer = 6 + (gidx - TG_L67F) / 32; G = (gidx - TG_L67F) % 32; }  // 6, 7, 8 (= feature_linear)
+            const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
+            const int o = 32 * slot + jl;
+            if (layer == 8) v = params[off.feat_w + (int64_t)o * T_W + in];
+            else if (l5h) v = params[off.w[5] + (int64_t)o * (T_W + T_XYZ) + T_XYZ + in];
+            else v = params[off.w[layer] + (int64_t)o * T_W + in];
+        } else if (gidx < TG_VDIR) {  // views layer, feature part: slot = (k-group parity)*4 + tile
+            const int G = 2 * (gidx - TG_VIEWS) + (slot >> 2), tile = slot & 3;
+            const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
+            const int o = 32 * tile + jl;
+            v = params[off.views_w + (int64_t)o * (T_W + T_DIR) + in];
+        } else {  // views layer, direction-embedding part
+            const int g = 2 * (gidx - TG_VDIR) + (slot >> 2), tile = slot & 3;
+            const int col = t_dir_col(4 * g + j, h);
+            const int o = 32 * tile + jl;
+            if (col >= 0) v = params[off.views_w + (int64_t)o * (T_W + T_DIR) + T_W + col];
+        }
+        out[i] = v;
+    }
+}
+
+struct TeacherArgs {
+    const float* rays_o;    // [R,3]
+    const float* rays_d;    // [R,3]
+    const float* viewdirs;  // [R,3] unit view directions (render(): d / |d|, create_data.py:154-157)
+    const float* z;         // [R,S]
+    const float* wstream;
+    const float* params;
+    float* raw;             // [R,S,4]
+    int64_t n_pts;          // R*S
+    int S;
+};
+
+// k-steps of the xyz embedding for this lane's half-wave
+__device__ __forceinline__ void t_xyz_feats(const float (&p)[3], int h, float (&f)[T_PE_STEPS]) {
+    const float base = h ? 32.0f : 1.0f;
+#pragma unroll
+    for (int fl = 0; fl < 5; ++fl)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) r2l_sincos(p[ax] * (base * (float)(1 << fl)), f[fl * 6 + ax], f[fl * 6 + 3 + ax]);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) f[30 + ax] = h ? 0.f : p[ax];
+    f[33] = f[34] = f[35] = 0.f;
+}
+
+__device__ __forceinline__ void t_pe_gemm(f32x16 (&acc)[R2L_NT], const float (&f)[T_PE_STEPS], WStream& ws) {
+#pragma unroll
+    for (int g = 0; g < T_PE_GROUPS; ++g) {
+        f32x4 w[R2L_NT];
+        ws.advance(w);
+        mfma_group(acc, w, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+        r2l_pin_group_schedule();
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherArgs a) {
+    const TOff off = t_offsets();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile * R2L_TILE_RAYS >= a.n_pts) return;
+    const int64_t pt = tile * R2L_TILE_RAYS + (lane & 31);
+    const bool valid = pt < a.n_pts;
+    const int64_t pc = valid ? pt : a.n_pts - 1;
+    const int64_t ray = pc / a.S;
+
+    float p[3], vd[3];
+    {
+        const float z = a.z[pc];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p[k] = a.rays_o[ray * 3 + k] + a.rays_d[ray * 3 + k] * z;  // create_data.py:484, mul/add rounded separately
+            vd[k] = a.viewdirs[ray * 3 + k];
+        }
+    }
+    WStream ws;
+    ws.init(a.wstream, lane);
+    const float* P = a.params;
+
+    f32x16 x[R2L_NT], t[R2L_NT];
+    // layer 0
+    {
+        float f[T_PE_STEPS];
+        t_xyz_feats(p, h, f);
+        add_bias<false>(x, P + off.b[0], h);
+        t_pe_gemm(x, f, ws);
+        relu_inplace(x);
+    }
+    // (L1,L2) (L3,L4) (L5,L6) (L7,feature): t = relu(W_odd x [+ W5pe pe]); x = act(W_even t)
+    float alpha = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        // bias offsets of layers 2k+1 / 2k+2 without indexing the offset table dynamically (it would go to scratch)
+        const int64_t b_odd = k == 0 ? off.b[1] : k == 1 ? off.b[3] : k == 2 ? off.b[5] : off.b[7];
+        const int64_t b_even = k == 0 ? off.b[2] : k == 1 ? off.b[4] : k == 2 ? off.b[6] : off.feat_b;
+        add_bias<false>(t, P + b_odd, h);
+        if (k == 2) {
+            float f[T_PE_STEPS];
+            t_xyz_feats(p, h, f);
+            t_pe_gemm(t, f, ws);
+        }
+        gemm256(t, x, ws);
+        relu_inplace(t);
+        if (k == 3) {  // alpha_linear on the output of layer 7
+            float acc = 0.f;
+#pragma unroll
+            for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(P + off.alpha_w + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(wv[j], t[T][4 * q + j], acc);
+                }
+            acc += __shfl_xor(acc, 32);
+            alpha = acc + P[off.alpha_b];
+        }
+        add_bias<false>(x, P + b_even, h);
+        gemm256(x, t, ws);
+        if (k != 3) relu_inplace(x);
+    }
+    // views layer: v[128] = relu(Wv [feature, dir-embedding] + bv)   (4 output tiles)
+    f32x16 v[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(P + off.views_b + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[T][4 * q + j] = b[j];
+        }
+#pragma unroll
+    for (int G2 = 0; G2 < 16; ++G2) {
+        f32x4 w[R2L_NT];
+        ws.advance(w);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int G = 2 * G2 + half, T = G >> 2, q = (G & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    v[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[half * 4 + tt][j], x[T][q + j], v[tt], 0, 0, 0);
+        }
+        r2l_pin_group_schedule();
+    }
+    {
+        float fd[T_DIR_STEPS];
+        const float base = h ? 4.0f : 1.0f;
+#pragma unroll
+        for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax)
+                r2l_sincos(vd[ax] * (base * (float)(1 << fl)), fd[fl * 6 + ax], fd[fl * 6 + 3 + ax]);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) fd[12 + ax] = h ? 0.f : vd[ax];
+        fd[15] = 0.f;
+#pragma unroll
+        for (int G2 = 0; G2 < 2; ++G2) {
+            f32x4 w[R2L_NT];
+            ws.advance(w);
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        v[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[half * 4 + tt][j], fd[(2 * G2 + half) * 4 + j],
+                                                                     v[tt], 0, 0, 0);
+            r2l_pin_group_schedule();
+        }
+    }
+    // rgb = Wrgb relu(v) + b
+    float acc3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 wv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(P + off.rgb_w + c * 128 + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = fmaxf(v[T][4 * q + j], 0.f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc3[c] = __builtin_fmaf(wv[c][j], y, acc3[c]);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc3[c] = acc3[c] + __shfl_xor(acc3[c], 32) + P[off.rgb_b + c];
+    if (valid && h == 0) {
+        const f32x4 o4 = {acc3[0], acc3[1], acc3[2], alpha};
+        *reinterpret_cast<f32x4*>(a.raw + pt * 4) = o4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t r2l_teacher_param_count(void) { return t_offsets().total; }
+extern "C" int64_t r2l_teacher_stream_floats(void) { return (int64_t)TG_TOTAL * R2L_GROUP_FLOATS + R2L_STREAM_PAD; }
+
+extern "C" int r2l_pack_teacher(const float* params, float* wstream, void* stream) {
+    hipLaunchKernelGGL(r2l_pack_teacher_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, params, wstream);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
+                               const float* wstream, const float* params, float* raw, int64_t R, int S, void* stream) {
+    TeacherArgs a{};
+    a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.z = z; a.wstream = wstream; a.params = params;
+    a.raw = raw; a.n_pts = R * (int64_t)S; a.S = S;
+    if (a.n_pts <= 0) return 0;
+    const int64_t tiles = (a.n_pts + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    hipLaunchKernelGGL(r2l_teacher_mlp_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,129 @@
+"""GPU parity of the teacher path (fused NeRF MLP, raw2outputs, sample_pdf+sort, render_rays) through the C ABI,
+against reference-made goldens and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def make_teacher(sd):
+    from model.nerf_raybased import NeRF
+    m = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("S", [64, 192])
+@pytest.mark.parametrize("wb", [False, True])
+def test_raw2outputs_golden(golden_dir, S, wb):
+    from r2l_amd.render import raw2outputs
+    g = np.load(os.path.join(golden_dir, "raw2outputs.npz"))
+    outs = raw2outputs(T(g["S%d/raw" % S]).cuda(), T(g["S%d/z" % S]).cuda(), T(g["S%d/d" % S]).cuda(), 0, wb)
+    for name, t in zip(("rgb", "disp", "acc", "weights", "depth"), outs):
+        ref = g["S%d_wb%d/%s" % (S, int(wb), name)]
+        got = t.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), name  # disp = NaN on the empty ray, nowhere else
+        np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(ref), rtol=2e-5, atol=2e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("S,R", [(2, 3), (16, 5), (65, 7), (200, 9), (256, 1000)])  # S=1 is degenerate in the reference (empty dists)
+def test_raw2outputs_shapes_vs_oracle(S, R):
+    from r2l_amd.render import raw2outputs
+    g = torch.Generator().manual_seed(S)
+    raw = torch.randn(R, S, 4, generator=g) * 3
+    z = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, -1)[0]
+    d = torch.randn(R, 3, generator=g)
+    noise = torch.randn(R, S, generator=g)
+    ref = O.raw2outputs(raw, z, d, None, True)
+    got = raw2outputs(raw.cuda(), z.cuda(), d.cuda(), 0, True)
+    for a, b in zip(got, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-5, atol=3e-6)
+
+
+def test_sample_pdf_sort_golden(golden_dir):
+    from r2l_amd.render import sample_pdf_sort
+    g = np.load(os.path.join(golden_dir, "sample_pdf.npz"))
+    bins, w = T(g["bins"]), T(g["weights"])
+    R = bins.shape[0]
+    # rebuild a z_vals / weights pair whose mid-points and inner weights are the golden's bins / weights
+    # (sample_pdf_sort takes the coarse z and weights like render_rays does): use z with exact midpoints instead
+    z = torch.zeros(R, 64)
+    z[:, 0] = bins[:, 0] - 0.01
+    for k in range(63):
+        z[:, k + 1] = 2 * bins[:, k] - z[:, k]
+    mids = .5 * (z[:, 1:] + z[:, :-1])
+    wfull = torch.cat([torch.zeros(R, 1), w, torch.zeros(R, 1)], -1)
+    for det, u, key in ((True, torch.linspace(0., 1., 128), "samples_det"), (False, T(g["u_pytest"]), "samples_pytest")):
+        ref = O.sample_pdf(mids, w, 128, det=det, u=None if det else u)
+        zs, z_all, z_std = sample_pdf_sort(z.cuda(), wfull.cuda(), 128, det=det, u=u)
+        got = zs.cpu().numpy()
+        bad = np.abs(got - ref.numpy()) > 1e-5 + 1e-5 * np.abs(ref.numpy())
+        if det:
+            # u == 1.0 (det's last sample) sits exactly on cdf[-1] ~= 1 +- 1 ulp: in a degenerate last bin
+            # (pdf < 1e-5, helpers:325-326) the reference's own answer flips between bins[-1] and bins[-2] with the
+            # rounding of its vectorised torch.sum — not reproducible across CPUs, excluded here.
+            bad[:, -1] = False
+        assert not bad.any(), np.argwhere(bad)[:10]
+        ref_all = torch.sort(torch.cat([z, zs.cpu()], -1), -1)[0]
+        assert torch.equal(z_all.cpu(), ref_all)  # sorting is exact
+        np.testing.assert_allclose(z_std.cpu().numpy(), torch.std(zs.cpu(), dim=-1, unbiased=False).numpy(), rtol=1e-4)
+
+
+def test_teacher_mlp_vs_oracle():
+    from r2l_amd.render import teacher_engine
+    coarse, _ = O.make_teacher_state_dicts(11, 2, alpha_bias=0.5)
+    m = make_teacher(coarse)
+    g = torch.Generator().manual_seed(0)
+    R, S = 37, 64
+    o = torch.randn(R, 3, generator=g)
+    d = torch.randn(R, 3, generator=g)
+    vd = d / d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, -1)[0]
+    pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
+    with torch.no_grad():
+        ref = O.run_network(coarse, pts, vd)
+        raw = teacher_engine(m).mlp(o.cuda(), d.cuda(), vd.cuda(), z.cuda()).cpu()
+    err = (raw - ref).abs().max().item()
+    print("teacher raw max err", err, "ref scale", ref.abs().max().item())
+    assert err < 2e-5
+
+
+def test_render_rays_golden(golden_dir):
+    """render_rays with the seeded teacher pair vs the reference's own dict (perturb=0 and the pytest=True path)."""
+    from r2l_amd.render import render_rays
+    g = np.load(os.path.join(golden_dir, "render_rays.npz"))
+    csd, fsd = O.make_teacher_state_dicts(11, 2, alpha_bias=0.5)
+    coarse, fine = make_teacher(csd), make_teacher(fsd)
+    rb = T(g["ray_batch"]).cuda()
+    with torch.no_grad():
+        det = render_rays(rb, coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=0.)
+        rnd = render_rays(rb, coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                          pytest=True)
+    for tag, ret in (("det", det), ("pytest", rnd)):
+        for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "disp0", "acc0", "z_std"):
+            if tag + "/" + k not in g.files:
+                continue
+            np.testing.assert_allclose(ret[k].cpu().numpy(), g[tag + "/" + k], rtol=2e-4, atol=1e-4,
+                                       err_msg=tag + "/" + k)
+        assert np.abs(ret["rgb_map"].cpu().numpy() - g[tag + "/rgb_map"]).max() < 1e-4
+
+
+def test_render_frame_chunks():
+    """render() over a small frame with 2 chunks equals one chunk; shapes as the reference returns them."""
+    from r2l_amd.render import render
+    csd, fsd = O.make_teacher_state_dicts(3, 2, alpha_bias=0.5)
+    coarse, fine = make_teacher(csd), make_teacher(fsd)
+    c2w = T(O.pose_spherical(20., -40., 4.)[:3, :4]).cuda()
+    kw = dict(network_fn=coarse, network_query_fn=None, N_samples=64, N_importance=128, network_fine=fine,
+              white_bkgd=True, perturb=0., ndc=False, near=2., far=6., use_viewdirs=True)
+    with torch.no_grad():
+        a = render(20, 24, 30., chunk=1 << 15, c2w=c2w, **kw)
+        b = render(20, 24, 30., chunk=200, c2w=c2w, **kw)
+    assert a[0].shape == (20, 24, 3) and a[1].shape == (20, 24) and "rgb0" in a[3]
+    assert torch.equal(a[0], b[0])
