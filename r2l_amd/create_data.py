@@ -1,0 +1,109 @@
+"""Teacher pseudo-data generation — the `python utils/create_data.py --create_data rand ...` surface
+(/root/reference/utils/create_data.py:606-872, 'rand' branch 777-872): a pretrained NeRF (coarse + fine) renders
+random poses; the rays [o, d, rgb] are shuffled and written as data_<k>.npy shards of 4096 rays.
+
+Per pose the whole stack runs on the GPU through libr2l_hip.so: get_rays -> stratified z -> fused embed+MLP (coarse)
+-> raw2outputs -> sample_pdf + sort -> fused embed+MLP (fine) -> raw2outputs.  Poses are partitioned over ranks
+(i % world == rank) with rank-disjoint shard indices and NO collective; each rank uses its own
+RandomState, so the reference's single global np.random replay is distributional, not bitwise.
+"""
+import os
+import shutil
+import time
+
+import numpy as np
+import torch
+
+from . import data as D
+from .checkpoint import load_weights
+from .driver import init_distributed, sync
+from .logger import Logger
+from .nerf_raybased import NeRF
+from .options import parse_args, validate_accelerated
+from .render import get_embedder, get_rays, render, run_network
+
+
+def create_teacher(args, device):
+    """Coarse + fine NeRF(D=8, W=256, 63+27) with frozen weights from --teacher_ckpt (create_data.py:250-280)."""
+    nets = []
+    for key in ("network_fn_state_dict", "network_fine_state_dict"):
+        net = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27,
+                   use_viewdirs=args.use_viewdirs).to(device)
+        net.eval()
+        for p in net.parameters():
+            p.requires_grad = False
+        if args.teacher_ckpt:
+            load_weights(net, args.teacher_ckpt, key)
+        nets.append(net)
+    return nets
+
+
+def teacher_render_kwargs(args, coarse, fine):
+    """render_kwargs_train of create_data.py:302-318 with the teacher pair plugged in (create_data.py:802-808)."""
+    embed_fn, _ = get_embedder(args.multires, args.i_embed)
+    embeddirs_fn, _ = get_embedder(args.multires_views, args.i_embed)
+    qfn = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                                                   netchunk=args.netchunk)
+    return dict(network_query_fn=qfn, perturb=args.perturb, N_importance=args.N_importance, network_fine=fine,
+                N_samples=args.N_samples, network_fn=coarse, use_viewdirs=args.use_viewdirs, white_bkgd=args.white_bkgd,
+                raw_noise_std=args.raw_noise_std, ndc=False, lindisp=args.lindisp)
+
+
+def render_pose_rows(pose, H, W, focal, near, far, chunk, render_kwargs):
+    """[H*W, 9] rows [o, d, rgb] of one teacher-rendered pose (create_data.py:819-840)."""
+    rays_o, rays_d = get_rays(H, W, focal, pose[:3, :4])
+    with torch.no_grad():
+        rgb, *_ = render(H, W, focal, chunk=chunk, rays=torch.stack([rays_o, rays_d], 0), near=near, far=far,
+                         **render_kwargs)
+    return torch.cat([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), rgb.reshape(-1, 3)], dim=-1)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    validate_accelerated(args)
+    if args.create_data != "rand":
+        raise NotImplementedError("only --create_data rand (the README pipeline) is on the accelerated path")
+    rank, world, device = init_distributed()
+    logger = Logger(args, rank)
+    rng = np.random.RandomState(1000003 * rank)  # per-rank pose / focal / shuffle stream
+
+    if os.path.exists(os.path.join(args.datadir, "transforms_train.json")):
+        _, _, _, hwf, _ = D.load_blender_data(args.datadir, args.half_res, args.testskip)
+        H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
+    else:  # intrinsics of the 400x400 lego setting when no scene directory is present (main.py:927 comment)
+        H, W, focal = 400, 400, 555.5555155968841
+    near, far = 2., 6.
+    coarse, fine = create_teacher(args, device)
+    kwargs = teacher_render_kwargs(args, coarse, fine)
+
+    datadir_new = args.datadir_kd.split(":")[-1]
+    if rank == 0:
+        if os.path.exists(datadir_new) and args.rm_existing_data:
+            shutil.rmtree(datadir_new)
+        os.makedirs(datadir_new, exist_ok=True)
+    if world > 1:
+        torch.distributed.barrier()
+    n_pose = args.n_pose_kd if isinstance(args.n_pose_kd, int) else int(args.n_pose_kd[0])
+    mine = [i for i in range(1, n_pose + 1) if i % world == rank]
+    rays_per_file = 4096
+    # rank-disjoint shard index ranges: each flush of `create_data_chunk` poses yields at most this many files
+    files_per_flush = (args.create_data_chunk * H * W) // rays_per_file
+    flushes = (len(mine) + args.create_data_chunk - 1) // max(args.create_data_chunk, 1)
+    next_index = rank * (flushes * files_per_flush)
+    buf, t0, n_rays = [], time.time(), 0
+    for j, i in enumerate(mine, 1):
+        pose = D.get_rand_pose(rng).to(device)
+        focal_ = focal * (1 + rng.rand()) if args.use_rand_focal else focal  # focal x U[1,2) (create_data.py:816)
+        buf.append(render_pose_rows(pose, H, W, focal_, near, far, args.chunk, kwargs).cpu())
+        n_rays += H * W
+        if j % args.create_data_chunk == 0 or j == len(mine):
+            rows = torch.cat(buf, 0).numpy()
+            rows = rows[rng.permutation(rows.shape[0])]
+            rows = rows[rng.permutation(rows.shape[0])]  # the reference permutes twice (create_data.py:854-859)
+            next_index = D.write_ray_shards(rows, datadir_new, next_index, rays_per_file)
+            buf = []
+            sync(device)
+            dt = time.time() - t0
+            logger.info("[%d/%d poses on rank %d] %d rays in %.1fs = %.0f rays/s; shards up to data_%d.npy" %
+                        (j, len(mine), rank, n_rays, dt, n_rays / dt, next_index - 1))
+    return {"n_rays": n_rays, "datadir": datadir_new, "logger": logger}

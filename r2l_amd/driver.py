@@ -1,0 +1,283 @@
+"""R2L driver: the `python main.py --model_name R2L ...` surface (render_only / render_test / --benchmark / distillation
+training with hard-ray mining / checkpoints), mirroring the control flow of the reference's main.py:888-1542 for the
+accelerated path only.  One process per GPU; under torchrun the ray shards, test frames and log output are
+rank-partitioned and the only collective is the flat-gradient all-reduce inside R2LTrainer.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import data as D
+from .checkpoint import load_ckpt, load_weights_v2, parse_expid_iter, save_ckpt
+from .logger import Logger
+from .metrics import img2mse, mse2psnr, to8b
+from .nerf_raybased import NeRF_v3_2, PointSampler, PositionalEmbedder
+from .options import parse_args, validate_accelerated
+from .train_step import R2LTrainer, lr_schedule
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def init_distributed():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        device = torch.device("cuda", local % torch.cuda.device_count())
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
+    return rank, world, device
+
+
+def sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+
+
+class HardRayPool:
+    """Hard-example pool of main.py:1164-1165, 1325-1347, 1410-1425: after each step the hard_ratio*B rays with the
+    largest per-ray MSE enter the pool (appended until it holds B*hard_mul rows, then replacing random rows), and
+    n_hard_out random pool rows are appended to every batch once the pool is full."""
+
+    def __init__(self, hard_ratio, hard_mul, rng=None):
+        self.ratio, self.mul = hard_ratio, hard_mul
+        self.pool = None
+        self.full = False
+        self.rng = rng or np.random
+        self._ix_out = None
+
+    def sizes(self, batch_size):
+        if isinstance(self.ratio, list):
+            n_in, n_out = int(self.ratio[0] * batch_size), int(self.ratio[1] * batch_size)
+        else:
+            n_in = n_out = int(self.ratio * batch_size)
+        return min(n_in, n_out), n_out
+
+    def augment(self, rays_o, rays_d, target):
+        if not self.full:
+            return rays_o, rays_d, target
+        _, n_out = self.sizes(rays_o.shape[0])
+        self._ix_out = self.rng.permutation(self.pool.shape[0])[:n_out]
+        picked = self.pool[torch.as_tensor(self._ix_out, device=self.pool.device)]
+        return (torch.cat([rays_o, picked[:, :3]], 0), torch.cat([rays_d, picked[:, 3:6]], 0),
+                torch.cat([target, picked[:, 6:]], 0))
+
+    def update(self, rgb, rays_o, rays_d, target, batch_size):
+        n_in, _ = self.sizes(batch_size)
+        if n_in <= 0:
+            return
+        err = torch.mean((rgb[:batch_size] - target[:batch_size])**2, dim=1)
+        _, order = torch.sort(err)
+        hard = order[-n_in:]
+        rows = torch.cat([rays_o[hard], rays_d[hard], target[hard]], dim=-1)
+        if self.full:
+            self.pool[torch.as_tensor(self._ix_out[:n_in], device=self.pool.device)] = rows
+        else:
+            self.pool = rows if self.pool is None else torch.cat([self.pool, rows], 0)
+            if self.pool.shape[0] >= batch_size * self.mul:
+                self.full = True
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def create_r2l(args, device, logger):
+    """Model + (optional) checkpoint, following main.py:455-509: a checkpoint that carries the pickled `network_fn`
+    REPLACES the freshly constructed module before its state dict is loaded."""
+    embedder = PositionalEmbedder(L=args.multires, device=device)
+    input_dim = args.n_sample_per_ray * 3 * embedder.embed_dim
+    model = NeRF_v3_2(args, input_dim, 3).to(device)
+    history = {"start": 0, "best_psnr": 0, "best_psnr_step": 0}
+    ckpt = None
+    if args.pretrained_ckpt:
+        ckpt = load_ckpt(args.pretrained_ckpt, map_location=device)
+        if "network_fn" in ckpt:
+            model = ckpt["network_fn"].to(device)
+            logger.info('Use model arch saved in checkpoint "%s"' % args.pretrained_ckpt)
+        load_weights_v2(model, ckpt, "network_fn_state_dict")
+        logger.info('Load pretrained ckpt successfully: "%s".' % args.pretrained_ckpt)
+        if args.resume:
+            history.update(start=ckpt["global_step"], best_psnr=ckpt.get("best_psnr", 0),
+                           best_psnr_step=ckpt.get("best_psnr_step", 0))
+    n_params = sum(p.numel() for p in model.parameters())
+    macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
+    logger.info("Model complexity per pixel: FLOPs %.10fM, Params %.10fM" % (macs / 1e6, n_params / 1e6))
+    return model, embedder, history, ckpt
+
+
+def render_frame(model, point_sampler, c2w):
+    """One frame [H,W,3] (main.py:300-324 R2L branch): fused sample -> encode -> network."""
+    with torch.no_grad():
+        rgb = model.render_pose(c2w[:3, :4], point_sampler)
+    return rgb.view(point_sampler.H, point_sampler.W, 3)
+
+
+def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, savedir=None, rank=0, world=1):
+    """Render poses[rank::world]; returns (rgbs [n,H,W,3], misc with test_loss/test_psnr/test_psnr_v2 over ALL frames)
+    — the R2L branch of main.py:189-398 with PSNR as the graded metric (SSIM/LPIPS/FLIP are out of scope)."""
+    model.eval()
+    mine = list(range(rank, len(poses), world))
+    rgbs, sq_err, psnrs = [], [], []
+    for i in mine:
+        sync(device)
+        t0 = time.time()
+        rgb = render_frame(model, point_sampler, poses[i])
+        sync(device)
+        logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, time.time() - t0))
+        rgbs.append(rgb)
+        if gt_imgs is not None:
+            gt = gt_imgs[i].to(rgb.device)
+            mse = img2mse(rgb, gt)
+            sq_err.append(mse)
+            psnrs.append(mse2psnr(mse))
+        if savedir is not None:
+            from PIL import Image
+            Image.fromarray(to8b(rgb)).save(os.path.join(savedir, "%03d.png" % i))
+            if gt_imgs is not None:
+                Image.fromarray(to8b(gt_imgs[i])).save(os.path.join(savedir, "%03d_gt.png" % i))
+    rgbs = torch.stack(rgbs, 0) if rgbs else torch.empty(0)
+    misc = {}
+    if gt_imgs is not None:
+        stats = torch.tensor([float(sum(sq_err)) if sq_err else 0., float(sum(psnrs)) if psnrs else 0., len(mine)],
+                             dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(stats)  # host-side metric gather (3 scalars), not on the data path
+        misc["test_loss"] = torch.tensor(stats[0].item() / max(stats[2].item(), 1))
+        misc["test_psnr"] = mse2psnr(misc["test_loss"].float()).squeeze()
+        misc["test_psnr_v2"] = torch.tensor(stats[1].item() / max(stats[2].item(), 1))
+    model.train()
+    return rgbs, misc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    args = parse_args(argv)
+    validate_accelerated(args)
+    if args.model_name not in ("R2L", "nerf_v3.2"):
+        raise NotImplementedError("main.py accelerates --model_name R2L; the NeRF teacher is used through "
+                                  "utils/create_data.py (its training is out of scope)")
+    rank, world, device = init_distributed()
+    np.random.seed(0)
+    logger = Logger(args, rank)
+
+    images, poses, render_poses, hwf, i_split = D.load_blender_data(args.datadir, args.half_res, args.testskip)
+    logger.info("Loaded blender", tuple(images.shape), tuple(poses.shape), hwf, args.datadir)
+    i_train, i_val, i_test = i_split
+    near, far = 2., 6.
+    if hasattr(args, "trial") and args.trial.near > 0:
+        assert args.trial.far > args.trial.near
+        near, far = args.trial.near, args.trial.far
+    images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:]) if args.white_bkgd else images[..., :3]
+    H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
+    if args.focal_scale > 0:
+        focal *= args.focal_scale
+
+    model, embedder, history, ckpt = create_r2l(args, device, logger)
+    point_sampler = PointSampler(H, W, focal, args.n_sample_per_ray, near, far, device=device)
+    test_poses, test_images = poses[i_test], images[i_test]
+    video_poses = D.get_novel_poses(args, n_pose=args.n_pose_video)
+    start, best_psnr, best_psnr_step = history["start"], history["best_psnr"], history["best_psnr_step"]
+
+    if args.test_pretrained:
+        _, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images, rank=rank,
+                              world=world)
+        logger.info("Pretrained test: TestLoss %.4f TestPSNR %.4f TestPSNRv2 %.4f" %
+                    (misc["test_loss"].item(), misc["test_psnr"].item(), misc["test_psnr_v2"].item()))
+
+    if args.render_only:
+        logger.info("RENDER ONLY")
+        expid, iter_ = parse_expid_iter(args.pretrained_ckpt)
+        t_ = time.time()
+        if args.render_test:
+            rgbs, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images,
+                                     savedir=logger.gen_img_path if rank == 0 or world > 1 else None, rank=rank,
+                                     world=world)
+            logger.info("[TEST] TestPSNR %.4f TestPSNRv2 %.4f" % (misc["test_psnr"].item(), misc["test_psnr_v2"].item()))
+        else:
+            rgbs, misc = render_path(video_poses, model, point_sampler, device, logger, savedir=logger.gen_img_path,
+                                     rank=rank, world=world)
+        n_rays = rgbs.shape[0] * H * W if rgbs.numel() else 0
+        dt = time.time() - t_
+        logger.info("Rendered %d frames (%d rays) in %.2fs on rank 0 = %.0f rays/s incl. I/O; frames in %s "
+                    "(mp4 muxing needs imageio/ffmpeg, absent on this image)" %
+                    (rgbs.shape[0], n_rays, dt, n_rays / max(dt, 1e-9), logger.gen_img_path))
+        return {"misc": misc, "rgbs": rgbs, "logger": logger}
+
+    if args.benchmark:
+        # torch.utils.benchmark.Timer('render_func(model, pose)').timeit(100) in the reference (main.py:1124-1133)
+        pose = video_poses[0]
+        for _ in range(3):
+            render_frame(model, point_sampler, pose)
+        sync(device)
+        t0 = time.time()
+        n = 100 if device.type == "cuda" else 2
+        for _ in range(n):
+            render_frame(model, point_sampler, pose)
+        sync(device)
+        per = (time.time() - t0) / n
+        logger.info("render_func(model, pose): %.3f ms per %dx%d frame = %.3f M rays/s" % (per * 1e3, H, W,
+                                                                                           H * W / per / 1e6))
+        return {"ms_per_frame": per * 1e3, "logger": logger}
+
+    # ---------------- distillation training (data_mode rays) ----------------
+    if args.data_mode != "rays" or not args.datadir_kd:
+        raise NotImplementedError("training on the accelerated path needs --data_mode rays --datadir_kd <dir of "
+                                  "[4096,9] .npy ray shards> (README step 3/5)")
+    if device.type != "cuda":
+        raise RuntimeError("R2L training runs on the HIP path and needs a ROCm GPU")
+    datadir_kd = args.datadir_kd.split(":")[1] if ":" in args.datadir_kd else args.datadir_kd
+    files = D.list_ray_shards(datadir_kd, args.pseudo_ratio, args.pseudo_data_hold_ratio)
+    loader = D.RayShardLoader(files, args.N_rand, rank=rank, world=world)
+    logger.info("Loaded data. Now total #train files: %d (this rank: %d)" % (len(files), len(loader.files)))
+    trainer = R2LTrainer(model, point_sampler, lw_rgb=args.lw_rgb)
+    if ckpt is not None and args.resume:
+        trainer.load_optimizer_state_dict(ckpt["optimizer_state_dict"])
+        logger.info("Resume optimizer successfully.")
+    pool = HardRayPool(args.hard_ratio, args.hard_mul) if args.hard_ratio else None
+    hist_psnr, t_data, t_batch = 0., 0., 0.
+    logger.info("Begin training")
+    for i in range(start + 1, args.N_iters + 1):
+        t0 = time.time()
+        lr = lr_schedule(i, args.lrate, args.lrate_decay, args.warmup_lr)
+        batch = loader.next().to(device, non_blocking=True)  # H2D of 36 B/ray
+        rays_o, rays_d, target = batch[:, :3], batch[:, 3:6], batch[:, 6:9]
+        batch_size = rays_o.shape[0]
+        if pool is not None:
+            rays_o, rays_d, target = pool.augment(rays_o, rays_d, target)
+        t_data = time.time() - t0
+        rgb, loss_out = trainer.step(rays_o, rays_d, target, lr, perturb=args.perturb)
+        if pool is not None:
+            pool.update(rgb, rays_o, rays_d, target, batch_size)
+        t_batch = time.time() - t0
+        if i % args.i_print == 0:
+            loss, psnr = loss_out.tolist()  # the only host sync of the loop, every i_print iterations
+            hist_psnr = psnr if hist_psnr == 0. else hist_psnr * 0.95 + psnr * 0.05
+            logger.info("[TRAIN] Iter %d data_time %.4f batch_time %.4f loss %.6f psnr %.4f hist_psnr %.4f LR %.10f" %
+                        (i, t_data, t_batch, loss, psnr, hist_psnr, lr))
+        if i % args.i_testset == 0:
+            savedir = os.path.join(logger.gen_img_path, "testset_%s_iter%d" % (logger.ExpID, i))
+            os.makedirs(savedir, exist_ok=True)
+            t_ = time.time()
+            _, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images,
+                                  savedir=savedir, rank=rank, world=world)
+            if misc["test_psnr_v2"] > best_psnr:
+                best_psnr, best_psnr_step = misc["test_psnr_v2"].item(), i
+                if rank == 0:
+                    save_ckpt(os.path.join(logger.weights_path, "ckpt_best.tar"), i, model,
+                              trainer.optimizer_state_dict(lr), best_psnr, best_psnr_step)
+            logger.info("[TEST] Iter %d TestPSNR %.4f TestPSNRv2 %.4f BestPSNRv2 %.4f (Iter %d) TrainHistPSNR %.4f "
+                        "LR %.8f Time %.1fs" % (i, misc["test_psnr"].item(), misc["test_psnr_v2"].item(), best_psnr,
+                                                best_psnr_step, hist_psnr, lr, time.time() - t_))
+        if i % args.i_weights == 0 and rank == 0:
+            name = "ckpt_%d.tar" % i if args.save_intermediate_models else "ckpt.tar"
+            path = save_ckpt(os.path.join(logger.weights_path, name), i, model, trainer.optimizer_state_dict(lr),
+                             best_psnr, best_psnr_step)
+            logger.info('Iter %d Save checkpoint: "%s".' % (i, path))
+    loader.close()
+    return {"trainer": trainer, "logger": logger, "model": model}

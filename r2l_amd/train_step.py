@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .dist_utils import GradAllReducer
 from .engine import N_SAMPLE, W, _ptr, _stream, get_engine
 
 
@@ -32,7 +33,7 @@ class R2LTrainer:
         self.eng = get_engine(module)
         self.lib = self.eng.lib
         self.betas, self.eps, self.lw_rgb = betas, eps, lw_rgb
-        self.pg = process_group
+        self.reducer = GradAllReducer(process_group)
         self.step_count = 0
         self.cap = 0
         self._alloc_state()
@@ -100,14 +101,11 @@ class R2LTrainer:
         return rgb
 
     def world(self):
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_world_size(self.pg)
-        return 1
+        return self.reducer.world()
 
     def allreduce_grads(self):
         """ONE collective per step: sum of the flat fp32 gradient over ranks."""
-        if self.world() > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+        self.reducer.allreduce(self.grads)
 
     def adam(self, lr):
         self.step_count += 1
@@ -115,7 +113,7 @@ class R2LTrainer:
         _lib.check(
             self.lib.r2l_adam_step(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                    eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
-                                   1.0 / self.world(), _stream()), "r2l_adam_step")
+                                   self.reducer.grad_scale(), _stream()), "r2l_adam_step")
         eng.mark_dirty()
 
     def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None):

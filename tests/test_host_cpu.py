@@ -1,0 +1,122 @@
+"""Host logic on CPU: options/config parsing, checkpoint un-pickling of a REFERENCE-written .tar, data layer,
+LR schedule, C-ABI library exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import torch
+
+from oracle import r2l_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from r2l_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "r2l_hip.h")).read()
+    declared = set(re.findall(r"\b(r2l_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.r2l_param_count(43) == 5917187
+    assert lib.r2l_teacher_param_count() == sum(v.numel() for v in O.make_teacher_state_dicts(0, 1)[0].values())
+    assert lib.r2l_num_tiles(33) == 2
+
+
+def test_options_readme_command(tmp_path):
+    from r2l_amd.options import parse_args
+    cfg = os.path.join(ROOT, "configs", "lego_noview.txt")
+    a = parse_args(["--model_name", "R2L", "--config", cfg, "--n_sample_per_ray", "16", "--netwidth", "256",
+                    "--netdepth", "88", "--use_residual", "--trial.ON", "--trial.body_arch", "resmlp", "--N_rand", "20",
+                    "--data_mode", "rays", "--hard_ratio", "0.2", "--hard_mul", "20", "--num_worker", "8",
+                    "--warmup_lr", "0.0001,200", "--N_iters", "1200000", "--datadir_kd", "data/x:data/y"])
+    assert a.netdepth == 88 and a.trial.body_arch == "resmlp" and a.trial.res_scale == 1.0 and a.trial.n_block == -1
+    assert a.white_bkgd and a.half_res and not a.use_viewdirs and a.lrate_decay == 500  # from the config file
+    assert a.N_rand == 20  # command line overrides the file's 1024
+    assert a.hard_ratio == 0.2 and a.hard_mul == 20 and a.num_workers == 8 and a.n_pose_video == 40
+    assert not hasattr(a, "trial.ON")
+    b = parse_args(["--config", os.path.join(ROOT, "configs", "lego.txt")])
+    assert b.use_viewdirs and b.N_importance == 128 and not hasattr(b, "trial")
+
+
+def test_unpickle_reference_checkpoint(golden_dir):
+    """ckpt_w32d6.tar was written by the REFERENCE's save_ckpt (pickled reference NeRF_v3_2): it must load into our
+    classes without running __init__, and the restored module must compute the reference's rgb."""
+    from r2l_amd.checkpoint import load_ckpt, save_ckpt
+    import model.nerf_raybased as mine
+    ckpt = load_ckpt(os.path.join(golden_dir, "ckpt_w32d6.tar"), map_location="cpu")
+    assert set(ckpt) >= {"global_step", "best_psnr", "network_fn_state_dict", "optimizer_state_dict", "network_fn"}
+    net = ckpt["network_fn"]
+    assert type(net) is mine.NeRF_v3_2 and type(net.body[0]) is mine.ResMLP
+    g = np.load(os.path.join(golden_dir, "r2l_w32d6.npz"))
+    g256 = np.load(os.path.join(golden_dir, "r2l_w256d88.npz"))
+    emb = O.positional_embed(O.sample_train(torch.from_numpy(g256["rays_o"]), torch.from_numpy(g256["rays_d"]),
+                                            O.z_vals(16, 2., 6.), 0.), 10)
+    # the checkpoint holds the weights after 3 Adam steps
+    sd3 = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p3/")}
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd3[k]), k
+    with torch.no_grad():
+        out = net(emb)
+    np.testing.assert_allclose(out.numpy(), O.r2l_forward(sd3, emb).numpy(), atol=1e-6)
+    assert ckpt["global_step"] == 3 and ckpt["optimizer_state_dict"]["state"][0]["exp_avg"].shape == (32, 1008)
+    # and our writer produces a file the same loader (and hence the reference's) reads back identically
+    path = save_ckpt(os.path.join(str(golden_dir), "..", "_tmp_ckpt.tar"), 7, net, ckpt["optimizer_state_dict"], 1., 2)
+    again = load_ckpt(path, map_location="cpu")
+    os.remove(path)
+    assert again["global_step"] == 7 and type(again["network_fn"]) is mine.NeRF_v3_2
+    assert all(torch.equal(again["network_fn_state_dict"][k], v) for k, v in net.state_dict().items())
+
+
+def test_lr_schedule_matches_oracle():
+    from r2l_amd.train_step import lr_schedule
+    for step in (1, 50, 199, 200, 201, 5000, 600000):
+        for w in ("", "0.0001,200"):
+            assert lr_schedule(step, 5e-4, 500, w) == O.lr_schedule(step, 5e-4, 500, w)
+
+
+def test_pose_spherical_and_shards(tmp_path, golden_dir):
+    from r2l_amd import data
+    g = np.load(os.path.join(golden_dir, "sampler.npz"))
+    for (th, ph, r), c2w in zip(g["pose_spherical_args"], g["poses"]):
+        np.testing.assert_allclose(data.pose_spherical(th, ph, r)[:3, :4].numpy(), c2w, atol=1e-6)
+    rows = np.random.RandomState(0).rand(3 * 4096 + 100, 9).astype(np.float32)
+    nxt = data.write_ray_shards(rows, str(tmp_path), 5)
+    assert nxt == 8 and sorted(os.listdir(tmp_path)) == ["data_5.npy", "data_6.npy", "data_7.npy"]
+    assert os.path.getsize(tmp_path / "data_5.npy") == 147584  # NumPy v1 header + 4096*9*4
+    files = data.list_ray_shards(str(tmp_path))
+    ds = data.BlenderDataset_v2(str(tmp_path), pseudo_ratio=-1)
+    o, d, c = ds[0]
+    assert o.shape == (4096, 3) and torch.equal(torch.cat([o, d, c], -1), torch.from_numpy(rows[:4096]))
+    assert data.shard_for_rank(files, 0, 2) + data.shard_for_rank(files, 1, 2) != files  # interleaved
+    assert sorted(data.shard_for_rank(files, 0, 2) + data.shard_for_rank(files, 1, 2)) == sorted(files)
+    ld = data.RayShardLoader(files, 2, rank=1, world=2, pin=False)
+    b = ld.next()
+    ld.close()
+    assert b.shape == (8192, 9)
+
+
+def test_load_blender_synthetic(tmp_path):
+    """A tiny Blender-format scene written with PIL: loader returns the documented shapes; half_res = 2x2 mean."""
+    import json
+    from PIL import Image
+    from r2l_amd import data
+    rng = np.random.RandomState(0)
+    for split, n in (("train", 3), ("val", 1), ("test", 2)):
+        os.makedirs(tmp_path / split)
+        frames = []
+        for i in range(n):
+            img = (rng.rand(8, 8, 4) * 255).astype(np.uint8)
+            Image.fromarray(img).save(tmp_path / split / ("r_%d.png" % i))
+            frames.append({"file_path": "./%s/r_%d" % (split, i),
+                           "transform_matrix": data.pose_spherical(30. * i, -30., 4.).tolist()})
+        with open(tmp_path / ("transforms_%s.json" % split), "w") as f:
+            json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, f)
+    imgs, poses, render_poses, hwf, i_split = data.load_blender_data(str(tmp_path), half_res=True, testskip=1)
+    assert imgs.shape == (6, 4, 4, 4) and poses.shape == (6, 4, 4) and render_poses.shape == (40, 4, 4)
+    assert hwf[0] == 4 and abs(hwf[2] - 0.5 * 8 / np.tan(0.5 * 0.6911112070083618) / 2) < 1e-9
+    assert [len(s) for s in i_split] == [3, 1, 2]
+    full, *_ = data.load_blender_data(str(tmp_path), half_res=False, testskip=1)
+    np.testing.assert_allclose(imgs.numpy(), full.numpy().reshape(6, 4, 2, 4, 2, 4).mean(axis=(2, 4)), atol=1e-7)
