@@ -121,3 +121,30 @@ def test_gradient_accumulation_and_zeroing():
     g1 = tr.grads.clone()
     tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda(), zero_grad=False)
     assert rel_err(tr.grads, 2 * g1) < 1e-5
+
+
+def test_autograd_bridge_module_boundary():
+    """rgb = model(embedded); loss.backward(); torch.optim.Adam.step() — the reference's idiom — on the HIP path."""
+    from model.nerf_raybased import PointSampler, PositionalEmbedder
+    sd = O.make_state_dict(n_block=2, seed=6)
+    m = build_model(sd, 2)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    pe = PositionalEmbedder(10)
+    gen = torch.Generator().manual_seed(2)
+    n = 300
+    o, d, tgt = torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen), torch.rand(n, 3, generator=gen)
+    emb_ref = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
+    loss_ref, _, gref = O.r2l_loss_and_grads(sd, emb_ref, tgt)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    emb = pe(ps.sample_train(o.cuda(), d.cuda(), perturb=0.))
+    rgb = m(emb)
+    loss = torch.mean((rgb - tgt.cuda())**2)
+    opt.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-6
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), gref[k]) < 2e-3, k
+    opt.step()
+    with torch.no_grad():
+        rgb2 = m(emb)  # parameters changed in place -> engine re-packs the weight stream
+    assert (rgb2 - rgb).abs().max().item() > 1e-5
