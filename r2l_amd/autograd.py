@@ -16,8 +16,9 @@ class R2LEmbFunction(torch.autograd.Function):
         emb2 = emb.reshape(-1, emb.shape[-1]).contiguous().float()
         n, nb = emb2.shape[0], eng.n_block
         f = dict(dtype=torch.float32, device=emb2.device)
-        save_x = torch.empty((nb + 1) * n * W, **f)
-        save_t = torch.empty(max(nb, 1) * n * W, **f)
+        npad = int(eng.lib.r2l_padded_rows(n))
+        save_x = torch.empty((nb + 1) * npad * W, **f)
+        save_t = torch.empty(max(nb, 1) * npad * W, **f)
         rgb = eng.forward_emb(emb2, save=(save_x, save_t))
         ctx.module, ctx.n = module, n
         ctx.lead = emb.shape[:-1]
@@ -34,8 +35,9 @@ class R2LEmbFunction(torch.autograd.Function):
         wbwd = torch.empty(lib.r2l_bwd_stream_floats(nb), **f)
         _lib.check(lib.r2l_pack_backward(_ptr(eng.flat), nb, _ptr(wbwd), _stream()), "r2l_pack_backward")
         grads = torch.zeros(eng.n_param, **f)
-        gx = torch.empty((nb + 1) * n * W, **f)
-        gt = torch.empty(max(nb, 1) * n * W, **f)
+        npad = int(lib.r2l_padded_rows(n))
+        gx = torch.empty((nb + 1) * npad * W, **f)
+        gt = torch.empty(max(nb, 1) * npad * W, **f)
         dpre = torch.empty(n * 3, **f)
         drgb = grad_rgb.reshape(-1, 3).contiguous().float()
         _lib.check(

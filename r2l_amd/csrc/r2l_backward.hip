@@ -37,6 +37,32 @@ struct R2LBwdArgs {
     int64_t N;
 };
 
+// GEMM-A hook of the backward chain (u = W2^T g): (1) g = dL/dx_{b+1} is the B operand, its store to gx[b+1] rides
+// along; (2) the ReLU mask of the block's hidden activation is prefetched one 16-byte piece per group from the forward
+// stash and folded into 128 bits per lane, so no load latency is exposed between the two GEMMs.
+struct BwdAHook {
+    static constexpr int RD = 1, WR = 1;
+    StoreHook st;
+    const float* trow;  // save_t row of this lane (+4h)
+    unsigned (&mb)[4];
+    f32x4 pend;
+    __device__ __forceinline__ BwdAHook(float* gbase, const float* tbase, int64_t ray, int h,
+                                        const f32x16 (&g)[R2L_NT], unsigned (&m)[4])
+        : st(gbase, ray, h, g), trow(tbase + ray * R2L_W + 4 * h), mb(m) {}
+    __device__ __forceinline__ void fold(int G) {
+        const int sh = ((G >> 2) & 1) * 16 + (G & 3) * 4;
+        unsigned bits = (pend[0] > 0.f ? 1u : 0u) | (pend[1] > 0.f ? 2u : 0u) | (pend[2] > 0.f ? 4u : 0u) |
+                        (pend[3] > 0.f ? 8u : 0u);
+        mb[G >> 3] |= bits << sh;
+    }
+    __device__ __forceinline__ void at(int G) {
+        st.at(G);
+        if (G > 0) fold(G - 1);
+        pend = *reinterpret_cast<const f32x4*>(trow + 32 * (G >> 2) + 8 * (G & 3));
+    }
+    __device__ __forceinline__ void finish() { fold(R2L_LAYER_GROUPS - 1); }
+};
+
 __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs a) {
     __shared__ float stash[4][R2L_NT * 16][64];  // dy of each wave's tile (outer residual branch), re-added at the head
 
@@ -51,6 +77,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
 
     WStream ws;
     ws.init(a.wstream, lane);
+    const int64_t Np = R2L_PAD_ROWS(a.N);  // rows per stash / gradient slot
 
     // loss gradient through the sigmoid: dpre = grad_scale*(rgb-target) * rgb*(1-rgb)
     float dp[3], se = 0.f;
@@ -102,36 +129,34 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
     for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
         for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = g[T][c];
-    store_frag(a.gx + (int64_t)a.n_block * a.N * R2L_W, ray, valid, h, g);
-
 #pragma unroll 1
     for (int b = a.n_block - 1; b >= 0; --b) {
-        // u = W2^T g, masked by relu'(hidden) = (t_b > 0)
+        // u = W2^T g, masked by relu'(hidden) = (t_b > 0); g (= dL/dx_{b+1}) is stored to gx[b+1] along the way
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
             for (int c = 0; c < 16; ++c) u[T][c] = 0.f;
-        gemm256(u, g, ws);
+        unsigned mb[4] = {0u, 0u, 0u, 0u};
         {
-            const float* r = a.save_t + ((int64_t)b * a.N + rc) * R2L_W + 4 * h;
-#pragma unroll
-            for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(r + 32 * T + 8 * q);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) u[T][4 * q + j] = tv[j] > 0.f ? u[T][4 * q + j] : 0.f;
-                }
+            BwdAHook hk(a.gx + (int64_t)(b + 1) * Np * R2L_W, a.save_t + (int64_t)b * Np * R2L_W, ray, h, g, mb);
+            gemm256(u, g, ws, hk);
+            hk.finish();
         }
-        store_frag(a.gt + (int64_t)b * a.N * R2L_W, ray, valid, h, u);
-        // g += W1^T u
-        gemm256(g, u, ws);
-        if (b > 0) store_frag(a.gx + (int64_t)b * a.N * R2L_W, ray, valid, h, g);
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                u[T][c] = ((mb[T >> 1] >> ((T & 1) * 16 + c)) & 1u) ? u[T][c] : 0.f;
+        // g += W1^T u ; u (= dL/d hidden pre-activation) is stored to gt[b] along the way
+        {
+            StoreHook su(a.gt + (int64_t)b * Np * R2L_W, ray, h, u);
+            gemm256(g, u, ws, su);
+        }
     }
 
     // head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0)
     {
-        const float* r = a.save_x + rc * R2L_W + 4 * h;
+        const float* r = a.save_x + ray * R2L_W + 4 * h;
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
@@ -144,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
                 }
             }
     }
-    store_frag(a.gx, ray, valid, h, g);
+    store_frag(a.gx, ray, h, g);
 }
 
 // =================================================================================================================
@@ -223,40 +248,60 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
         int64_t cend = cu + (u1 - u);
         if (cend > a.units_per_layer) cend = a.units_per_layer;
         const int b = layer >> 1;
-        const float* G = (layer & 1) ? a.gx + (int64_t)(b + 1) * a.N * R2L_W : a.gt + (int64_t)b * a.N * R2L_W;
-        const float* A = (layer & 1) ? a.save_t + (int64_t)b * a.N * R2L_W : a.save_x + (int64_t)b * a.N * R2L_W;
+        const int64_t Np = R2L_PAD_ROWS(a.N);
+        const float* G = (layer & 1) ? a.gx + (int64_t)(b + 1) * Np * R2L_W : a.gt + (int64_t)b * Np * R2L_W;
+        const float* A = (layer & 1) ? a.save_t + (int64_t)b * Np * R2L_W : a.save_x + (int64_t)b * Np * R2L_W;
         const int64_t r0 = cu * DW_CHUNK;
         int64_t r1 = cend * DW_CHUNK;
         if (r1 > a.N) r1 = a.N;
         const float* gp = G + (int64_t)wo * 128 + 4 * jl;
         const float* ap = A + (int64_t)wi * 128 + 4 * jl;
-        // software pipeline: operands of k-step s+2 are loaded while k-step s computes
-        const int64_t nsteps = (r1 - r0 + 1) / 2;
-        f32x4 gq[3], aq[3];
+        // Software pipeline without predicates: operands of k-step s+2 are loaded (row index clamped into the
+        // segment, so the loads are unconditional and hipcc can use counted vmcnt waits) while k-step s computes.
+        const int64_t nfull = (r1 - r0) / 2;  // k-steps with both rays present
+        const float* gbase = gp + (r0 + hh) * R2L_W;
+        const float* abase = ap + (r0 + hh) * R2L_W;
         auto ld = [&](int64_t s, f32x4& gv, f32x4& av) {
-            const int64_t r = r0 + 2 * s + hh;
-            if (s < nsteps && r < r1) {
-                gv = *reinterpret_cast<const f32x4*>(gp + r * R2L_W);
-                av = *reinterpret_cast<const f32x4*>(ap + r * R2L_W);
-            } else {
-                gv = f32x4{0.f, 0.f, 0.f, 0.f};
-                av = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const int64_t sc = s < nfull ? s : (nfull > 0 ? nfull - 1 : 0);
+            gv = *reinterpret_cast<const f32x4*>(gbase + sc * (2 * R2L_W));
+            av = *reinterpret_cast<const f32x4*>(abase + sc * (2 * R2L_W));
         };
-        ld(0, gq[0], aq[0]);
-        ld(1, gq[1], aq[1]);
-        for (int64_t s = 0; s < nsteps; s += 3) {
+        auto kstep = [&](const f32x4& gv, const f32x4& av) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ld(s + k + 2, gq[(k + 2) % 3], aq[(k + 2) % 3]);
-                const f32x4 gv = gq[k], av = aq[k];
+            for (int eo = 0; eo < 4; ++eo)
 #pragma unroll
-                for (int eo = 0; eo < 4; ++eo)
+                for (int ei = 0; ei < 4; ++ei)
+                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[eo], av[ei], acc[eo][ei], 0, 0, 0);
+            bsum += gv;
+        };
+        if (nfull > 0) {
+            // 4 rotating operand buffers, each reloaded right after the k-step that consumed it: every load is issued
+            // three k-steps (3072 MFMA cycles) before its use, with no register copies.  The loop body is a whole
+            // 64-ray chunk (32 k-steps) because hipcc drains vmcnt to 0 at every loop header.
+            f32x4 gb[4], ab[4];
 #pragma unroll
-                    for (int ei = 0; ei < 4; ++ei)
-                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[eo], av[ei], acc[eo][ei], 0, 0, 0);
-                bsum += gv;
+            for (int k = 0; k < 4; ++k) ld(k, gb[k], ab[k]);
+            int64_t s = 0;
+            for (; s + 32 <= nfull; s += 32) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    kstep(gb[k & 3], ab[k & 3]);
+                    ld(s + k + 4, gb[k & 3], ab[k & 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            for (; s < nfull; ++s) {  // remainder: only the last, partial chunk at the end of N
+                f32x4 gv, av;
+                ld(s, gv, av);
+                kstep(gv, av);
+            }
+        }
+        if ((r1 - r0) & 1) {  // odd tail (only at the very end of N): the second ray of the pair does not exist
+            const int64_t r = r1 - 1;
+            f32x4 gv = *reinterpret_cast<const f32x4*>(gp + r * R2L_W);
+            f32x4 av = *reinterpret_cast<const f32x4*>(ap + r * R2L_W);
+            if (hh) { gv = f32x4{0.f, 0.f, 0.f, 0.f}; av = gv; }
+            kstep(gv, av);
         }
         float* gw = a.grads + b_off_body_w(layer);
         float* gb = a.grads + b_off_body_b(layer);
@@ -418,6 +463,7 @@ __global__ __launch_bounds__(256) void r2l_dw_tail_kernel(const float* __restric
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
+extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
@@ -477,7 +523,7 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         if (per < 1) per = 1;
         wgs = (N + per - 1) / per;
         hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, save_x,
-                           save_x + (int64_t)n_block * N * R2L_W, grads, n_block, N, per);
+                           save_x + (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W, grads, n_block, N, per);
         R2L_CHECK(hipGetLastError());
     }
     return 0;

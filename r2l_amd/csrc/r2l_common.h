@@ -33,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define R2L_HEAD_ID_GROUPS 6                         // 24 identity features per half-wave
 #define R2L_HEAD_GROUPS (R2L_HEAD_TRIG_GROUPS + R2L_HEAD_ID_GROUPS)
 #define R2L_HEAD_FLOATS (R2L_HEAD_GROUPS * R2L_GROUP_FLOATS)    // 258048 = 1008*256
+#define R2L_PAD_ROWS(n) ((((int64_t)(n)) + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS * R2L_TILE_RAYS)
 #define R2L_STREAM_PAD (2 * R2L_GROUP_FLOATS)        // the prefetcher runs up to two groups past the end
 
 // feature index held by fragment register (T, c) in lane-half h
@@ -77,26 +78,59 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], const f32x4 (&
 
 // Pin the issue order of one group: the 8 prefetch loads of the NEXT group are spread one per 4 MFMAs of the
 // current group and may not sink below it (hipcc otherwise sinks them next to their use and the wave then
-// eats the full L2 latency with nothing else resident on the SIMD to hide it).
+// eats the full L2 latency with nothing else resident on the SIMD to hide it).  EXTRA_RD / EXTRA_WR: additional
+// VMEM reads / writes a hook issues inside the group (mask prefetch, stash store).
+template <int EXTRA_RD = 0, int EXTRA_WR = 0>
 __device__ __forceinline__ void r2l_pin_group_schedule() {
 #pragma unroll
     for (int i = 0; i < R2L_NT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+        if (i == 3 && EXTRA_WR > 0) __builtin_amdgcn_sched_group_barrier(0x040, EXTRA_WR, 0);
+        if (i == 5 && EXTRA_RD > 0) __builtin_amdgcn_sched_group_barrier(0x020, EXTRA_RD, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- per-group hooks: memory traffic that rides along a GEMM instead of bursting between GEMMs ---------------------
+struct NoHook {
+    static constexpr int RD = 0, WR = 0;
+    __device__ __forceinline__ void at(int) {}
+};
+
+// Stores the fragment that is the GEMM's B operand (so its registers stay live and unmodified for the whole GEMM) to a
+// row-major [N][256] tensor, one 16-byte piece per group: lane (ray j, half h) writes row*1 KiB + (32T + 8q + 4h)*4.
+// Stash tensors have r2l_padded_rows(N) = ceil(N/32)*32 rows per slot, so the lanes of a ragged last tile store to
+// their own padding rows: no predicate, no branch inside the GEMM.
+struct StoreHook {
+    static constexpr int RD = 0, WR = 1;
+    float* row;  // base + ray*256 + 4*h (per lane)
+    const f32x16 (&src)[R2L_NT];
+    __device__ __forceinline__ StoreHook(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT])
+        : row(base + ray * R2L_W + 4 * h), src(s) {}
+    __device__ __forceinline__ void at(int G) {
+        const int T = G >> 2, q = (G & 3) * 4;
+        const f32x4 v = {src[T][q + 0], src[T][q + 1], src[T][q + 2], src[T][q + 3]};
+        *reinterpret_cast<f32x4*>(row + 32 * T + 8 * (G & 3)) = v;
+    }
+};
+
 // acc += W[256x256] . in   (one full layer, 32 groups, 1024 MFMAs)
-__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws) {
+template <class Hook>
+__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws, Hook& hook) {
 #pragma unroll
     for (int G = 0; G < R2L_LAYER_GROUPS; ++G) {
         f32x4 w[R2L_NT];
         ws.advance(w);
+        hook.at(G);
         const int T = G >> 2, q = (G & 3) * 4;
         mfma_group(acc, w, in[T][q + 0], in[T][q + 1], in[T][q + 2], in[T][q + 3]);
-        r2l_pin_group_schedule();
+        r2l_pin_group_schedule<Hook::RD, Hook::WR>();
     }
+}
+__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws) {
+    NoHook nh;
+    gemm256(acc, in, ws, nh);
 }
 
 // acc[T][c] (+)= bias[feat(T,c,h)] read from the natural [256] bias vector as float4s
@@ -122,9 +156,7 @@ __device__ __forceinline__ void relu_inplace(f32x16 (&a)[R2L_NT]) {
 // Store / load a fragment to a row-major [N][256] fp32 tensor (saved activations / gradients).
 // Lane (ray j, half h) writes 16 B at row*1 KiB + (32T + 8q + 4h)*4: lanes j and j+32 complete a
 // 32-byte sector; the 32 (T,q) stores of one call complete every 128-byte line of the 32 rows.
-__device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t row, bool valid, int h,
-                                           const f32x16 (&a)[R2L_NT]) {
-    if (!valid) return;
+__device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t row, int h, const f32x16 (&a)[R2L_NT]) {
     float* r = base + row * R2L_W + 4 * h;
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)

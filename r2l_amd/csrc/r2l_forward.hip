@@ -24,8 +24,8 @@ struct R2LFwdArgs {
     int n_block;
     // outputs
     float* rgb;            // [N,3]
-    float* save_x;         // [(n_block+1)][N][256]  X_0 (=relu(head)), X_1 .. X_n   or nullptr
-    float* save_t;         // [n_block][N][256]      relu(hidden) of each block      or nullptr
+    float* save_x;         // [(n_block+1)][Np][256] (Np = N padded to 32)  X_0 (=relu(head)), X_1 .. X_n   or nullptr
+    float* save_t;         // [n_block][Np][256]     relu(hidden) of each block      or nullptr
     int64_t N;
 };
 
@@ -164,21 +164,30 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
     for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
         for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = x[T][c];
-    if constexpr (SAVE) store_frag(a.save_x, ray, valid, h, x);
 
     // body: x <- x + W2 relu(W1 x + b1) + b2     (ResMLP.forward with res_scale 1, nerf_raybased.py:461-465)
     const float* bias = a.params + off_body_b(0);
+    const int64_t Np = R2L_PAD_ROWS(a.N);  // rows per stash slot
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         add_bias<false>(t, bias, h);
-        gemm256(t, x, ws);
+        if constexpr (SAVE) {  // X_b is this GEMM's B operand: its stash store rides along, one 16-byte piece per group
+            StoreHook sx(a.save_x + (int64_t)b * Np * R2L_W, ray, h, x);
+            gemm256(t, x, ws, sx);
+        } else {
+            gemm256(t, x, ws);
+        }
         relu_inplace(t);
-        if constexpr (SAVE) store_frag(a.save_t + (int64_t)b * a.N * R2L_W, ray, valid, h, t);
         add_bias<true>(x, bias + (R2L_W * R2L_W + R2L_W), h);
-        gemm256(x, t, ws);
-        if constexpr (SAVE) store_frag(a.save_x + (int64_t)(b + 1) * a.N * R2L_W, ray, valid, h, x);
+        if constexpr (SAVE) {
+            StoreHook st(a.save_t + (int64_t)b * Np * R2L_W, ray, h, t);
+            gemm256(x, t, ws, st);
+        } else {
+            gemm256(x, t, ws);
+        }
         bias += 2 * (R2L_W * R2L_W + R2L_W);
     }
+    if constexpr (SAVE) store_frag(a.save_x + (int64_t)a.n_block * Np * R2L_W, ray, h, x);
 
     // tail: rgb = sigmoid(Wt (x + X_0) + bt)
     const float* tw = a.params + off_tail_w(a.n_block);

@@ -56,10 +56,11 @@ class R2LTrainer:
         dev, nb = self.eng.device, self.eng.n_block
         self.cap = n
         f = dict(dtype=torch.float32, device=dev)
-        self.save_x = torch.empty((nb + 1) * n * W, **f)
-        self.save_t = torch.empty(max(nb, 1) * n * W, **f)
-        self.gx = torch.empty((nb + 1) * n * W, **f)
-        self.gt = torch.empty(max(nb, 1) * n * W, **f)
+        npad = int(self.lib.r2l_padded_rows(n))  # rows per slot: N rounded up to a 32-ray tile
+        self.save_x = torch.empty((nb + 1) * npad * W, **f)
+        self.save_t = torch.empty(max(nb, 1) * npad * W, **f)
+        self.gx = torch.empty((nb + 1) * npad * W, **f)
+        self.gt = torch.empty(max(nb, 1) * npad * W, **f)
         self.dpre = torch.empty(n * 3, **f)
         self.sqerr = torch.empty(int(self.lib.r2l_num_tiles(n)), **f)
 
