@@ -45,22 +45,26 @@ struct BwdAHook {
     StoreHook st;
     const float* trow;  // save_t row of this lane (+4h)
     unsigned (&mb)[4];
-    f32x4 pend;
+    f32x4 pend[2];  // mask pieces in flight: consumed two groups after their load was issued
     __device__ __forceinline__ BwdAHook(float* gbase, const float* tbase, int64_t ray, int h,
                                         const f32x16 (&g)[R2L_NT], unsigned (&m)[4])
         : st(gbase, ray, h, g), trow(tbase + ray * R2L_W + 4 * h), mb(m) {}
     __device__ __forceinline__ void fold(int G) {
+        const f32x4 p = pend[G & 1];
         const int sh = ((G >> 2) & 1) * 16 + (G & 3) * 4;
-        unsigned bits = (pend[0] > 0.f ? 1u : 0u) | (pend[1] > 0.f ? 2u : 0u) | (pend[2] > 0.f ? 4u : 0u) |
-                        (pend[3] > 0.f ? 8u : 0u);
+        unsigned bits = (p[0] > 0.f ? 1u : 0u) | (p[1] > 0.f ? 2u : 0u) | (p[2] > 0.f ? 4u : 0u) |
+                        (p[3] > 0.f ? 8u : 0u);
         mb[G >> 3] |= bits << sh;
     }
     __device__ __forceinline__ void at(int G) {
         st.at(G);
-        if (G > 0) fold(G - 1);
-        pend = *reinterpret_cast<const f32x4*>(trow + 32 * (G >> 2) + 8 * (G & 3));
+        if (G > 1) fold(G - 2);
+        pend[G & 1] = *reinterpret_cast<const f32x4*>(trow + 32 * (G >> 2) + 8 * (G & 3));
     }
-    __device__ __forceinline__ void finish() { fold(R2L_LAYER_GROUPS - 1); }
+    __device__ __forceinline__ void finish() {
+        fold(R2L_LAYER_GROUPS - 2);
+        fold(R2L_LAYER_GROUPS - 1);
+    }
 };
 
 __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs a) {

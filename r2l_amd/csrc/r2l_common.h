@@ -33,6 +33,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define R2L_HEAD_ID_GROUPS 6                         // 24 identity features per half-wave
 #define R2L_HEAD_GROUPS (R2L_HEAD_TRIG_GROUPS + R2L_HEAD_ID_GROUPS)
 #define R2L_HEAD_FLOATS (R2L_HEAD_GROUPS * R2L_GROUP_FLOATS)    // 258048 = 1008*256
+// forward stream: every layer is preceded by ONE bias group (component 0 of each float4 = bias of the tile row, for the
+// k=0 half-wave only); the kernel turns it into 8 MFMAs against the constant B operand [1, 0], so the accumulators are
+// initialised by the matrix pipe (C = 0 inline) instead of 32 bias loads + 128 register writes per layer.
+#define R2L_FWD_HEAD_GROUPS (1 + R2L_HEAD_GROUPS)
+#define R2L_FWD_LAYER_GROUPS (1 + R2L_LAYER_GROUPS)
 #define R2L_PAD_ROWS(n) ((((int64_t)(n)) + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS * R2L_TILE_RAYS)
 #define R2L_STREAM_PAD (2 * R2L_GROUP_FLOATS)        // the prefetcher runs up to two groups past the end
 
@@ -40,54 +45,63 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int r2l_feat(int T, int c, int h) { return 32 * T + 8 * (c >> 2) + 4 * h + (c & 3); }
 
 // ---------------------------------------------------------------------------------------------
-// Weight stream reader: a wave walks the packed stream one group (8 x float4 per lane) at a time,
-// always holding the NEXT group in registers so that the loads are a full group (32 MFMAs = 2048
-// cycles) ahead of their use.  Fully unrolled call sites turn the cur/nxt swap into pure renaming.
+// Weight stream reader.  A wave walks the packed stream one group (8 tiles x float4 per lane) at a time with ONE
+// register buffer: a group is consumed tile-major (4 MFMAs on tile t's accumulator, then tile t+1, ...) and tile t's
+// registers are reloaded with the NEXT group's tile t right after its 4 MFMAs have issued.  Every load is therefore
+// issued exactly 28 MFMAs (1792 cycles) before its first use, for every tile.
 // ---------------------------------------------------------------------------------------------
 struct WStream {
     const f32x4* p;  // lane-adjusted pointer to the next group to LOAD
-    f32x4 nxt[R2L_NT];
+    f32x4 w[R2L_NT];
     __device__ __forceinline__ void init(const float* stream, int lane) {
         p = reinterpret_cast<const f32x4*>(stream) + lane;
 #pragma unroll
-        for (int t = 0; t < R2L_NT; ++t) nxt[t] = p[t * 64];
-        p += R2L_NT * 64;
-    }
-    // returns the current group and starts loading the following one
-    __device__ __forceinline__ void advance(f32x4 (&cur)[R2L_NT]) {
-#pragma unroll
-        for (int t = 0; t < R2L_NT; ++t) cur[t] = nxt[t];
-#pragma unroll
-        for (int t = 0; t < R2L_NT; ++t) nxt[t] = p[t * 64];
+        for (int t = 0; t < R2L_NT; ++t) w[t] = p[t * 64];
         p += R2L_NT * 64;
     }
 };
 
-// acc[256x32] += W_group . b  for the four k-pairs of one group.  b0..b3 are B-operand registers.
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], const f32x4 (&w)[R2L_NT], float b0, float b1,
-                                           float b2, float b3) {
-#pragma unroll
-    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][0], b0, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][1], b1, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][2], b2, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < R2L_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][3], b3, acc[t], 0, 0, 0);
-}
-
-// Pin the issue order of one group: the 8 prefetch loads of the NEXT group are spread one per 4 MFMAs of the
-// current group and may not sink below it (hipcc otherwise sinks them next to their use and the wave then
-// eats the full L2 latency with nothing else resident on the SIMD to hide it).  EXTRA_RD / EXTRA_WR: additional
-// VMEM reads / writes a hook issues inside the group (mask prefetch, stash store).
+// acc[256x32] += W_group . b  for the four k-pairs of the current group (b0..b3 = B-operand registers), and start
+// streaming the next group in.  Schedule pinned: [4 MFMA, 1 VMEM read] x 8 (hipcc otherwise sinks the prefetch
+// loads next to their use and the wave eats the L2 latency with nothing else resident on the SIMD to hide it).
+// EXTRA_RD / EXTRA_WR: VMEM reads / writes a hook issued just before (mask prefetch, stash store) go FIRST: vmcnt
+// retires in order, so they must be older than the group's weight loads to get a whole group to complete.
 template <int EXTRA_RD = 0, int EXTRA_WR = 0>
-__device__ __forceinline__ void r2l_pin_group_schedule() {
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WStream& ws, float b0, float b1, float b2, float b3) {
+#pragma unroll
+    for (int t = 0; t < R2L_NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][0], b0, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][1], b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][2], b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][3], b3, acc[t], 0, 0, 0);
+        ws.w[t] = ws.p[t * 64];
+    }
+    ws.p += R2L_NT * 64;
+    if (EXTRA_WR > 0) __builtin_amdgcn_sched_group_barrier(0x040, EXTRA_WR, 0);
+    if (EXTRA_RD > 0) __builtin_amdgcn_sched_group_barrier(0x020, EXTRA_RD, 0);
 #pragma unroll
     for (int i = 0; i < R2L_NT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-        if (i == 3 && EXTRA_WR > 0) __builtin_amdgcn_sched_group_barrier(0x040, EXTRA_WR, 0);
-        if (i == 5 && EXTRA_RD > 0) __builtin_amdgcn_sched_group_barrier(0x020, EXTRA_RD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Same for a layer with 4 output tiles: one stream load-group carries two k-groups (slots 0-3: k-group A, 4-7: B).
+__device__ __forceinline__ void mfma_group4x2(f32x16 (&acc)[4], WStream& ws, const float (&ba)[4], const float (&bb)[4]) {
+#pragma unroll
+    for (int s8 = 0; s8 < R2L_NT; ++s8) {
+        const int tt = s8 & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[s8][j], s8 < 4 ? ba[j] : bb[j], acc[tt], 0, 0, 0);
+        ws.w[s8] = ws.p[s8 * 64];
+    }
+    ws.p += R2L_NT * 64;
+#pragma unroll
+    for (int i = 0; i < R2L_NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -102,31 +116,61 @@ struct NoHook {
 // row-major [N][256] tensor, one 16-byte piece per group: lane (ray j, half h) writes row*1 KiB + (32T + 8q + 4h)*4.
 // Stash tensors have r2l_padded_rows(N) = ceil(N/32)*32 rows per slot, so the lanes of a ragged last tile store to
 // their own padding rows: no predicate, no branch inside the GEMM.
-struct StoreHook {
+template <bool RELU = false>
+struct StoreHookT {
     static constexpr int RD = 0, WR = 1;
     float* row;  // base + ray*256 + 4*h (per lane)
     const f32x16 (&src)[R2L_NT];
-    __device__ __forceinline__ StoreHook(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT])
+    __device__ __forceinline__ StoreHookT(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT])
         : row(base + ray * R2L_W + 4 * h), src(s) {}
     __device__ __forceinline__ void at(int G) {
         const int T = G >> 2, q = (G & 3) * 4;
-        const f32x4 v = {src[T][q + 0], src[T][q + 1], src[T][q + 2], src[T][q + 3]};
+        f32x4 v = {src[T][q + 0], src[T][q + 1], src[T][q + 2], src[T][q + 3]};
+        if (RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
         *reinterpret_cast<f32x4*>(row + 32 * T + 8 * (G & 3)) = v;
     }
 };
+typedef StoreHookT<false> StoreHook;
 
-// acc += W[256x256] . in   (one full layer, 32 groups, 1024 MFMAs)
-template <class Hook>
-__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws, Hook& hook) {
+// Consume one bias group of the forward stream: acc (+)= bias x [1,0]^T  — 8 MFMAs, one per tile.
+template <bool ZERO_INIT>
+__device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WStream& ws, float one_h0) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < R2L_NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][0], one_h0, ZERO_INIT ? zero : acc[t], 0, 0, 0);
+        ws.w[t] = ws.p[t * 64];
+    }
+    ws.p += R2L_NT * 64;
+#pragma unroll
+    for (int i = 0; i < R2L_NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc += W[256x256] . act(in)   (one full layer, 32 groups, 1024 MFMAs).  RELU_IN applies the ReLU lazily to the four
+// B-operand registers of each group (VALU work hidden in the MFMA shadow) instead of a 384-instruction burst between
+// the GEMMs; `in` itself keeps the pre-activation values.
+template <bool RELU_IN, class Hook>
+__device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws, Hook& hook) {
 #pragma unroll
     for (int G = 0; G < R2L_LAYER_GROUPS; ++G) {
-        f32x4 w[R2L_NT];
-        ws.advance(w);
         hook.at(G);
         const int T = G >> 2, q = (G & 3) * 4;
-        mfma_group(acc, w, in[T][q + 0], in[T][q + 1], in[T][q + 2], in[T][q + 3]);
-        r2l_pin_group_schedule<Hook::RD, Hook::WR>();
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = RELU_IN ? fmaxf(in[T][q + j], 0.f) : in[T][q + j];
+        mfma_group<Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
     }
+}
+template <class Hook>
+__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws, Hook& hook) {
+    gemm256x<false>(acc, in, ws, hook);
 }
 __device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws) {
     NoHook nh;

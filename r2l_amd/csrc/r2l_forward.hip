@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
     ws.init(a.wstream, lane);
 
     f32x16 x[R2L_NT], t[R2L_NT];
-    add_bias<false>(x, a.params + off_head_b(), h);
+    const float one_h0 = h ? 0.f : 1.f;  // B operand of the bias k-step: k = 0 is carried by the lower half-wave
+    mfma_bias_group<true>(x, ws, one_h0);  // x = head bias
 
     if constexpr (MODE == MODE_EMB) {
         // B operand straight from the embedded input: stream step s of half h reads emb[ray][s + 504 h]
@@ -68,17 +69,13 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
                 const float* ec = e + (it * 3 + ax) * 21;
 #pragma unroll
                 for (int g = 0; g < 5; ++g) {
-                    f32x4 w[R2L_NT];
-                    ws.advance(w);
-                    mfma_group(x, w, ec[4 * g + 0], ec[4 * g + 1], ec[4 * g + 2], ec[4 * g + 3]);
+                    mfma_group(x, ws, ec[4 * g + 0], ec[4 * g + 1], ec[4 * g + 2], ec[4 * g + 3]);
                 }
             }
         }
 #pragma unroll
         for (int g = 0; g < R2L_HEAD_ID_GROUPS; ++g) {
-            f32x4 w[R2L_NT];
-            ws.advance(w);
-            mfma_group(x, w, e[(4 * g + 0) * 21 + 20], e[(4 * g + 1) * 21 + 20], e[(4 * g + 2) * 21 + 20],
+            mfma_group(x, ws, e[(4 * g + 0) * 21 + 20], e[(4 * g + 1) * 21 + 20], e[(4 * g + 2) * 21 + 20],
                        e[(4 * g + 3) * 21 + 20]);
         }
     } else {
@@ -138,9 +135,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
                 for (int k = 0; k < R2L_L; ++k) r2l_sincos(xc * (float)(1 << k), f[k], f[R2L_L + k]);
 #pragma unroll
                 for (int g = 0; g < 5; ++g) {
-                    f32x4 w[R2L_NT];
-                    ws.advance(w);
-                    mfma_group(x, w, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+                    mfma_group(x, ws, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
                 }
             }
         }
@@ -151,9 +146,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
             for (int e = 0; e < 24; ++e) id[e] = o[e % 3] + d[e % 3] * z[e / 3];
 #pragma unroll
             for (int g = 0; g < R2L_HEAD_ID_GROUPS; ++g) {
-                f32x4 w[R2L_NT];
-                ws.advance(w);
-                mfma_group(x, w, id[4 * g + 0], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
+                mfma_group(x, ws, id[4 * g + 0], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
             }
         }
     }
@@ -166,26 +159,27 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
         for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = x[T][c];
 
     // body: x <- x + W2 relu(W1 x + b1) + b2     (ResMLP.forward with res_scale 1, nerf_raybased.py:461-465)
-    const float* bias = a.params + off_body_b(0);
     const int64_t Np = R2L_PAD_ROWS(a.N);  // rows per stash slot
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
-        add_bias<false>(t, bias, h);
+        // t = W1 x + b1 (pre-activation; its ReLU is applied on the fly when t feeds the second GEMM)
+        mfma_bias_group<true>(t, ws, one_h0);
         if constexpr (SAVE) {  // X_b is this GEMM's B operand: its stash store rides along, one 16-byte piece per group
             StoreHook sx(a.save_x + (int64_t)b * Np * R2L_W, ray, h, x);
-            gemm256(t, x, ws, sx);
+            gemm256x<false>(t, x, ws, sx);
         } else {
-            gemm256(t, x, ws);
+            NoHook nh;
+            gemm256x<false>(t, x, ws, nh);
         }
-        relu_inplace(t);
-        add_bias<true>(x, bias + (R2L_W * R2L_W + R2L_W), h);
+        // x += W2 relu(t) + b2
+        mfma_bias_group<false>(x, ws, one_h0);
         if constexpr (SAVE) {
-            StoreHook st(a.save_t + (int64_t)b * Np * R2L_W, ray, h, t);
-            gemm256(x, t, ws, st);
+            StoreHookT<true> st(a.save_t + (int64_t)b * Np * R2L_W, ray, h, t);
+            gemm256x<true>(x, t, ws, st);
         } else {
-            gemm256(x, t, ws);
+            NoHook nh;
+            gemm256x<true>(x, t, ws, nh);
         }
-        bias += 2 * (R2L_W * R2L_W + R2L_W);
     }
     if constexpr (SAVE) store_frag(a.save_x + (int64_t)a.n_block * Np * R2L_W, ray, h, x);
 

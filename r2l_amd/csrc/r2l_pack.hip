@@ -7,9 +7,11 @@ __host__ __device__ static inline int64_t pk_off_body_w(int layer) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
 }
 
-// forward stream: head trig groups (sample it, axis, g) | head identity groups | body layers in execution order
+// forward stream: [head bias group | head trig groups (sample it, axis, g) | head identity groups] then per body layer
+// [bias group | 32 weight groups] in execution order.  Bias group: float4 component 0 of lane (l<32) of tile t holds
+// bias[32t + l]; everything else is 0 (the kernel multiplies it by the B operand [1, 0]).
 __global__ void r2l_pack_fwd_kernel(const float* __restrict__ params, float* __restrict__ out, int n_block) {
-    const int64_t total = (int64_t)R2L_HEAD_FLOATS + (int64_t)2 * n_block * R2L_LAYER_FLOATS;
+    const int64_t total = (int64_t)(R2L_FWD_HEAD_GROUPS + 2 * n_block * R2L_FWD_LAYER_GROUPS) * R2L_GROUP_FLOATS;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + R2L_STREAM_PAD;
          i += (int64_t)gridDim.x * blockDim.x) {
         if (i >= total) { out[i] = 0.f; continue; }
@@ -17,22 +19,31 @@ __global__ void r2l_pack_fwd_kernel(const float* __restrict__ params, float* __r
         const int rem = (int)(i % R2L_GROUP_FLOATS);
         const int tile = rem >> 8, lane = (rem & 255) >> 2, j = rem & 3;
         const int h = lane >> 5, o = 32 * tile + (lane & 31);
-        int64_t src;
-        if (gidx < R2L_HEAD_TRIG_GROUPS) {
-            const int it = (int)gidx / 15, ax = ((int)gidx % 15) / 5, g = (int)gidx % 5;
-            const int k = ((8 * h + it) * 3 + ax) * 21 + 4 * g + j;
-            src = (int64_t)o * R2L_IN + k;
-        } else if (gidx < R2L_HEAD_GROUPS) {
-            const int e = 4 * ((int)gidx - R2L_HEAD_TRIG_GROUPS) + j;
-            const int k = (24 * h + e) * 21 + 20;
-            src = (int64_t)o * R2L_IN + k;
+        float v;
+        if (gidx < R2L_FWD_HEAD_GROUPS) {
+            const int g1 = (int)gidx - 1;
+            if (g1 < 0) {
+                v = (j == 0 && h == 0) ? params[(int64_t)R2L_IN * R2L_W + o] : 0.f;
+            } else if (g1 < R2L_HEAD_TRIG_GROUPS) {
+                const int it = g1 / 15, ax = (g1 % 15) / 5, g = g1 % 5;
+                const int k = ((8 * h + it) * 3 + ax) * 21 + 4 * g + j;
+                v = params[(int64_t)o * R2L_IN + k];
+            } else {
+                const int e = 4 * (g1 - R2L_HEAD_TRIG_GROUPS) + j;
+                const int k = (24 * h + e) * 21 + 20;
+                v = params[(int64_t)o * R2L_IN + k];
+            }
         } else {
-            const int64_t gb = gidx - R2L_HEAD_GROUPS;
-            const int layer = (int)(gb / R2L_LAYER_GROUPS), G = (int)(gb % R2L_LAYER_GROUPS);
-            const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
-            src = pk_off_body_w(layer) + (int64_t)o * R2L_W + in;
+            const int64_t gb = gidx - R2L_FWD_HEAD_GROUPS;
+            const int layer = (int)(gb / R2L_FWD_LAYER_GROUPS), G = (int)(gb % R2L_FWD_LAYER_GROUPS) - 1;
+            if (G < 0) {
+                v = (j == 0 && h == 0) ? params[pk_off_body_w(layer) + R2L_W * R2L_W + o] : 0.f;
+            } else {
+                const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
+                v = params[pk_off_body_w(layer) + (int64_t)o * R2L_W + in];
+            }
         }
-        out[i] = params[src];
+        out[i] = v;
     }
 }
 
@@ -58,7 +69,7 @@ extern "C" int64_t r2l_param_count(int n_block) {
 }
 
 extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
-    return (int64_t)R2L_HEAD_FLOATS + (int64_t)2 * n_block * R2L_LAYER_FLOATS + R2L_STREAM_PAD;
+    return (int64_t)(R2L_FWD_HEAD_GROUPS + 2 * n_block * R2L_FWD_LAYER_GROUPS) * R2L_GROUP_FLOATS + R2L_STREAM_PAD;
 }
 
 extern "C" int64_t r2l_bwd_stream_floats(int n_block) {

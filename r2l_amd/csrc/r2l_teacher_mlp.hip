@@ -131,10 +131,7 @@ __device__ __forceinline__ void t_xyz_feats(const float (&p)[3], int h, float (&
 __device__ __forceinline__ void t_pe_gemm(f32x16 (&acc)[R2L_NT], const float (&f)[T_PE_STEPS], WStream& ws) {
 #pragma unroll
     for (int g = 0; g < T_PE_GROUPS; ++g) {
-        f32x4 w[R2L_NT];
-        ws.advance(w);
-        mfma_group(acc, w, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
-        r2l_pin_group_schedule();
+        mfma_group(acc, ws, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
     }
 }
 
@@ -214,18 +211,12 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
         }
 #pragma unroll
     for (int G2 = 0; G2 < 16; ++G2) {
-        f32x4 w[R2L_NT];
-        ws.advance(w);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int G = 2 * G2 + half, T = G >> 2, q = (G & 3) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    v[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[half * 4 + tt][j], x[T][q + j], v[tt], 0, 0, 0);
-        }
-        r2l_pin_group_schedule();
+        const int Ga = 2 * G2, Gb = 2 * G2 + 1;
+        const float ba[4] = {x[Ga >> 2][(Ga & 3) * 4 + 0], x[Ga >> 2][(Ga & 3) * 4 + 1], x[Ga >> 2][(Ga & 3) * 4 + 2],
+                             x[Ga >> 2][(Ga & 3) * 4 + 3]};
+        const float bb[4] = {x[Gb >> 2][(Gb & 3) * 4 + 0], x[Gb >> 2][(Gb & 3) * 4 + 1], x[Gb >> 2][(Gb & 3) * 4 + 2],
+                             x[Gb >> 2][(Gb & 3) * 4 + 3]};
+        mfma_group4x2(v, ws, ba, bb);
     }
     {
         float fd[T_DIR_STEPS];
@@ -240,17 +231,9 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
         fd[15] = 0.f;
 #pragma unroll
         for (int G2 = 0; G2 < 2; ++G2) {
-            f32x4 w[R2L_NT];
-            ws.advance(w);
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        v[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[half * 4 + tt][j], fd[(2 * G2 + half) * 4 + j],
-                                                                     v[tt], 0, 0, 0);
-            r2l_pin_group_schedule();
+            const float ba[4] = {fd[8 * G2 + 0], fd[8 * G2 + 1], fd[8 * G2 + 2], fd[8 * G2 + 3]};
+            const float bb[4] = {fd[8 * G2 + 4], fd[8 * G2 + 5], fd[8 * G2 + 6], fd[8 * G2 + 7]};
+            mfma_group4x2(v, ws, ba, bb);
         }
     }
     // rgb = Wrgb relu(v) + b
