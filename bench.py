@@ -106,6 +106,34 @@ def cpu_baseline(O, sd, n_rays=8192, repeats=1):
                       % (n_rays, repeats, cpu_model)}, rgb, rows
 
 
+def teacher_leg(O, device, world, rank, distributed, frames=2):
+    """NeRF-teacher pseudo-data render (BASELINE configs[4]): `frames` 400x400 poses per GPU, 64 coarse + 128 fine
+    samples, perturb=1 (create_data.py 'rand' settings), seeded D8W256 teacher pair; poses shard over ranks."""
+    from model.nerf_raybased import NeRF
+    from r2l_amd.render import render
+    nets = []
+    for sd in O.make_teacher_state_dicts(11, 2, alpha_bias=0.5):
+        m = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+        m.load_state_dict(sd)
+        nets.append(m.to(device))
+    kw = dict(network_fn=nets[0], network_query_fn=None, N_samples=64, N_importance=128, network_fine=nets[1],
+              white_bkgd=True, perturb=1., ndc=False, near=2., far=6., use_viewdirs=True)
+    poses = [torch.from_numpy(O.pose_spherical(17. * (i * world + rank), -35., 4.)[:3, :4]).to(device)
+             for i in range(frames + 1)]
+
+    def step(i):
+        with torch.no_grad():
+            render(H, W, FOCAL, chunk=32768, c2w=poses[i % len(poses)], **kw)
+
+    dt, step_ms = timed(step, frames, 1, distributed, device)
+    flop_per_ray = 2 * 593408 * 256  # 303.82 MFLOP/ray (BASELINE.md)
+    achieved = H * W * flop_per_ray / (step_ms * 1e-3) / 1e12
+    return {"value": H * W * frames * world / dt, "unit": "rays/s", "ms_per_frame": dt / frames * 1e3,
+            "workload": "NeRF teacher render 400x400, 64+128 samples/ray, perturb=1, chunk 32768 (create_data rand)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA, "flop_per_ray": flop_per_ray}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +143,7 @@ def main():
                     help="rays per GPU per training step (README: N_rand 20 x 4096 + 20%% hard rays)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-teacher", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,6 +205,8 @@ def main():
         out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
                                        PEAK_FP32_MFMA)
 
+    if not a.no_teacher:
+        out["teacher"] = teacher_leg(O, device, world, rank, distributed)
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -327,27 +327,46 @@ struct R2LDwHeadArgs {
     const float* ztab;
     const float* emb;  // [N,1008] given encoding (module-boundary path) or nullptr -> recompute from the rays
     const float* gh;   // [N,256] = gx[0]
+    float* slab;       // [n_slices][256][1024] per-slice partial dW (plain stores, reduced in fixed order) or nullptr
     float* grads;
     int64_t N;
     int64_t rays_per_wg;
 };
 
-__device__ __forceinline__ float pe_feature(int k, const float* __restrict__ o, const float* __restrict__ d,
-                                            const float* __restrict__ tr, const float* __restrict__ ztab, bool jitter) {
-    // column k of PositionalEmbedder's output for one ray: coord c = k/21 (sample c/3, axis c%3), slot f = k%21
-    if (k >= R2L_IN) return 0.f;
-    const int c = k / 21, f = k - 21 * c;
-    const int smp = c / 3, ax = c - 3 * smp;
-    float z = ztab[smp];
-    if (jitter) z = z + ztab[16 + smp] * tr[smp];
-    const float x = o[ax] + d[ax] * z;
-    if (f == 20) return x;
-    const int kk = f < 10 ? f : f - 10;
+// Per-lane description of one encoding column k (fixed for the whole kernel): which sample / axis it reads and what it
+// applies.  column k of PositionalEmbedder's output: coord c = k/21 (sample c/3, axis c%3), slot f = k%21
+// (f < 10: sin(2^f x), 10 <= f < 20: cos(2^(f-10) x), f == 20: x).
+struct PECol {
+    int smp, ax;
+    float scale;  // 2^freq (trig columns)
+    int kind;     // 0 sin, 1 cos, 2 identity, 3 padding (k >= 1008)
+};
+__device__ __forceinline__ PECol pe_col(int k) {
+    PECol c;
+    if (k >= R2L_IN) { c.smp = 0; c.ax = 0; c.scale = 0.f; c.kind = 3; return c; }
+    const int co = k / 21, f = k - 21 * co;
+    c.smp = co / 3;
+    c.ax = co - 3 * c.smp;
+    c.kind = f == 20 ? 2 : (f < 10 ? 0 : 1);
+    c.scale = f == 20 ? 1.f : (float)(1 << (f < 10 ? f : f - 10));
+    return c;
+}
+// value of the column for the point x = o + d*z of one ray
+__device__ __forceinline__ float pe_eval(const PECol& c, float x) {
     float s, co;
-    r2l_sincos(x * (float)(1 << kk), s, co);
-    return f < 10 ? s : co;
+    r2l_sincos(x * c.scale, s, co);
+    const float t = c.kind == 0 ? s : co;
+    return c.kind == 2 ? x : (c.kind == 3 ? 0.f : t);
 }
 
+struct HeadStep {  // raw operands of one k-step (two rays), as loaded
+    f32x4 g0, g1;
+    float o0, d0, u0, o1, d1, u1;
+};
+
+// FROM_EMB / JITTER are compile-time so that the pipelined loop body is branch-free (runtime flags inside it made hipcc
+// emit per-load branches, spills and vmcnt(0) drains).
+template <bool FROM_EMB, bool JITTER>
 __global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hh = lane >> 5, jl = lane & 31;
@@ -358,7 +377,14 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs
     if (r1 > a.N) r1 = a.N;
     if (r0 >= r1) return;
     const int kbase = kq * 256 + wave * 64;
-    const bool jitter = a.t_rand != nullptr && a.emb == nullptr;
+    constexpr bool from_emb = FROM_EMB;
+    constexpr bool jitter = JITTER && !FROM_EMB;
+    const int k0 = kbase + jl, k1 = kbase + 32 + jl;
+    const PECol c0 = pe_col(k0), c1 = pe_col(k1);
+    const int e0 = k0 < R2L_IN ? k0 : R2L_IN - 1, e1 = k1 < R2L_IN ? k1 : R2L_IN - 1;  // clamped emb columns
+    const float m0 = k0 < R2L_IN ? 1.f : 0.f, m1 = k1 < R2L_IN ? 1.f : 0.f;
+    const float zl0 = from_emb ? 0.f : a.ztab[c0.smp], zs0 = jitter ? a.ztab[16 + c0.smp] : 0.f;
+    const float zl1 = from_emb ? 0.f : a.ztab[c1.smp], zs1 = jitter ? a.ztab[16 + c1.smp] : 0.f;
 
     f32x16 acc[8][2];
 #pragma unroll
@@ -369,44 +395,99 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs
             for (int c = 0; c < 16; ++c) acc[eo][ei][c] = 0.f;
     f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f};
 
-    const int64_t nsteps = (r1 - r0 + 1) / 2;
-    for (int64_t s = 0; s < nsteps; ++s) {
-        const int64_t r = r0 + 2 * s + hh;
-        const bool ok = r < r1;
-        const int64_t rr = ok ? r : r1 - 1;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gh + rr * R2L_W + 4 * jl);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gh + rr * R2L_W + 128 + 4 * jl);
-        const float* o = a.rays_o + (a.emb ? 0 : rr * 3);
-        const float* d = a.rays_d + (a.emb ? 0 : rr * 3);
-        const float* tr = jitter ? a.t_rand + rr * 16 : nullptr;
-        float p0, p1;
-        if (a.emb != nullptr) {
-            const int k0 = kbase + jl, k1 = kbase + 32 + jl;
-            p0 = k0 < R2L_IN ? a.emb[rr * R2L_IN + k0] : 0.f;
-            p1 = k1 < R2L_IN ? a.emb[rr * R2L_IN + k1] : 0.f;
+    const int64_t nfull = (r1 - r0) / 2;
+    // unconditional loads of k-step s (row index clamped into the slice)
+    auto ld = [&](int64_t s, HeadStep& v) {
+        const int64_t sc = s < nfull ? s : (nfull > 0 ? nfull - 1 : 0);
+        const int64_t r = r0 + 2 * sc + hh;
+        v.g0 = *reinterpret_cast<const f32x4*>(a.gh + r * R2L_W + 4 * jl);
+        v.g1 = *reinterpret_cast<const f32x4*>(a.gh + r * R2L_W + 128 + 4 * jl);
+        if constexpr (from_emb) {
+            v.o0 = a.emb[r * R2L_IN + e0];
+            v.o1 = a.emb[r * R2L_IN + e1];
+            v.d0 = v.d1 = v.u0 = v.u1 = 0.f;
         } else {
-            p0 = pe_feature(kbase + jl, o, d, tr, a.ztab, jitter);
-            p1 = pe_feature(kbase + 32 + jl, o, d, tr, a.ztab, jitter);
+            v.o0 = a.rays_o[r * 3 + c0.ax]; v.d0 = a.rays_d[r * 3 + c0.ax];
+            v.o1 = a.rays_o[r * 3 + c1.ax]; v.d1 = a.rays_d[r * 3 + c1.ax];
+            if constexpr (jitter) {
+                v.u0 = a.t_rand[r * 16 + c0.smp];
+                v.u1 = a.t_rand[r * 16 + c1.smp];
+            } else {
+                v.u0 = v.u1 = 0.f;
+            }
         }
-        f32x4 gg0 = g0, gg1 = g1;
-        if (!ok) {
-            gg0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            gg1 = gg0;
-            p0 = 0.f;
-            p1 = 0.f;
-        }
+    };
+    auto encode = [&](const HeadStep& v, float& p0, float& p1) {
+        if constexpr (from_emb) { p0 = v.o0 * m0; p1 = v.o1 * m1; return; }
+        const float z0 = jitter ? zl0 + zs0 * v.u0 : zl0;
+        const float z1 = jitter ? zl1 + zs1 * v.u1 : zl1;
+        p0 = pe_eval(c0, v.o0 + v.d0 * z0);
+        p1 = pe_eval(c1, v.o1 + v.d1 * z1);
+    };
+    auto kstep = [&](const f32x4& g0, const f32x4& g1, float p0, float p1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg0[e], p0, acc[e][0], 0, 0, 0);
-            acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg0[e], p1, acc[e][1], 0, 0, 0);
-            acc[4 + e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg1[e], p0, acc[4 + e][0], 0, 0, 0);
-            acc[4 + e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg1[e], p1, acc[4 + e][1], 0, 0, 0);
+            acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[e], p0, acc[e][0], 0, 0, 0);
+            acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[e], p1, acc[e][1], 0, 0, 0);
+            acc[4 + e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[e], p0, acc[4 + e][0], 0, 0, 0);
+            acc[4 + e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[e], p1, acc[4 + e][1], 0, 0, 0);
         }
-        bs0 += gg0;
-        bs1 += gg1;
+        bs0 += g0;
+        bs1 += g1;
+    };
+    if (nfull > 0) {
+        // 4 rotating raw-operand buffers (loads three k-steps ahead); the encoding of k-step s+1 is evaluated on the
+        // VALU while the 32 MFMAs of k-step s run.  16 k-steps per loop trip (hipcc drains vmcnt at loop headers).
+        HeadStep hb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ld(k, hb[k]);
+        float pa0, pa1;
+        encode(hb[0], pa0, pa1);
+        int64_t s = 0;
+        for (; s + 16 <= nfull; s += 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const f32x4 g0 = hb[k & 3].g0, g1 = hb[k & 3].g1;
+                float pn0, pn1;
+                encode(hb[(k + 1) & 3], pn0, pn1);  // next k-step's columns
+                kstep(g0, g1, pa0, pa1);
+                ld(s + k + 4, hb[k & 3]);
+                pa0 = pn0;
+                pa1 = pn1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (; s < nfull; ++s) {  // remainder of the slice
+            HeadStep v;
+            ld(s, v);
+            float p0, p1;
+            encode(v, p0, p1);
+            kstep(v.g0, v.g1, p0, p1);
+        }
+    }
+    if ((r1 - r0) & 1) {  // odd tail: only the lower half-wave's ray exists
+        const int64_t r = r1 - 1;
+        HeadStep v;
+        v.g0 = *reinterpret_cast<const f32x4*>(a.gh + r * R2L_W + 4 * jl);
+        v.g1 = *reinterpret_cast<const f32x4*>(a.gh + r * R2L_W + 128 + 4 * jl);
+        if constexpr (from_emb) {
+            v.o0 = a.emb[r * R2L_IN + e0];
+            v.o1 = a.emb[r * R2L_IN + e1];
+            v.d0 = v.d1 = v.u0 = v.u1 = 0.f;
+        } else {
+            v.o0 = a.rays_o[r * 3 + c0.ax]; v.d0 = a.rays_d[r * 3 + c0.ax];
+            v.o1 = a.rays_o[r * 3 + c1.ax]; v.d1 = a.rays_d[r * 3 + c1.ax];
+            v.u0 = jitter ? a.t_rand[r * 16 + c0.smp] : 0.f;
+            v.u1 = jitter ? a.t_rand[r * 16 + c1.smp] : 0.f;
+        }
+        float p0, p1;
+        encode(v, p0, p1);
+        if (hh) { v.g0 = f32x4{0.f, 0.f, 0.f, 0.f}; v.g1 = v.g0; p0 = 0.f; p1 = 0.f; }
+        kstep(v.g0, v.g1, p0, p1);
     }
     // flush: output row o = half*128 + 4*ro + e, encoding column k = kbase + ei*32 + jl
     float* gw = a.grads;  // head.0.weight is first in the flat buffer, [256][1008]
+    float* sl = a.slab ? a.slab + slice * (int64_t)(R2L_W * 1024) : nullptr;
 #pragma unroll
     for (int eo = 0; eo < 8; ++eo)
 #pragma unroll
@@ -416,7 +497,8 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs
                 const int ro = (c & 3) + 8 * (c >> 2) + 4 * hh;
                 const int o = (eo >> 2) * 128 + 4 * ro + (eo & 3);
                 const int k = kbase + ei * 32 + jl;
-                if (k < R2L_IN) atomicAdd(gw + (int64_t)o * R2L_IN + k, acc[eo][ei][c]);
+                if (sl) sl[o * 1024 + k] = acc[eo][ei][c];  // 64 slices x 64-way same-address atomics are slow
+                else if (k < R2L_IN) atomicAdd(gw + (int64_t)o * R2L_IN + k, acc[eo][ei][c]);
             }
     if (kq == 0 && wave == 0) {
         float* gb = a.grads + b_off_head_b();
@@ -430,6 +512,17 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs
             }
         }
     }
+}
+
+// dWh[o][k] += sum over slices of slab[slice][o][k], slices added in index order (deterministic)
+__global__ void r2l_head_reduce_kernel(const float* __restrict__ slab, int n_slices, float* __restrict__ grads) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [256][1024]
+    if (i >= (int64_t)R2L_W * 1024) return;
+    const int o = (int)(i >> 10), k = (int)(i & 1023);
+    if (k >= R2L_IN) return;
+    float s = 0.f;
+    for (int sidx = 0; sidx < n_slices; ++sidx) s += slab[(int64_t)sidx * (R2L_W * 1024) + i];
+    grads[(int64_t)o * R2L_IN + k] += s;
 }
 
 // =================================================================================================================
@@ -517,8 +610,20 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         if (per < 2) per = 2;
         slices = (N + per - 1) / per;
         a.rays_per_wg = per;
-        hipLaunchKernelGGL(r2l_dw_head_kernel, dim3((unsigned)(slices * 4)), dim3(256), 0, stream, a);
+        // per-slice partials go to the (by now dead) gt scratch when it is large enough, else fp32 atomics
+        const int64_t slab_floats = slices * (int64_t)(R2L_W * 1024);
+        const int64_t gt_floats = (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W;
+        a.slab = (slices > 1 && slab_floats <= gt_floats) ? gt : nullptr;
+        const dim3 hg((unsigned)(slices * 4)), hb(256);
+        if (emb != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<true, false>), hg, hb, 0, stream, a);
+        else if (t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<false, true>), hg, hb, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_dw_head_kernel<false, false>), hg, hb, 0, stream, a);
         R2L_CHECK(hipGetLastError());
+        if (a.slab) {
+            hipLaunchKernelGGL(r2l_head_reduce_kernel, dim3(R2L_W * 1024 / 256), dim3(256), 0, stream, a.slab,
+                               (int)slices, grads);
+            R2L_CHECK(hipGetLastError());
+        }
     }
     // 4. tail gradients
     {
