@@ -51,15 +51,20 @@ __host__ __device__ static inline int t_dir_col(int s, int h) {
     return -1;
 }
 
-// stream layout (units: load-groups of 8 float4 per lane = 2048 floats)
-#define TG_L0 0
-#define TG_BODY (TG_L0 + T_PE_GROUPS)                 // layers 1..4: 4 x 32
-#define TG_L5PE (TG_BODY + 4 * 32)
-#define TG_L5H (TG_L5PE + T_PE_GROUPS)
-#define TG_L67F (TG_L5H + 32)                         // layers 6, 7, feature: 3 x 32
-#define TG_VIEWS (TG_L67F + 3 * 32)                   // 32 k-groups x 4 tiles = 16 load-groups
+// stream layout (units: load-groups of 8 float4 per lane = 2048 floats); "B*" = bias group (r2l_common.h)
+//   [B0][L0 pe x9] {[B_i][L_i x32]} i=1..4  [B5][L5 pe x9][L5 h x32] [B6][L6 x32] [B7][L7 x32] [BF][feature x32]
+//   [BV][views(feature part) x16][views(dir part) x2]
+#define TG_B0 0
+#define TG_L0 1
+#define TG_BODY (TG_L0 + T_PE_GROUPS)                 // 10: layers 1..4, 33 groups each (bias + 32)
+#define TG_B5 (TG_BODY + 4 * 33)                      // 142
+#define TG_L5PE (TG_B5 + 1)
+#define TG_L5H (TG_L5PE + T_PE_GROUPS)                // 152
+#define TG_L67F (TG_L5H + 32)                         // 184: layers 6, 7, feature: 33 groups each
+#define TG_BV (TG_L67F + 3 * 33)                      // 283
+#define TG_VIEWS (TG_BV + 1)                          // 32 k-groups x 4 tiles = 16 load-groups
 #define TG_VDIR (TG_VIEWS + 16)                       // 4 k-groups x 4 tiles = 2 load-groups
-#define TG_TOTAL (TG_VDIR + 2)
+#define TG_TOTAL (TG_VDIR + 2)                        // 302
 
 __global__ void r2l_pack_teacher_kernel(const float* __restrict__ params, float* __restrict__ out) {
     const TOff off = t_offsets();
@@ -71,34 +76,48 @@ __global__ void r2l_pack_teacher_kernel(const float* __restrict__ params, float*
         const int rem = (int)(i % R2L_GROUP_FLOATS);
         const int slot = rem >> 8, lane = (rem & 255) >> 2, j = rem & 3;
         const int h = lane >> 5, jl = lane & 31;
+        const int o = 32 * slot + jl;
+        // decode the group: kind 0 bias (bias offset in `boff`), 1 xyz-embedding part (layer 0 or 5), 2 256->256 layer,
+        // 3 views feature part, 4 views direction part
+        int kind, layer = 0, G = 0;
+        int64_t boff = 0;
+        if (gidx == TG_B0) { kind = 0; boff = off.b[0]; }
+        else if (gidx < TG_BODY) { kind = 1; layer = 0; G = gidx - TG_L0; }
+        else if (gidx < TG_B5) {
+            layer = 1 + (gidx - TG_BODY) / 33; G = (gidx - TG_BODY) % 33 - 1;
+            kind = G < 0 ? 0 : 2; boff = off.b[layer];
+        }
+        else if (gidx == TG_B5) { kind = 0; boff = off.b[5]; }
+        else if (gidx < TG_L5H) { kind = 1; layer = 5; G = gidx - TG_L5PE; }
+        else if (gidx < TG_L67F) { kind = 2; layer = 5; G = gidx - TG_L5H; }
+        else if (gidx < TG_BV) {
+            layer = 6 + (gidx - TG_L67F) / 33; G = (gidx - TG_L67F) % 33 - 1;  // 6, 7, 8 (= feature_linear)
+            kind = G < 0 ? 0 : 2; boff = layer == 8 ? off.feat_b : off.b[layer];
+        }
+        else if (gidx == TG_BV) { kind = 0; boff = off.views_b; }
+        else if (gidx < TG_VDIR) { kind = 3; G = gidx - TG_VIEWS; }
+        else { kind = 4; G = gidx - TG_VDIR; }
         float v = 0.f;
-        if (gidx < TG_BODY || (gidx >= TG_L5PE && gidx < TG_L5H)) {  // xyz-embedding part of layer 0 / layer 5
-            const bool l5 = gidx >= TG_L5PE;
-            const int g = l5 ? gidx - TG_L5PE : gidx;
-            const int col = t_xyz_col(4 * g + j, h);
-            const int o = 32 * slot + jl;
-            if (col >= 0) v = l5 ? params[off.w[5] + (int64_t)o * (T_W + T_XYZ) + col] : params[off.w[0] + (int64_t)o * T_XYZ + col];
-        } else if (gidx < TG_VIEWS) {  // 256 -> 256 layers
-            int layer, G;
-            bool l5h = false;
-            if (gidx < TG_L5PE) { layer = 1 + (gidx - TG_BODY) / 32; G = (gidx - TG_BODY) % 32; }
-            else if (gidx < TG_L67F) { layer = 5; G = gidx - TG_L5H; l5h = true; }
-            else { layer = 6 + (gidx - TG_L67F) / 32; G = (gidx - TG_L67F) % 32; }  // 6, 7, 8 (= feature_linear)
+        if (kind == 0) {
+            const bool in_range = gidx == TG_BV ? slot < 4 : true;  // the views layer has 4 output tiles
+            if (j == 0 && h == 0 && in_range) v = params[boff + o];
+        } else if (kind == 1) {
+            const int col = t_xyz_col(4 * G + j, h);
+            if (col >= 0) v = layer == 5 ? params[off.w[5] + (int64_t)o * (T_W + T_XYZ) + col]
+                                         : params[off.w[0] + (int64_t)o * T_XYZ + col];
+        } else if (kind == 2) {
             const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
-            const int o = 32 * slot + jl;
             if (layer == 8) v = params[off.feat_w + (int64_t)o * T_W + in];
-            else if (l5h) v = params[off.w[5] + (int64_t)o * (T_W + T_XYZ) + T_XYZ + in];
+            else if (layer == 5) v = params[off.w[5] + (int64_t)o * (T_W + T_XYZ) + T_XYZ + in];
             else v = params[off.w[layer] + (int64_t)o * T_W + in];
-        } else if (gidx < TG_VDIR) {  // views layer, feature part: slot = (k-group parity)*4 + tile
-            const int G = 2 * (gidx - TG_VIEWS) + (slot >> 2), tile = slot & 3;
-            const int in = 32 * (G >> 2) + 8 * (G & 3) + 4 * h + j;
-            const int o = 32 * tile + jl;
-            v = params[off.views_w + (int64_t)o * (T_W + T_DIR) + in];
-        } else {  // views layer, direction-embedding part
-            const int g = 2 * (gidx - TG_VDIR) + (slot >> 2), tile = slot & 3;
+        } else if (kind == 3) {  // slot = (k-group parity)*4 + tile
+            const int Gk = 2 * G + (slot >> 2), tile = slot & 3;
+            const int in = 32 * (Gk >> 2) + 8 * (Gk & 3) + 4 * h + j;
+            v = params[off.views_w + (int64_t)(32 * tile + jl) * (T_W + T_DIR) + in];
+        } else {
+            const int g = 2 * G + (slot >> 2), tile = slot & 3;
             const int col = t_dir_col(4 * g + j, h);
-            const int o = 32 * tile + jl;
-            if (col >= 0) v = params[off.views_w + (int64_t)o * (T_W + T_DIR) + T_W + col];
+            if (col >= 0) v = params[off.views_w + (int64_t)(32 * tile + jl) * (T_W + T_DIR) + T_W + col];
         }
         out[i] = v;
     }
@@ -130,9 +149,7 @@ __device__ __forceinline__ void t_xyz_feats(const float (&p)[3], int h, float (&
 
 __device__ __forceinline__ void t_pe_gemm(f32x16 (&acc)[R2L_NT], const float (&f)[T_PE_STEPS], WStream& ws) {
 #pragma unroll
-    for (int g = 0; g < T_PE_GROUPS; ++g) {
-        mfma_group(acc, ws, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
-    }
+    for (int g = 0; g < T_PE_GROUPS; ++g) mfma_group(acc, ws, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
 }
 
 __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherArgs a) {
@@ -159,30 +176,27 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
     const float* P = a.params;
 
     f32x16 x[R2L_NT], t[R2L_NT];
-    // layer 0
+    const float one_h0 = h ? 0.f : 1.f;  // B operand of the bias k-steps
+    // layer 0 (x holds PRE-activations from here on: every consumer applies the ReLU to its B operands on the fly)
     {
         float f[T_PE_STEPS];
         t_xyz_feats(p, h, f);
-        add_bias<false>(x, P + off.b[0], h);
+        mfma_bias_group<true>(x, ws, one_h0);
         t_pe_gemm(x, f, ws);
-        relu_inplace(x);
     }
-    // (L1,L2) (L3,L4) (L5,L6) (L7,feature): t = relu(W_odd x [+ W5pe pe]); x = act(W_even t)
+    // (L1,L2) (L3,L4) (L5,L6) (L7,feature): t = W_odd relu(x) [+ W5pe pe] + b ; x = W_even relu(t) + b
     float alpha = 0.f;
+    NoHook nh;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        // bias offsets of layers 2k+1 / 2k+2 without indexing the offset table dynamically (it would go to scratch)
-        const int64_t b_odd = k == 0 ? off.b[1] : k == 1 ? off.b[3] : k == 2 ? off.b[5] : off.b[7];
-        const int64_t b_even = k == 0 ? off.b[2] : k == 1 ? off.b[4] : k == 2 ? off.b[6] : off.feat_b;
-        add_bias<false>(t, P + b_odd, h);
+        mfma_bias_group<true>(t, ws, one_h0);
         if (k == 2) {
             float f[T_PE_STEPS];
             t_xyz_feats(p, h, f);
             t_pe_gemm(t, f, ws);
         }
-        gemm256(t, x, ws);
-        relu_inplace(t);
-        if (k == 3) {  // alpha_linear on the output of layer 7
+        gemm256x<true>(t, x, ws, nh);
+        if (k == 3) {  // alpha_linear on relu(layer 7)
             float acc = 0.f;
 #pragma unroll
             for (int T = 0; T < R2L_NT; ++T)
@@ -190,25 +204,26 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(P + off.alpha_w + 32 * T + 8 * q + 4 * h);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(wv[j], t[T][4 * q + j], acc);
+                    for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(wv[j], fmaxf(t[T][4 * q + j], 0.f), acc);
                 }
             acc += __shfl_xor(acc, 32);
             alpha = acc + P[off.alpha_b];
         }
-        add_bias<false>(x, P + b_even, h);
-        gemm256(x, t, ws);
-        if (k != 3) relu_inplace(x);
+        mfma_bias_group<true>(x, ws, one_h0);
+        gemm256x<true>(x, t, ws, nh);  // k == 3: x = feature_linear(relu(layer 7)), consumed WITHOUT a ReLU below
     }
-    // views layer: v[128] = relu(Wv [feature, dir-embedding] + bv)   (4 output tiles)
+    // views layer: v[128] = Wv [feature, dir-embedding] + bv   (4 output tiles; ReLU applied by the rgb head)
     f32x16 v[4];
+    {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(P + off.views_b + 32 * T + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[T][4 * q + j] = b[j];
+        for (int t4 = 0; t4 < R2L_NT; ++t4) {
+            if (t4 < 4) v[t4] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t4][0], one_h0, zero, 0, 0, 0);
+            ws.w[t4] = ws.p[t4 * 64];
         }
+        ws.p += R2L_NT * 64;
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int G2 = 0; G2 < 16; ++G2) {
         const int Ga = 2 * G2, Gb = 2 * G2 + 1;
