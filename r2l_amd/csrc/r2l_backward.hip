@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
     const bool valid = ray < a.N;
     const int64_t rc = valid ? ray : a.N - 1;
 
-    WStream ws;
+    WRing2 ws;  // 64 groups per block: ring slots are static (r2l_common.h)
     ws.init(a.wstream, lane);
     const int64_t Np = R2L_PAD_ROWS(a.N);  // rows per stash / gradient slot
 

@@ -45,36 +45,68 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int r2l_feat(int T, int c, int h) { return 32 * T + 8 * (c >> 2) + 4 * h + (c & 3); }
 
 // ---------------------------------------------------------------------------------------------
-// Weight stream reader.  A wave walks the packed stream one group (8 tiles x float4 per lane) at a time with ONE
-// register buffer: a group is consumed tile-major (4 MFMAs on tile t's accumulator, then tile t+1, ...) and tile t's
-// registers are reloaded with the NEXT group's tile t right after its 4 MFMAs have issued.  Every load is therefore
-// issued exactly 28 MFMAs (1792 cycles) before its first use, for every tile.
+// Weight stream reader.  A wave walks the packed stream one group (8 tiles x float4 per lane) at a time through a ring
+// of D register buffers: a group is consumed tile-major (4 MFMAs on tile t's accumulator, then tile t+1, ...) and the
+// registers of tile t are reloaded with tile t of the group D positions ahead right after its 4 MFMAs have issued.
+// Every load is therefore issued 32*D - 4 MFMAs before its first use (D=1: 1792 cycles, D=2: 3840 cycles).  D = 2 is
+// used by the student chains: vmcnt retires in order, so the (slow, HBM-latency) stash stores / mask loads that ride
+// along in training would otherwise stall the weight loads queued behind them.  The ring slot of every group is a
+// compile-time constant (SLOT), which is why loops over groups are arranged to have even trip lengths.
 // ---------------------------------------------------------------------------------------------
-struct WStream {
-    const f32x4* p;  // lane-adjusted pointer to the next group to LOAD
-    f32x4 w[R2L_NT];
-    __device__ __forceinline__ void init(const float* stream, int lane) {
-        p = reinterpret_cast<const f32x4*>(stream) + lane;
-#pragma unroll
-        for (int t = 0; t < R2L_NT; ++t) w[t] = p[t * 64];
-        p += R2L_NT * 64;
+// The stream pointer is kept as a wave-uniform base (SGPR pair) + a constant per-lane byte offset (one VGPR), so the
+// loads select the `global_load_dwordx4 v, v_off, s[base]` form: no 64-bit VALU address arithmetic, half the address
+// VGPR traffic per VMEM issue.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct WPtr {
+    __amdgpu_buffer_rsrc_t rsrc;  // buffer descriptor of the whole stream (4 SGPRs, wave-uniform by construction)
+    unsigned voff;                // lane * 16
+    unsigned soff;                // wave-uniform byte position of the next group to LOAD
+    __device__ __forceinline__ f32x4 operator[](int i) const {  // i = t * 64: tile t of the next group
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)i * 16u, soff, 0);
+        return __builtin_bit_cast(f32x4, v);
+    }
+    __device__ __forceinline__ WPtr& operator+=(int n) {  // advance by n float4 slots (n = 512: one group)
+        soff += (unsigned)n * 16u;
+        return *this;
     }
 };
 
-// acc[256x32] += W_group . b  for the four k-pairs of the current group (b0..b3 = B-operand registers), and start
-// streaming the next group in.  Schedule pinned: [4 MFMA, 1 VMEM read] x 8 (hipcc otherwise sinks the prefetch
-// loads next to their use and the wave eats the L2 latency with nothing else resident on the SIMD to hide it).
-// EXTRA_RD / EXTRA_WR: VMEM reads / writes a hook issued just before (mask prefetch, stash store) go FIRST: vmcnt
-// retires in order, so they must be older than the group's weight loads to get a whole group to complete.
-template <int EXTRA_RD = 0, int EXTRA_WR = 0>
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WStream& ws, float b0, float b1, float b2, float b3) {
+template <int D>
+struct WRingT {
+    WPtr p;  // the next group to LOAD
+    f32x4 w[D][R2L_NT];
+    __device__ __forceinline__ void init(const float* stream, int lane) {
+        // 0x00020000: raw buffer, 32-bit offsets (cdna_hip_programming.md T8); num_records = 4 GiB - 1 (no clamping)
+        p.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, 0xffffffff, 0x00020000);
+        p.voff = (unsigned)lane * 16u;
+        p.soff = 0u;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int t = 0; t < R2L_NT; ++t) w[d][t] = p[t * 64];
+            p += R2L_NT * 64;
+        }
+    }
+};
+typedef WRingT<1> WStream;
+typedef WRingT<2> WRing2;
+
+// acc[256x32] += W_group . b  for the four k-pairs of the group in ring slot SLOT (b0..b3 = B-operand registers), and
+// start streaming the group D positions ahead into the same registers.  Schedule pinned: [4 MFMA, 1 VMEM read
+// (, VPT VALU)] x 8 — hipcc otherwise sinks the prefetch loads next to their use and the wave eats the L2 latency with
+// nothing else resident on the SIMD to hide it.  EXTRA_RD / EXTRA_WR: VMEM reads / writes a hook issued just before
+// (mask prefetch, stash store) go FIRST.  VPT: non-MFMA VALU instructions to slot in after each tile (used by the
+// head to hide the next coordinate's sin/cos evaluation under the MFMAs).
+template <int SLOT = 0, int EXTRA_RD = 0, int EXTRA_WR = 0, int VPT = 0, int D>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws, float b0, float b1, float b2, float b3) {
+    static_assert(SLOT >= 0 && SLOT < D, "ring slot");
 #pragma unroll
     for (int t = 0; t < R2L_NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][0], b0, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][1], b1, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][2], b2, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][3], b3, acc[t], 0, 0, 0);
-        ws.w[t] = ws.p[t * 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][0], b0, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][1], b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][2], b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][3], b3, acc[t], 0, 0, 0);
+        ws.w[SLOT][t] = ws.p[t * 64];
     }
     ws.p += R2L_NT * 64;
     if (EXTRA_WR > 0) __builtin_amdgcn_sched_group_barrier(0x040, EXTRA_WR, 0);
@@ -83,19 +115,21 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WStream& ws, f
     for (int i = 0; i < R2L_NT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+        if (VPT > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPT, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // Same for a layer with 4 output tiles: one stream load-group carries two k-groups (slots 0-3: k-group A, 4-7: B).
-__device__ __forceinline__ void mfma_group4x2(f32x16 (&acc)[4], WStream& ws, const float (&ba)[4], const float (&bb)[4]) {
+template <int SLOT = 0, int D>
+__device__ __forceinline__ void mfma_group4x2(f32x16 (&acc)[4], WRingT<D>& ws, const float (&ba)[4], const float (&bb)[4]) {
 #pragma unroll
     for (int s8 = 0; s8 < R2L_NT; ++s8) {
         const int tt = s8 & 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[s8][j], s8 < 4 ? ba[j] : bb[j], acc[tt], 0, 0, 0);
-        ws.w[s8] = ws.p[s8 * 64];
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][s8][j], s8 < 4 ? ba[j] : bb[j], acc[tt], 0, 0, 0);
+        ws.w[SLOT][s8] = ws.p[s8 * 64];
     }
     ws.p += R2L_NT * 64;
 #pragma unroll
@@ -136,13 +170,13 @@ struct StoreHookT {
 typedef StoreHookT<false> StoreHook;
 
 // Consume one bias group of the forward stream: acc (+)= bias x [1,0]^T  — 8 MFMAs, one per tile.
-template <bool ZERO_INIT>
-__device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WStream& ws, float one_h0) {
+template <bool ZERO_INIT, int SLOT = 0, int D>
+__device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws, float one_h0) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < R2L_NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[t][0], one_h0, ZERO_INIT ? zero : acc[t], 0, 0, 0);
-        ws.w[t] = ws.p[t * 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][0], one_h0, ZERO_INIT ? zero : acc[t], 0, 0, 0);
+        ws.w[SLOT][t] = ws.p[t * 64];
     }
     ws.p += R2L_NT * 64;
 #pragma unroll
@@ -155,26 +189,34 @@ __device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WStream& 
 
 // acc += W[256x256] . act(in)   (one full layer, 32 groups, 1024 MFMAs).  RELU_IN applies the ReLU lazily to the four
 // B-operand registers of each group (VALU work hidden in the MFMA shadow) instead of a 384-instruction burst between
-// the GEMMs; `in` itself keeps the pre-activation values.
-template <bool RELU_IN, class Hook>
-__device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws, Hook& hook) {
+// the GEMMs; `in` itself keeps the pre-activation values.  BASE: ring slot of the first group.
+template <bool RELU_IN, int BASE = 0, class Hook, int D>
+__device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook) {
+    static_assert(R2L_LAYER_GROUPS % D == 0, "layer groups must be a multiple of the ring depth");
 #pragma unroll
-    for (int G = 0; G < R2L_LAYER_GROUPS; ++G) {
-        hook.at(G);
-        const int T = G >> 2, q = (G & 3) * 4;
-        float b[4];
+    for (int G2 = 0; G2 < R2L_LAYER_GROUPS; G2 += D) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = RELU_IN ? fmaxf(in[T][q + j], 0.f) : in[T][q + j];
-        mfma_group<Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+        for (int dd = 0; dd < D; ++dd) {
+            const int G = G2 + dd;
+            hook.at(G);
+            const int T = G >> 2, q = (G & 3) * 4;
+            float b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = RELU_IN ? fmaxf(in[T][q + j], 0.f) : in[T][q + j];
+            if (D == 1) mfma_group<0, Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+            else if ((BASE + dd) % D == 0) mfma_group<0, Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+            else mfma_group<(D > 1 ? 1 : 0), Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+        }
     }
 }
-template <class Hook>
-__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws, Hook& hook) {
-    gemm256x<false>(acc, in, ws, hook);
+template <class Hook, int D>
+__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook) {
+    gemm256x<false, 0>(acc, in, ws, hook);
 }
-__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WStream& ws) {
+template <int D>
+__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws) {
     NoHook nh;
-    gemm256(acc, in, ws, nh);
+    gemm256x<false, 0>(acc, in, ws, nh);
 }
 
 // acc[T][c] (+)= bias[feat(T,c,h)] read from the natural [256] bias vector as float4s

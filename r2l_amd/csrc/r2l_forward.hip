@@ -52,31 +52,34 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
     const bool valid = ray < a.N;
     const int64_t rc = valid ? ray : a.N - 1;
 
-    WStream ws;
+    // ring slots (r2l_common.h): stream position 0 = head bias (slot 0), 1..120 trig groups, 121..126 identity groups,
+    // 127 + 66 b + i = group i of block b; all loops over groups have even trip lengths, so slots are static.
+    WRing2 ws;
     ws.init(a.wstream, lane);
 
     f32x16 x[R2L_NT], t[R2L_NT];
     const float one_h0 = h ? 0.f : 1.f;  // B operand of the bias k-step: k = 0 is carried by the lower half-wave
-    mfma_bias_group<true>(x, ws, one_h0);  // x = head bias
+    mfma_bias_group<true, 0>(x, ws, one_h0);  // x = head bias
 
     if constexpr (MODE == MODE_EMB) {
         // B operand straight from the embedded input: stream step s of half h reads emb[ray][s + 504 h]
         const float* e = a.emb + rc * R2L_IN + 504 * h;
         // same step order as the fused path: trig steps (sample it, axis, f) then identity steps
-        for (int it = 0; it < 8; ++it) {
+#pragma unroll 1
+        for (int it2 = 0; it2 < 4; ++it2) {
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const float* ec = e + (it * 3 + ax) * 21;
-#pragma unroll
-                for (int g = 0; g < 5; ++g) {
-                    mfma_group(x, ws, ec[4 * g + 0], ec[4 * g + 1], ec[4 * g + 2], ec[4 * g + 3]);
-                }
+            for (int li = 0; li < 30; ++li) {  // (sample 2*it2 + li/15, axis (li%15)/5, group li%5)
+                const float* ec = e + ((2 * it2 + li / 15) * 3 + (li % 15) / 5) * 21 + 4 * (li % 5);
+                if ((1 + li) % 2 == 0) mfma_group<0>(x, ws, ec[0], ec[1], ec[2], ec[3]);
+                else mfma_group<1>(x, ws, ec[0], ec[1], ec[2], ec[3]);
             }
         }
 #pragma unroll
         for (int g = 0; g < R2L_HEAD_ID_GROUPS; ++g) {
-            mfma_group(x, ws, e[(4 * g + 0) * 21 + 20], e[(4 * g + 1) * 21 + 20], e[(4 * g + 2) * 21 + 20],
-                       e[(4 * g + 3) * 21 + 20]);
+            const float i0 = e[(4 * g + 0) * 21 + 20], i1 = e[(4 * g + 1) * 21 + 20], i2 = e[(4 * g + 2) * 21 + 20],
+                        i3 = e[(4 * g + 3) * 21 + 20];
+            if ((1 + g) % 2 == 0) mfma_group<0>(x, ws, i0, i1, i2, i3);
+            else mfma_group<1>(x, ws, i0, i1, i2, i3);
         }
     } else {
         float o[3], d[3];
@@ -122,21 +125,39 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
             }
         }
         // trig features: per coordinate [sin(2^0 x) .. sin(2^9 x), cos(2^0 x) .. cos(2^9 x)]   (nerf_raybased.py:199-203)
-#pragma unroll 1
-        for (int it = 0; it < 8; ++it) {
+        // Software pipeline: while the 5 groups (160 MFMAs) of coordinate c run, the VALU evaluates the 10 sin/cos
+        // pairs of coordinate c+1 (two per group, slotted between the MFMAs by the schedule pin).
+        auto zsel = [&](int s) {  // z[s] for a runtime sample index (registers cannot be indexed dynamically)
             float zz = z[0];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) zz = (it == k) ? z[k] : zz;
+            for (int k = 1; k < 8; ++k) zz = (s == k) ? z[k] : zz;
+            return zz;
+        };
+        float fc[20], fn[20];
+        {
+            const float xc = o[0] + d[0] * z[0];  // pts = o + d*z, mul and add rounded separately (-ffp-contract=off)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const float xc = o[ax] + d[ax] * zz;  // pts = o + d*z, mul and add rounded separately (-ffp-contract=off)
-                float f[20];
+            for (int k = 0; k < R2L_L; ++k) r2l_sincos(xc * (float)(1 << k), fc[k], fc[R2L_L + k]);
+        }
+#pragma unroll 1
+        for (int it2 = 0; it2 < 4; ++it2) {
+            const float za = zsel(2 * it2), zb = zsel(2 * it2 + 1), zc = zsel(2 * it2 + 2 < 8 ? 2 * it2 + 2 : 7);
 #pragma unroll
-                for (int k = 0; k < R2L_L; ++k) r2l_sincos(xc * (float)(1 << k), f[k], f[R2L_L + k]);
+            for (int ci = 0; ci < 6; ++ci) {  // coordinates (sample 2*it2 + ci/3, axis ci%3)
+                // the NEXT coordinate (the one after the last is a harmless recomputation)
+                const int nax = (ci + 1) % 3;
+                const float nz = (ci + 1) / 3 == 0 ? za : ((ci + 1) / 3 == 1 ? zb : zc);
+                const float xn = o[nax] + d[nax] * nz;
 #pragma unroll
                 for (int g = 0; g < 5; ++g) {
-                    mfma_group(x, ws, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+                    r2l_sincos(xn * (float)(1 << (2 * g)), fn[2 * g], fn[R2L_L + 2 * g]);
+                    r2l_sincos(xn * (float)(1 << (2 * g + 1)), fn[2 * g + 1], fn[R2L_L + 2 * g + 1]);
+                    const int li = ci * 5 + g;
+                    if ((1 + li) % 2 == 0) mfma_group<0, 0, 0, 9>(x, ws, fc[4 * g + 0], fc[4 * g + 1], fc[4 * g + 2], fc[4 * g + 3]);
+                    else mfma_group<1, 0, 0, 9>(x, ws, fc[4 * g + 0], fc[4 * g + 1], fc[4 * g + 2], fc[4 * g + 3]);
                 }
+#pragma unroll
+                for (int k = 0; k < 20; ++k) fc[k] = fn[k];
             }
         }
         // identity features (the trailing x of each coordinate's 21)
@@ -146,7 +167,8 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
             for (int e = 0; e < 24; ++e) id[e] = o[e % 3] + d[e % 3] * z[e / 3];
 #pragma unroll
             for (int g = 0; g < R2L_HEAD_ID_GROUPS; ++g) {
-                mfma_group(x, ws, id[4 * g + 0], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
+                if ((1 + g) % 2 == 0) mfma_group<0>(x, ws, id[4 * g + 0], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
+                else mfma_group<1>(x, ws, id[4 * g + 0], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
             }
         }
     }
@@ -163,22 +185,22 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1 (pre-activation; its ReLU is applied on the fly when t feeds the second GEMM)
-        mfma_bias_group<true>(t, ws, one_h0);
+        mfma_bias_group<true, 1>(t, ws, one_h0);  // block-local group 0 -> ring slot 1
         if constexpr (SAVE) {  // X_b is this GEMM's B operand: its stash store rides along, one 16-byte piece per group
             StoreHook sx(a.save_x + (int64_t)b * Np * R2L_W, ray, h, x);
-            gemm256x<false>(t, x, ws, sx);
+            gemm256x<false, 0>(t, x, ws, sx);
         } else {
             NoHook nh;
-            gemm256x<false>(t, x, ws, nh);
+            gemm256x<false, 0>(t, x, ws, nh);
         }
         // x += W2 relu(t) + b2
-        mfma_bias_group<false>(x, ws, one_h0);
+        mfma_bias_group<false, 0>(x, ws, one_h0);  // block-local group 33 -> slot 0
         if constexpr (SAVE) {
             StoreHookT<true> st(a.save_t + (int64_t)b * Np * R2L_W, ray, h, t);
-            gemm256x<true>(x, t, ws, st);
+            gemm256x<true, 1>(x, t, ws, st);
         } else {
             NoHook nh;
-            gemm256x<true>(x, t, ws, nh);
+            gemm256x<true, 1>(x, t, ws, nh);
         }
     }
     if constexpr (SAVE) store_frag(a.save_x + (int64_t)a.n_block * Np * R2L_W, ray, h, x);
