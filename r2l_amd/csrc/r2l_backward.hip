@@ -263,12 +263,19 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
         // Software pipeline without predicates: operands of k-step s+2 are loaded (row index clamped into the
         // segment, so the loads are unconditional and hipcc can use counted vmcnt waits) while k-step s computes.
         const int64_t nfull = (r1 - r0) / 2;  // k-steps with both rays present
-        const float* gbase = gp + (r0 + hh) * R2L_W;
-        const float* abase = ap + (r0 + hh) * R2L_W;
+        // operands through buffer descriptors based at the segment start (SGPR base + 32-bit offsets: the 64-bit VGPR
+        // address form costs MFMA issue slots); per-lane part in voff, the k-step position in the scalar offset
+        const __amdgpu_buffer_rsrc_t grs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G + r0 * R2L_W), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ars =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + r0 * R2L_W), 0, 0xffffffff, 0x00020000);
+        const unsigned gvo = (unsigned)(hh * R2L_W + wo * 128 + 4 * jl) * 4u;
+        const unsigned avo = (unsigned)(hh * R2L_W + wi * 128 + 4 * jl) * 4u;
         auto ld = [&](int64_t s, f32x4& gv, f32x4& av) {
             const int64_t sc = s < nfull ? s : (nfull > 0 ? nfull - 1 : 0);
-            gv = *reinterpret_cast<const f32x4*>(gbase + sc * (2 * R2L_W));
-            av = *reinterpret_cast<const f32x4*>(abase + sc * (2 * R2L_W));
+            const unsigned so = (unsigned)sc * (2u * R2L_W * 4u);
+            gv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, gvo, so, 0));
+            av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avo, so, 0));
         };
         auto kstep = [&](const f32x4& gv, const f32x4& av) {
 #pragma unroll
