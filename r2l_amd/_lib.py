@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libr2l_hip.so")
+LIB_PATH = os.environ.get("R2L_LIB_PATH") or os.path.join(_HERE, "lib", "libr2l_hip.so")  # env override: A/B builds
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

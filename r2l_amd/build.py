@@ -17,7 +17,8 @@ LIB = os.path.join(LIBDIR, "libr2l_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the point/ray arithmetic must reproduce the reference's separately rounded mul/add
 # (SURVEY.md §7 "Bit-exact point arithmetic"); FMAs are requested explicitly where wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+EXTRA = os.environ.get("R2L_EXTRA_FLAGS", "").split()
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def _sources():

@@ -43,12 +43,23 @@ struct R2LBwdArgs {
 struct BwdAHook {
     static constexpr int RD = 1, WR = 1;
     StoreHook st;
+#if R2L_HOOK_BUFFER
+    __amdgpu_buffer_rsrc_t trs;  // descriptor of this block's save_t slot
+    unsigned tvo;                // ray*1024 + 16*h
+#else
     const float* trow;  // save_t row of this lane (+4h)
+#endif
     unsigned (&mb)[4];
     f32x4 pend[2];  // mask pieces in flight: consumed two groups after their load was issued
     __device__ __forceinline__ BwdAHook(float* gbase, const float* tbase, int64_t ray, int h,
                                         const f32x16 (&g)[R2L_NT], unsigned (&m)[4])
+#if R2L_HOOK_BUFFER
+        : st(gbase, ray, h, g),
+          trs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, 0xffffffff, 0x00020000)),
+          tvo((unsigned)(ray * (R2L_W * 4) + 16 * h)), mb(m) {}
+#else
         : st(gbase, ray, h, g), trow(tbase + ray * R2L_W + 4 * h), mb(m) {}
+#endif
     __device__ __forceinline__ void fold(int G) {
         const f32x4 p = pend[G & 1];
         const int sh = ((G >> 2) & 1) * 16 + (G & 3) * 4;
@@ -59,7 +70,13 @@ struct BwdAHook {
     __device__ __forceinline__ void at(int G) {
         st.at(G);
         if (G > 1) fold(G - 2);
+#if R2L_HOOK_BUFFER
+        asm volatile("" : "+v"(tvo));
+        pend[G & 1] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo + (unsigned)(32 * (G >> 2) + 8 * (G & 3)) * 4u, 0, 0));
+#else
         pend[G & 1] = *reinterpret_cast<const f32x4*>(trow + 32 * (G >> 2) + 8 * (G & 3));
+#endif
     }
     __device__ __forceinline__ void finish() {
         fold(R2L_LAYER_GROUPS - 2);

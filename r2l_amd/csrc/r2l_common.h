@@ -61,10 +61,15 @@ struct WPtr {
     __amdgpu_buffer_rsrc_t rsrc;  // buffer descriptor of the whole stream (4 SGPRs, wave-uniform by construction)
     unsigned voff;                // lane * 16
     unsigned soff;                // wave-uniform byte position of the next group to LOAD
-    __device__ __forceinline__ f32x4 operator[](int i) const {  // i = t * 64: tile t of the next group
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)i * 16u, soff, 0);
+    // tile t of the next group (i = t * 64).  The constant part must land in the instruction's 12-bit offset field
+    // (tiles 4..7 go through soffset + 4096); `opaque()` keeps hipcc from hoisting voff + const into 8 loop-invariant
+    // VGPRs instead.
+    __device__ __forceinline__ f32x4 operator[](int i) const {
+        const unsigned byte = (unsigned)i * 16u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (byte & 4095u), soff + (byte & ~4095u), 0);
         return __builtin_bit_cast(f32x4, v);
     }
+    __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(voff)); }
     __device__ __forceinline__ WPtr& operator+=(int n) {  // advance by n float4 slots (n = 512: one group)
         soff += (unsigned)n * 16u;
         return *this;
@@ -100,6 +105,7 @@ typedef WRingT<2> WRing2;
 template <int SLOT = 0, int EXTRA_RD = 0, int EXTRA_WR = 0, int VPT = 0, int D>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws, float b0, float b1, float b2, float b3) {
     static_assert(SLOT >= 0 && SLOT < D, "ring slot");
+    ws.p.opaque();
 #pragma unroll
     for (int t = 0; t < R2L_NT; ++t) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][0], b0, acc[t], 0, 0, 0);
@@ -123,6 +129,7 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws,
 // Same for a layer with 4 output tiles: one stream load-group carries two k-groups (slots 0-3: k-group A, 4-7: B).
 template <int SLOT = 0, int D>
 __device__ __forceinline__ void mfma_group4x2(f32x16 (&acc)[4], WRingT<D>& ws, const float (&ba)[4], const float (&bb)[4]) {
+    ws.p.opaque();
 #pragma unroll
     for (int s8 = 0; s8 < R2L_NT; ++s8) {
         const int tt = s8 & 3;
@@ -150,13 +157,26 @@ struct NoHook {
 // row-major [N][256] tensor, one 16-byte piece per group: lane (ray j, half h) writes row*1 KiB + (32T + 8q + 4h)*4.
 // Stash tensors have r2l_padded_rows(N) = ceil(N/32)*32 rows per slot, so the lanes of a ragged last tile store to
 // their own padding rows: no predicate, no branch inside the GEMM.
+#ifndef R2L_HOOK_BUFFER
+#define R2L_HOOK_BUFFER 0  // ride-along stores / mask loads: 64-bit pointers (0) or buffer descriptors (1); same-box A/B: 0 is 0.3 % faster
+#endif
 template <bool RELU = false>
 struct StoreHookT {
     static constexpr int RD = 0, WR = 1;
+#if R2L_HOOK_BUFFER
+    __amdgpu_buffer_rsrc_t rsrc;  // descriptor of the destination slot (wave-uniform base)
+    unsigned voff;                // ray*1024 + 16*h (per lane)
+#else
     float* row;  // base + ray*256 + 4*h (per lane)
+#endif
     const f32x16 (&src)[R2L_NT];
     __device__ __forceinline__ StoreHookT(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT])
+#if R2L_HOOK_BUFFER
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000)),
+          voff((unsigned)(ray * (R2L_W * 4) + 16 * h)), src(s) {}
+#else
         : row(base + ray * R2L_W + 4 * h), src(s) {}
+#endif
     __device__ __forceinline__ void at(int G) {
         const int T = G >> 2, q = (G & 3) * 4;
         f32x4 v = {src[T][q + 0], src[T][q + 1], src[T][q + 2], src[T][q + 3]};
@@ -164,7 +184,13 @@ struct StoreHookT {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
+#if R2L_HOOK_BUFFER
+        asm volatile("" : "+v"(voff));  // keep voff + const out of loop-invariant VGPRs: it folds into offset:imm
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
+                                               voff + (unsigned)(32 * T + 8 * (G & 3)) * 4u, 0, 0);
+#else
         *reinterpret_cast<f32x4*>(row + 32 * T + 8 * (G & 3)) = v;
+#endif
     }
 };
 typedef StoreHookT<false> StoreHook;
@@ -173,6 +199,7 @@ typedef StoreHookT<false> StoreHook;
 template <bool ZERO_INIT, int SLOT = 0, int D>
 __device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws, float one_h0) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ws.p.opaque();
 #pragma unroll
     for (int t = 0; t < R2L_NT; ++t) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][0], one_h0, ZERO_INIT ? zero : acc[t], 0, 0, 0);

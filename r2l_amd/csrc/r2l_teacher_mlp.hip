@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
     f32x16 v[4];
     {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ws.p.opaque();
 #pragma unroll
         for (int t4 = 0; t4 < R2L_NT; ++t4) {
             if (t4 < 4) v[t4] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[0][t4][0], one_h0, zero, 0, 0, 0);
