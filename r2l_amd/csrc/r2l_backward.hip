@@ -37,6 +37,14 @@ struct R2LBwdArgs {
     int64_t N;
 };
 
+// relu'(t) as 128 bits per lane: bit (T&1)*16 + c of word T>>1 belongs to fragment register (T, c)
+struct MaskAct {
+    unsigned mb[4];
+    __device__ __forceinline__ float operator()(float v, int T, int c) const {
+        return ((mb[T >> 1] >> ((T & 1) * 16 + c)) & 1u) ? v : 0.f;
+    }
+};
+
 // GEMM-A hook of the backward chain (u = W2^T g): (1) g = dL/dx_{b+1} is the B operand, its store to gx[b+1] rides
 // along; (2) the ReLU mask of the block's hidden activation is prefetched one 16-byte piece per group from the forward
 // stash and folded into 128 bits per lane, so no load latency is exposed between the two GEMMs.
@@ -152,26 +160,20 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
         for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = g[T][c];
 #pragma unroll 1
     for (int b = a.n_block - 1; b >= 0; --b) {
-        // u = W2^T g, masked by relu'(hidden) = (t_b > 0); g (= dL/dx_{b+1}) is stored to gx[b+1] along the way
-#pragma unroll
-        for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) u[T][c] = 0.f;
+        // u = W2^T g (accumulators initialised by the first group, C = 0); g (= dL/dx_{b+1}) is stored to gx[b+1] and
+        // the ReLU mask bits of the block's hidden activation are prefetched along the way
         unsigned mb[4] = {0u, 0u, 0u, 0u};
         {
             BwdAHook hk(a.gx + (int64_t)(b + 1) * Np * R2L_W, a.save_t + (int64_t)b * Np * R2L_W, ray, h, g, mb);
-            gemm256(u, g, ws, hk);
+            gemm256a<IdentityAct, 0, true>(u, g, ws, hk, IdentityAct());
             hk.finish();
         }
-#pragma unroll
-        for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-                u[T][c] = ((mb[T >> 1] >> ((T & 1) * 16 + c)) & 1u) ? u[T][c] : 0.f;
-        // g += W1^T u ; u (= dL/d hidden pre-activation) is stored to gt[b] along the way
+        // g += W1^T (u . mask): the mask relu'(hidden) = (t_b > 0) is applied lazily to the B operands of each group and
+        // to the pieces of u (= dL/d hidden pre-activation) stored to gt[b] along the way
         {
-            StoreHook su(a.gt + (int64_t)b * Np * R2L_W, ray, h, u);
-            gemm256(g, u, ws, su);
+            const MaskAct mask{{mb[0], mb[1], mb[2], mb[3]}};
+            StoreHookT<false, MaskAct> su(a.gt + (int64_t)b * Np * R2L_W, ray, h, u, mask);
+            gemm256a<MaskAct, 0>(g, u, ws, su, mask);
         }
     }
 
@@ -310,6 +312,14 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) ld(k, gb[k], ab[k]);
             int64_t s = 0;
+            for (; s + 64 <= nfull; s += 64) {  // two chunks per trip: one vmcnt(0) drain per 1024 MFMAs
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    kstep(gb[k & 3], ab[k & 3]);
+                    ld(s + k + 4, gb[k & 3], ab[k & 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             for (; s + 32 <= nfull; s += 32) {
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {

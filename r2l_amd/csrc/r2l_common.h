@@ -102,13 +102,15 @@ typedef WRingT<2> WRing2;
 // nothing else resident on the SIMD to hide it.  EXTRA_RD / EXTRA_WR: VMEM reads / writes a hook issued just before
 // (mask prefetch, stash store) go FIRST.  VPT: non-MFMA VALU instructions to slot in after each tile (used by the
 // head to hide the next coordinate's sin/cos evaluation under the MFMAs).
-template <int SLOT = 0, int EXTRA_RD = 0, int EXTRA_WR = 0, int VPT = 0, int D>
+template <int SLOT = 0, int EXTRA_RD = 0, int EXTRA_WR = 0, int VPT = 0, bool ZERO_C = false, int D>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws, float b0, float b1, float b2, float b3) {
     static_assert(SLOT >= 0 && SLOT < D, "ring slot");
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ws.p.opaque();
 #pragma unroll
     for (int t = 0; t < R2L_NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][0], b0, acc[t], 0, 0, 0);
+        // ZERO_C: first group of a GEMM without bias: the accumulator is initialised by C = 0 (inline constant)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][0], b0, ZERO_C ? zero : acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][1], b1, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][2], b2, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.w[SLOT][t][3], b3, acc[t], 0, 0, 0);
@@ -147,6 +149,12 @@ __device__ __forceinline__ void mfma_group4x2(f32x16 (&acc)[4], WRingT<D>& ws, c
     __builtin_amdgcn_sched_barrier(0);
 }
 
+struct IdentityAct {
+    __device__ __forceinline__ float operator()(float v, int, int) const { return v; }
+};
+struct ReluAct {
+    __device__ __forceinline__ float operator()(float v, int, int) const { return fmaxf(v, 0.f); }
+};
 // ---- per-group hooks: memory traffic that rides along a GEMM instead of bursting between GEMMs ---------------------
 struct NoHook {
     static constexpr int RD = 0, WR = 0;
@@ -160,7 +168,7 @@ struct NoHook {
 #ifndef R2L_HOOK_BUFFER
 #define R2L_HOOK_BUFFER 0  // ride-along stores / mask loads: 64-bit pointers (0) or buffer descriptors (1); same-box A/B: 0 is 0.3 % faster
 #endif
-template <bool RELU = false>
+template <bool RELU = false, class Act = IdentityAct>
 struct StoreHookT {
     static constexpr int RD = 0, WR = 1;
 #if R2L_HOOK_BUFFER
@@ -170,16 +178,18 @@ struct StoreHookT {
     float* row;  // base + ray*256 + 4*h (per lane)
 #endif
     const f32x16 (&src)[R2L_NT];
-    __device__ __forceinline__ StoreHookT(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT])
+    Act act;  // applied to the stored values (e.g. the backward's ReLU mask), like the consumer GEMM applies it
+    __device__ __forceinline__ StoreHookT(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT], Act a = Act())
 #if R2L_HOOK_BUFFER
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000)),
-          voff((unsigned)(ray * (R2L_W * 4) + 16 * h)), src(s) {}
+          voff((unsigned)(ray * (R2L_W * 4) + 16 * h)), src(s), act(a) {}
 #else
-        : row(base + ray * R2L_W + 4 * h), src(s) {}
+        : row(base + ray * R2L_W + 4 * h), src(s), act(a) {}
 #endif
     __device__ __forceinline__ void at(int G) {
         const int T = G >> 2, q = (G & 3) * 4;
-        f32x4 v = {src[T][q + 0], src[T][q + 1], src[T][q + 2], src[T][q + 3]};
+        f32x4 v = {act(src[T][q + 0], T, q + 0), act(src[T][q + 1], T, q + 1), act(src[T][q + 2], T, q + 2),
+                   act(src[T][q + 3], T, q + 3)};
         if (RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -214,11 +224,13 @@ __device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WRingT<D>
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc += W[256x256] . act(in)   (one full layer, 32 groups, 1024 MFMAs).  RELU_IN applies the ReLU lazily to the four
+// acc += W[256x256] . act(in)   (one full layer, 32 groups, 1024 MFMAs).  The activation is applied lazily to the four
 // B-operand registers of each group (VALU work hidden in the MFMA shadow) instead of a 384-instruction burst between
-// the GEMMs; `in` itself keeps the pre-activation values.  BASE: ring slot of the first group.
-template <bool RELU_IN, int BASE = 0, class Hook, int D>
-__device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook) {
+// the GEMMs; `in` itself keeps the raw values.  Act: IdentityAct, ReluAct (forward) or a bit-mask (backward).
+// BASE: ring slot of the first group.  ZERO_FIRST: acc is initialised by the first group's MFMAs (C = 0).
+template <class Act, int BASE = 0, bool ZERO_FIRST = false, class Hook, int D>
+__device__ __forceinline__ void gemm256a(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook,
+                                         const Act& act) {
     static_assert(R2L_LAYER_GROUPS % D == 0, "layer groups must be a multiple of the ring depth");
 #pragma unroll
     for (int G2 = 0; G2 < R2L_LAYER_GROUPS; G2 += D) {
@@ -229,12 +241,22 @@ __device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&i
             const int T = G >> 2, q = (G & 3) * 4;
             float b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = RELU_IN ? fmaxf(in[T][q + j], 0.f) : in[T][q + j];
-            if (D == 1) mfma_group<0, Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
-            else if ((BASE + dd) % D == 0) mfma_group<0, Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
-            else mfma_group<(D > 1 ? 1 : 0), Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+            for (int j = 0; j < 4; ++j) b[j] = act(in[T][q + j], T, q + j);
+            constexpr int S1 = D > 1 ? 1 : 0;
+            if (G == 0 && ZERO_FIRST) {
+                if ((BASE + dd) % D == 0) mfma_group<0, Hook::RD, Hook::WR, 0, true>(acc, ws, b[0], b[1], b[2], b[3]);
+                else mfma_group<S1, Hook::RD, Hook::WR, 0, true>(acc, ws, b[0], b[1], b[2], b[3]);
+            } else {
+                if ((BASE + dd) % D == 0) mfma_group<0, Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+                else mfma_group<S1, Hook::RD, Hook::WR>(acc, ws, b[0], b[1], b[2], b[3]);
+            }
         }
     }
+}
+template <bool RELU_IN, int BASE = 0, class Hook, int D>
+__device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook) {
+    if (RELU_IN) gemm256a<ReluAct, BASE>(acc, in, ws, hook, ReluAct());
+    else gemm256a<IdentityAct, BASE>(acc, in, ws, hook, IdentityAct());
 }
 template <class Hook, int D>
 __device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook) {
