@@ -47,6 +47,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64 (same soname as /opt/rocm's).  It must be the one the process loads FIRST:
+    # if libr2l_hip.so pulled in the system runtime before torch was imported, torch would bind to that copy and fail
+    # with "no ROCm-capable device is detected".  One HIP runtime per process: torch's.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libr2l_hip.so not found at %s — build it with `python -m r2l_amd.build` "
