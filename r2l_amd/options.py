@@ -82,7 +82,7 @@ def read_config_file(path):
     with open(path) as f:
         for line in f:
             line = line.split("#", 1)[0].strip()
-            if not line:
+            if not line or (line.startswith("[") and line.endswith("]")):  # blank / [section] headers are cosmetic
                 continue
             if "=" in line:
                 key, val = [s.strip() for s in line.split("=", 1)]
