@@ -206,3 +206,48 @@ def write_ray_shards(rows, outdir, start_index, rays_per_file=4096, prefix="data
         np.save(os.path.join(outdir, "%s%d.npy" % (prefix, start_index + k)),
                 rows[k * rays_per_file:(k + 1) * rays_per_file])
     return start_index + n_files
+
+
+def convert_images_to_ray_shards(datadir, splits=("train",), suffix="", ignore=(), full_res=False, white_bkgd=True,
+                                 rays_per_file=4096, rng=np.random):
+    """Real images -> shuffled [4096,9] ray shards `<splits>_<k>.npy` in `<datadir>_real_<splits><suffix>/` for the
+    fine-tuning stage (README step 4; reference utils/convert_original_data_to_rays_blender.py:116-235, Blender
+    branch; the DONERF ray convention is out of scope).  Returns (savedir, n_files)."""
+    from .render import get_rays
+    prefix = "".join(splits)
+    savedir = "%s_real_%s%s" % (os.path.normpath(datadir), prefix, suffix)
+    os.makedirs(savedir, exist_ok=True)
+    ignore = set(str(i) for i in ignore)
+    imgs, poses, meta = [], [], None
+    for s in splits:
+        with open(os.path.join(datadir, "transforms_%s.json" % s)) as fp:
+            meta = json.load(fp)
+        for frame in meta["frames"]:
+            if frame["file_path"].split("_")[-1] in ignore:  # e.g. "./train/r_3" -> "3"
+                continue
+            imgs.append(_read_png(os.path.join(datadir, frame["file_path"] + ".png")))
+            poses.append(np.array(frame["transform_matrix"], dtype=np.float32))
+    imgs = (np.stack(imgs) / 255.).astype(np.float32)
+    H, W = imgs.shape[1:3]
+    if "camera_angle_x" in meta:
+        camera_angle_x = float(meta["camera_angle_x"])
+    else:
+        with open(os.path.join(datadir, "dataset_info.json")) as fp:
+            camera_angle_x = float(json.load(fp)["camera_angle_x"])
+    focal = .5 * W / np.tan(.5 * camera_angle_x)
+    if not full_res:
+        H, W, focal = H // 2, W // 2, focal / 2.
+        imgs = imgs[:, :2 * H, :2 * W].reshape(imgs.shape[0], H, 2, W, 2, imgs.shape[-1]).mean(axis=(2, 4))
+    if imgs.shape[-1] == 4 and white_bkgd:
+        imgs = imgs[..., :3] * imgs[..., -1:] + (1. - imgs[..., -1:])
+    imgs = imgs[..., :3]
+    rows = []
+    for im, po in zip(imgs, poses):
+        ro, rd = get_rays(H, W, focal, torch.from_numpy(po[:3, :4]))
+        rows.append(np.concatenate([ro.reshape(-1, 3).numpy(), rd.reshape(-1, 3).numpy(), im.reshape(-1, 3)], -1))
+    rows = np.concatenate(rows, 0).astype(np.float32)
+    rows = rows[rng.permutation(rows.shape[0])][rng.permutation(rows.shape[0])]  # shuffled twice, as the reference
+    n_files = rows.shape[0] // rays_per_file
+    for k in range(n_files):
+        np.save(os.path.join(savedir, "%s_%d.npy" % (prefix, k + 1)), rows[k * rays_per_file:(k + 1) * rays_per_file])
+    return savedir, n_files

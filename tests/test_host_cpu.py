@@ -120,3 +120,25 @@ def test_load_blender_synthetic(tmp_path):
     assert [len(s) for s in i_split] == [3, 1, 2]
     full, *_ = data.load_blender_data(str(tmp_path), half_res=False, testskip=1)
     np.testing.assert_allclose(imgs.numpy(), full.numpy().reshape(6, 4, 2, 4, 2, 4).mean(axis=(2, 4)), atol=1e-7)
+
+
+def test_convert_images_to_ray_shards(tmp_path):
+    """README step 4 data: every pixel of the train views becomes one [o,d,rgb] row; shards feed BlenderDataset_v2."""
+    from tests.test_driver_cpu import make_scene
+    from r2l_amd import data
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=128)  # 2 train views, half_res 64x64 -> 8192 rays -> 2 shards
+    savedir, n = data.convert_images_to_ray_shards(scene, ("train",), rng=np.random.RandomState(0))
+    assert n == 2 and sorted(os.listdir(savedir)) == ["train_1.npy", "train_2.npy"]
+    rows = np.concatenate([np.load(os.path.join(savedir, f)) for f in sorted(os.listdir(savedir))])
+    assert rows.shape == (8192, 9) and rows.dtype == np.float32
+    imgs, poses, _, hwf, i_split = data.load_blender_data(scene, half_res=True, testskip=1)
+    imgs = imgs[..., :3] * imgs[..., -1:] + (1. - imgs[..., -1:])
+    # the multiset of rgb values is exactly the composited train images; origins are the two camera centres
+    ref = imgs[i_split[0]].reshape(-1, 3).numpy()
+    assert np.allclose(np.sort(rows[:, 6:].sum(1)), np.sort(ref.sum(1)), atol=1e-6)
+    centres = {tuple(np.round(p[:3, 3].numpy(), 4)) for p in poses[i_split[0]]}
+    assert {tuple(np.round(r, 4)) for r in rows[:, :3]} == centres
+    files = data.list_ray_shards(savedir, pseudo_ratio=-1)
+    assert len(files) == 2  # 'train_*' files count as original data in BlenderDataset_v2's selection rule
