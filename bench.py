@@ -208,6 +208,10 @@ def main():
     if train_mod is not None:
         out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
                                        PEAK_FP32_MFMA)
+        # BASELINE configs[2] read literally ("N_rand=4096" as 4096 rays per step): one 32-ray tile per wave fills only
+        # 128 of the 1024 wave slots, reported for completeness
+        out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                            PEAK_FP32_MFMA, n_rays=4096)
 
     if not a.no_teacher:
         out["teacher"] = teacher_leg(O, device, world, rank, distributed)

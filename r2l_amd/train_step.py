@@ -188,10 +188,10 @@ def smoke_check(net, ps, sd, O):
     assert lerr < 1e-6 and gerr < 5e-3, (lerr, gerr)
 
 
-def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak):
+def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak, n_rays=None):
     """Training leg of bench.py: K fused steps of `a.train_rays` rays per GPU (synthetic [o,d,rgb] rows as in the
     `.npy` shards, main.py:1305-1311), RCCL all-reduce when world > 1."""
-    n = a.train_rays
+    n = a.train_rays if n_rays is None else n_rays
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(device)
     d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(device)
