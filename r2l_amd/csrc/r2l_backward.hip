@@ -611,7 +611,11 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
             n_cu = prop.multiProcessorCount;
     }
     // 1. dX chain
-    {
+    if (r2l_use_coop(N)) {
+        const int rc = r2l_coop_backward(rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block, grad_scale, dpre,
+                                         gx, gt, sqerr_partial, N, stream);
+        if (rc) return rc;
+    } else {
         R2LBwdArgs a{};
         a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t; a.wstream = wstream_bwd;
         a.params = params; a.n_block = n_block; a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt;

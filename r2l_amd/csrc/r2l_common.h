@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,7 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define R2L_FWD_HEAD_GROUPS (1 + R2L_HEAD_GROUPS)
 #define R2L_FWD_LAYER_GROUPS (1 + R2L_LAYER_GROUPS)
 #define R2L_PAD_ROWS(n) ((((int64_t)(n)) + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS * R2L_TILE_RAYS)
-#define R2L_STREAM_PAD (2 * R2L_GROUP_FLOATS)        // the prefetcher runs up to two groups past the end
+#define R2L_STREAM_PAD (10 * R2L_GROUP_FLOATS)       // prefetchers run up to 9 groups past the end (r2l_coop.hip ring)
 
 // feature index held by fragment register (T, c) in lane-half h
 __device__ __forceinline__ int r2l_feat(int T, int c, int h) { return 32 * T + 8 * (c >> 2) + 4 * h + (c & 3); }
@@ -338,6 +339,25 @@ __device__ __forceinline__ void r2l_sincos(float x, float& s_out, float& c_out) 
     const float c1 = (q & 1) ? sr : cr;
     s_out = (q & 2) ? -s1 : s1;
     c_out = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// ---- small-batch cooperative variants (r2l_coop.hip) ---------------------------------------------------------------------
+int r2l_coop_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                     const float* c2w_host12, int H, int W, float focal, const float* wstream, const float* params,
+                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
+int r2l_coop_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                      const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream);
+// Which chain variant is faster for N rays: the main kernels need ceil(N/32768) rounds of one tile-time each (1024 wave
+// slots x 32 rays), the cooperative ones ceil(N/8192) rounds (256 workgroups x 32 rays) of ~0.28 tile-times each.
+// R2L_FORCE_VARIANT=main|coop in the environment overrides (tests, A/B).
+static inline bool r2l_use_coop(int64_t N) {
+    const char* e = getenv("R2L_FORCE_VARIANT");  // read per call (~100 ns) so tests can flip it
+    if (e && e[0] == 'm') return false;
+    if (e && e[0] == 'c') return true;
+    const double main_t = (double)((N + 32767) / 32768);
+    const double coop_t = (double)((N + 8191) / 8192) * 0.28;
+    return coop_t < main_t;
 }
 
 // error plumbing shared by the C-ABI translation units

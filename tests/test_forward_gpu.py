@@ -8,6 +8,13 @@ import torch
 from oracle import r2l_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["main", "coop"])
+def chain_variant(request, monkeypatch):
+    """Every test runs twice: one-wave-per-tile kernels and the cooperative small-batch kernels (r2l_coop.hip)."""
+    monkeypatch.setenv("R2L_FORCE_VARIANT", request.param)
+    return request.param
 T = torch.from_numpy
 TOL = 1e-4  # north_star: RGB within 1e-4 abs of the reference PyTorch path
 

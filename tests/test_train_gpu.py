@@ -10,6 +10,13 @@ from oracle import r2l_oracle as O
 from tests.test_forward_gpu import build_model
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["main", "coop"])
+def chain_variant(request, monkeypatch):
+    """Every test runs twice: one-wave-per-tile kernels and the cooperative small-batch kernels (r2l_coop.hip)."""
+    monkeypatch.setenv("R2L_FORCE_VARIANT", request.param)
+    return request.param
 T = torch.from_numpy
 
 
