@@ -42,9 +42,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define R2L_PAD_ROWS(n) ((((int64_t)(n)) + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS * R2L_TILE_RAYS)
 #define R2L_STREAM_PAD (10 * R2L_GROUP_FLOATS)       // prefetchers run up to 9 groups past the end (r2l_coop.hip ring)
 
-// feature index held by fragment register (T, c) in lane-half h
-__device__ __forceinline__ int r2l_feat(int T, int c, int h) { return 32 * T + 8 * (c >> 2) + 4 * h + (c & 3); }
-
 // ---------------------------------------------------------------------------------------------
 // Weight stream reader.  A wave walks the packed stream one group (8 tiles x float4 per lane) at a time through a ring
 // of D register buffers: a group is consumed tile-major (4 MFMAs on tile t's accumulator, then tile t+1, ...) and the
@@ -259,29 +256,6 @@ __device__ __forceinline__ void gemm256x(f32x16 (&acc)[R2L_NT], const f32x16 (&i
     if (RELU_IN) gemm256a<ReluAct, BASE>(acc, in, ws, hook, ReluAct());
     else gemm256a<IdentityAct, BASE>(acc, in, ws, hook, IdentityAct());
 }
-template <class Hook, int D>
-__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws, Hook& hook) {
-    gemm256x<false, 0>(acc, in, ws, hook);
-}
-template <int D>
-__device__ __forceinline__ void gemm256(f32x16 (&acc)[R2L_NT], const f32x16 (&in)[R2L_NT], WRingT<D>& ws) {
-    NoHook nh;
-    gemm256x<false, 0>(acc, in, ws, nh);
-}
-
-// acc[T][c] (+)= bias[feat(T,c,h)] read from the natural [256] bias vector as float4s
-template <bool ACCUM>
-__device__ __forceinline__ void add_bias(f32x16 (&acc)[R2L_NT], const float* __restrict__ bias, int h) {
-#pragma unroll
-    for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * T + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[T][4 * q + j] = ACCUM ? acc[T][4 * q + j] + b[j] : b[j];
-        }
-}
-
 __device__ __forceinline__ void relu_inplace(f32x16 (&a)[R2L_NT]) {
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)
@@ -300,18 +274,6 @@ __device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t row
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {a[T][4 * q + 0], a[T][4 * q + 1], a[T][4 * q + 2], a[T][4 * q + 3]};
             *reinterpret_cast<f32x4*>(r + 32 * T + 8 * q) = v;
-        }
-}
-
-__device__ __forceinline__ void load_frag(const float* __restrict__ base, int64_t row, int h, f32x16 (&a)[R2L_NT]) {
-    const float* r = base + row * R2L_W + 4 * h;
-#pragma unroll
-    for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(r + 32 * T + 8 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[T][4 * q + j] = v[j];
         }
 }
 
