@@ -50,3 +50,56 @@ def test_create_data_then_train(tmp_path, monkeypatch):
     # render_only with the trained checkpoint reports PSNR on the 2 test views
     res3 = driver.main(common + ["--pretrained_ckpt", os.path.join(wdir, "ckpt.tar"), "--render_only", "--render_test"])
     assert res3["rgbs"].shape == (2, 64, 64, 3) and np.isfinite(res3["misc"]["test_psnr"].item())
+
+
+def test_distillation_converges_on_teacher_data(tmp_path):
+    """Functional check of the whole loop at the README architecture (W256 D88): a student trained for 150 fused steps
+    on rays rendered by a (seeded) teacher reduces its loss by > 3x and its held-out PSNR rises."""
+    from model.nerf_raybased import NeRF, NeRF_v3_2, PointSampler
+    from r2l_amd.options import parse_args
+    from r2l_amd.render import get_rays, render
+    from r2l_amd.train_step import R2LTrainer, lr_schedule
+    from r2l_amd import data
+    nets = []
+    for sd in O.make_teacher_state_dicts(21, 2, alpha_bias=0.5):
+        m = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+        m.load_state_dict(sd)
+        nets.append(m.cuda())
+    H = W = 64
+    focal = 80.
+    kw = dict(network_fn=nets[0], network_query_fn=None, N_samples=64, N_importance=128, network_fine=nets[1],
+              white_bkgd=True, perturb=0., ndc=False, near=2., far=6., use_viewdirs=True)
+    rng = np.random.RandomState(0)
+    rows = []
+    with torch.no_grad():
+        for _ in range(5):
+            pose = data.get_rand_pose(rng).cuda()
+            ro, rd = get_rays(H, W, focal, pose[:3, :4])
+            rgb, *_ = render(H, W, focal, chunk=1 << 15, rays=torch.stack([ro, rd], 0), **kw)
+            rows.append(torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), rgb.reshape(-1, 3)], -1))
+    train, held = torch.cat(rows[:4], 0), rows[4]
+    args = parse_args(["--netdepth", "88", "--netwidth", "256", "--use_residual", "--trial.ON", "--trial.body_arch",
+                       "resmlp", "--n_sample_per_ray", "16"])
+    torch.manual_seed(0)
+    net = NeRF_v3_2(args, 1008, 3).cuda()
+    ps = PointSampler(H, W, focal, 16, 2., 6.)
+    tr = R2LTrainer(net, ps)
+
+    def held_psnr():
+        with torch.no_grad():
+            out = net.forward_rays(held[:, :3], held[:, 3:6], ps)
+        return -10 * np.log10(((out - held[:, 6:])**2).mean().item())
+
+    p0 = held_psnr()
+    losses = []
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for it in range(1, 151):
+        idx = torch.randint(0, train.shape[0], (8192,), device="cuda", generator=g)
+        b = train[idx]
+        _, lo = tr.step(b[:, :3], b[:, 3:6], b[:, 6:], lr_schedule(it, 5e-4, 500, "0.0001,200"), perturb=1.)
+        losses.append(lo[0].item())
+    p1 = held_psnr()
+    print("loss %.4f -> %.4f, held-out psnr %.2f -> %.2f dB" % (losses[0], np.mean(losses[-10:]), p0, p1))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < losses[0] / 3
+    assert p1 > p0 + 3
