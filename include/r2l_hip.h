@@ -108,6 +108,23 @@ int r2l_raw2outputs(const float* raw, const float* z, const float* rays_d, const
 int r2l_sample_pdf_sort(const float* z, const float* weights, const float* u, int64_t u_stride, float* z_samples,
                         float* z_all, float* z_std, int64_t R, int S, int NI, void* stream);
 
+/* ---- ray-shard reader (host threads; --data_mode rays) ------------------------------------------------------------
+ * Replaces BlenderDataset_v2.__getitem__ (dataset/load_blender.py:257-324: np.load of one [4096,9] f32 shard),
+ * InfiniteSamplerWrapper (main.py:759-776: random permutations of the file list, forever) and the DataLoader's
+ * batch_size=N_rand collate + pin_memory (main.py:794-806).  `slot_ptrs[depth]` are caller-owned (pinned) host buffers
+ * of files_per_batch * rows * cols * 4 bytes each; reader threads pread() shard payloads straight into them.  All
+ * shards must have the shape of paths[0].  Format: NumPy .npy v1/v2/v3, '<f4', C order, 2-D. */
+typedef struct r2l_reader r2l_reader;
+int r2l_npy_shape(const char* path, int64_t* rows, int64_t* cols);
+int r2l_reader_open(const char* const* paths, int64_t n_paths, int files_per_batch, int n_threads, uint64_t seed,
+                    void* const* slot_ptrs, int depth, r2l_reader** out);
+int r2l_reader_info(r2l_reader* r, int64_t* rows, int64_t* cols, int64_t* files_read);
+/* Blocks until the oldest scheduled batch is complete; *slot = index of the buffer holding it.  The buffer is not
+ * rewritten until r2l_reader_release(slot), which queues the next batch into it. */
+int r2l_reader_next(r2l_reader* r, int* slot);
+int r2l_reader_release(r2l_reader* r, int slot);
+int r2l_reader_close(r2l_reader* r);
+
 #ifdef __cplusplus
 }
 #endif

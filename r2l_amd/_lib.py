@@ -37,6 +37,12 @@ SIGNATURES = {
     "r2l_stratified_z": (_i, [_p, _p, _i, _p, _p, _p, _l, _i, _p]),
     "r2l_raw2outputs": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p]),
     "r2l_sample_pdf_sort": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
+    "r2l_npy_shape": (_i, [ctypes.c_char_p, _p, _p]),
+    "r2l_reader_open": (_i, [_p, _l, _i, _i, ctypes.c_uint64, _p, _i, _p]),
+    "r2l_reader_info": (_i, [_p, _p, _p, _p]),
+    "r2l_reader_next": (_i, [_p, _p]),
+    "r2l_reader_release": (_i, [_p, _i]),
+    "r2l_reader_close": (_i, [_p]),
 }
 
 _lib = None

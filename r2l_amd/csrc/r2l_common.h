@@ -325,6 +325,7 @@ static inline bool r2l_use_coop(int64_t N) {
 // error plumbing shared by the C-ABI translation units
 extern "C" const char* r2l_last_error(void);
 void r2l_set_error(const char* what, hipError_t e);
+void r2l_set_error_msg(const char* msg);
 #define R2L_CHECK(expr)                        \
     do {                                       \
         hipError_t _e = (expr);                \

@@ -8,4 +8,6 @@ void r2l_set_error(const char* what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s -> %s (%d)", what, hipGetErrorString(e), (int)e);
 }
 
+void r2l_set_error_msg(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
 extern "C" const char* r2l_last_error(void) { return g_err; }

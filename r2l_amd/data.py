@@ -2,13 +2,11 @@
 (mirror of /root/reference/dataset/load_blender.py:22-28, 31-120, 257-368; PIL replaces imageio/cv2).
 
 Ray shards: NumPy v1 `.npy`, float32 C-order [n_ray, 9] rows [o(3), d(3), rgb(3)], named data_<k>.npy (teacher
-pseudo data, utils/create_data.py:854-872) or train_<k>.npy (real images).  RayShardLoader streams them with a
-prefetch thread into pinned memory, rank-sharded (files[rank::world]) — the per-process replacement of the
-reference's DataLoader(BlenderDataset_v2, batch_size=N_rand, InfiniteSampler) (main.py:759-808)."""
+pseudo data, utils/create_data.py:854-872) or train_<k>.npy (real images).  RayShardLoader streams them through the
+native reader threads of libr2l_hip.so into pinned memory, rank-sharded (files[rank::world]) — the per-process
+replacement of the reference's DataLoader(BlenderDataset_v2, batch_size=N_rand, InfiniteSampler) (main.py:759-808)."""
 import json
 import os
-import queue
-import threading
 
 import numpy as np
 import torch
@@ -150,51 +148,116 @@ def shard_for_rank(files, rank, world):
 
 
 class RayShardLoader:
-    """Infinite stream of batches of `n_files` shards concatenated to [n_files*rays_per_file, 9] (pinned host memory
-    when a GPU is present), with random permutations over this rank's files (the InfiniteSampler of main.py:759-767)
-    and a background prefetch thread (np.load releases the GIL while reading)."""
+    """Infinite stream of batches of `n_files` shards as one [n_files*rays_per_file, 9] tensor, drawn by random
+    permutations over this rank's files (the InfiniteSampler of main.py:759-767).
 
-    def __init__(self, files, n_files, rank=0, world=1, seed=0, prefetch=3, pin=None):
+    The reading is done by the native reader of libr2l_hip.so (csrc/r2l_shard_reader.hip): `threads` host threads pread()
+    shard payloads straight into a ring of `prefetch` pinned buffers owned by this object.  With `device` set, next()
+    returns a DEVICE tensor: the host->device copy of batch i+1 runs on a side stream while step i computes (two
+    device buffers), so neither the file reads nor the 36 B/ray PCIe copy sit on the training stream.  Without a
+    device, next() returns the pinned host tensor; either way the tensor is valid until the second-next call."""
+
+    def __init__(self, files, n_files, rank=0, world=1, seed=0, prefetch=3, pin=None, device=None, threads=4):
+        import ctypes
+        from . import _lib
         self.files = shard_for_rank(list(files), rank, world)
         if not self.files:
             raise ValueError("rank %d got no ray shards (have %d files, world %d)" % (rank, len(files), world))
         self.n_files = n_files
-        self.rng = np.random.RandomState(seed + 9973 * rank)
-        self.pin = torch.cuda.is_available() if pin is None else pin
-        self.q = queue.Queue(maxsize=prefetch)
-        self._stop = False
-        self.thread = threading.Thread(target=self._work, daemon=True)
-        self.thread.start()
+        self._L = _lib.load()
+        rows, cols = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._L.r2l_npy_shape(self.files[0].encode(), ctypes.byref(rows), ctypes.byref(cols)),
+                   "r2l_npy_shape")
+        self.rows_per_file, self.cols = rows.value, cols.value
+        depth = max(3, int(prefetch))
+        self.host = torch.empty(depth, n_files * rows.value, cols.value, dtype=torch.float32)
+        if torch.cuda.is_available() if pin is None else pin:
+            self.host = self.host.pin_memory()
+        self._paths = (ctypes.c_char_p * len(self.files))(*[f.encode() for f in self.files])
+        slots = (ctypes.c_void_p * depth)(*[self.host[i].data_ptr() for i in range(depth)])
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.r2l_reader_open(ctypes.cast(self._paths, ctypes.c_void_p), len(self.files), n_files,
+                                           max(1, int(threads)), seed + 9973 * rank, ctypes.cast(slots, ctypes.c_void_p),
+                                           depth, ctypes.byref(self._h)), "r2l_reader_open")
+        self._held = []  # [(slot, copy-done event | None)] checked out of the ring, oldest first
+        self.device = torch.device(device) if device is not None else None
+        if self.device is not None and self.device.type != "cuda":
+            self.device = None
+        if self.device is not None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+            self._dev = [torch.empty(n_files * rows.value, cols.value, device=self.device) for _ in range(2)]
+            self._ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self._k = 0
+            self._issue_copy()
 
-    def _order(self):
-        while True:
-            for i in self.rng.permutation(len(self.files)):
-                yield self.files[i]
-
-    def _work(self):
-        it = self._order()
-        while not self._stop:
-            arrs = [np.load(next(it)) for _ in range(self.n_files)]
-            batch = torch.from_numpy(np.concatenate([a.reshape(-1, a.shape[-1]) for a in arrs], 0).astype(np.float32))
-            if self.pin:
-                batch = batch.pin_memory()
-            while not self._stop:
-                try:
-                    self.q.put(batch, timeout=0.5)
+    def _take_slot(self):
+        import ctypes
+        from . import _lib
+        # hand finished slots back to the reader: all but the newest on the host path, copies that completed on the
+        # device path (blocking on the oldest only if the ring would otherwise run dry)
+        while self._held:
+            slot, ev = self._held[0]
+            if ev is None:
+                if len(self._held) < 2:
                     break
-                except queue.Full:
-                    continue
+            elif not ev.query():
+                if len(self._held) < self.host.shape[0] - 1:
+                    break
+                ev.synchronize()
+            self._held.pop(0)
+            _lib.check(self._L.r2l_reader_release(self._h, slot), "r2l_reader_release")
+        slot = ctypes.c_int()
+        _lib.check(self._L.r2l_reader_next(self._h, ctypes.byref(slot)), "r2l_reader_next")
+        return slot.value
+
+    def _issue_copy(self):
+        k = self._k
+        slot = self._take_slot()
+        cur = torch.cuda.current_stream(self.device)
+        self._copy_stream.wait_stream(cur)  # the step that read _dev[k] (two calls ago) is enqueued before this point
+        with torch.cuda.stream(self._copy_stream):
+            self._dev[k].copy_(self.host[slot], non_blocking=True)
+            self._ready[k].record(self._copy_stream)
+        self._held.append((slot, self._ready[k]))
 
     def next(self):
-        return self.q.get()
+        if self._h is None:
+            raise RuntimeError("RayShardLoader is closed")
+        if self.device is None:
+            slot = self._take_slot()
+            self._held.append((slot, None))
+            return self.host[slot]
+        k = self._k
+        torch.cuda.current_stream(self.device).wait_event(self._ready[k])
+        out = self._dev[k]
+        self._k ^= 1
+        self._ready[self._k] = torch.cuda.Event()
+        self._issue_copy()
+        return out
 
     __next__ = next
 
     def __iter__(self):
         return self
 
+    def files_read(self):
+        import ctypes
+        n = ctypes.c_int64()
+        self._L.r2l_reader_info(self._h, None, None, ctypes.byref(n))
+        return n.value
+
     def close(self):
-        self._stop = True
+        if getattr(self, "_h", None) is not None:
+            if self.device is not None:
+                self._copy_stream.synchronize()
+            self._L.r2l_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_ray_shards(rows, outdir, start_index, rays_per_file=4096, prefix="data_"):

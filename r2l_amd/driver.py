@@ -44,14 +44,21 @@ def sync(device):
 
 class HardRayPool:
     """Hard-example pool of main.py:1164-1165, 1325-1347, 1410-1425: after each step the hard_ratio*B rays with the
-    largest per-ray MSE enter the pool (appended until it holds B*hard_mul rows, then replacing random rows), and
-    n_hard_out random pool rows are appended to every batch once the pool is full."""
+    largest per-ray MSE enter the pool (appended until it holds >= B*hard_mul rows, then replacing random rows), and
+    n_hard_out random pool rows are appended to every batch once the pool is full.
 
-    def __init__(self, hard_ratio, hard_mul, rng=None):
+    The pool ([rows, 9] = o,d,rgb; 59 MB at the README sizes) lives on the device of the rays it is fed, is allocated
+    once at its final size, and on a GPU the random row choice is a device randperm: the reference's host-side
+    np.random.permutation(1.6 M) per step costs as much as a whole MI355X training step."""
+
+    def __init__(self, hard_ratio, hard_mul, rng=None, seed=0):
         self.ratio, self.mul = hard_ratio, hard_mul
-        self.pool = None
+        self.pool = None      # rows filled so far (a view of _store once allocated)
+        self._store = None
         self.full = False
         self.rng = rng or np.random
+        self.seed = seed
+        self._gen = None
         self._ix_out = None
 
     def sizes(self, batch_size):
@@ -61,12 +68,20 @@ class HardRayPool:
             n_in = n_out = int(self.ratio * batch_size)
         return min(n_in, n_out), n_out
 
+    def _pick(self, n_rows, n_out, device):
+        if device.type == "cuda":
+            if self._gen is None:
+                self._gen = torch.Generator(device=device)
+                self._gen.manual_seed(self.seed)
+            return torch.randperm(n_rows, device=device, generator=self._gen)[:n_out]
+        return torch.as_tensor(self.rng.permutation(n_rows)[:n_out], device=device)
+
     def augment(self, rays_o, rays_d, target):
         if not self.full:
             return rays_o, rays_d, target
         _, n_out = self.sizes(rays_o.shape[0])
-        self._ix_out = self.rng.permutation(self.pool.shape[0])[:n_out]
-        picked = self.pool[torch.as_tensor(self._ix_out, device=self.pool.device)]
+        self._ix_out = self._pick(self.pool.shape[0], n_out, self.pool.device)
+        picked = self.pool[self._ix_out]
         return (torch.cat([rays_o, picked[:, :3]], 0), torch.cat([rays_d, picked[:, 3:6]], 0),
                 torch.cat([target, picked[:, 6:]], 0))
 
@@ -79,11 +94,17 @@ class HardRayPool:
         hard = order[-n_in:]
         rows = torch.cat([rays_o[hard], rays_d[hard], target[hard]], dim=-1)
         if self.full:
-            self.pool[torch.as_tensor(self._ix_out[:n_in], device=self.pool.device)] = rows
-        else:
-            self.pool = rows if self.pool is None else torch.cat([self.pool, rows], 0)
-            if self.pool.shape[0] >= batch_size * self.mul:
-                self.full = True
+            self.pool[self._ix_out[:n_in]] = rows
+            return
+        if self._store is None:  # final size: the first multiple of n_in that reaches batch_size * hard_mul
+            steps = max(1, -(-int(np.ceil(batch_size * self.mul)) // n_in))
+            self._store = torch.empty(steps * n_in, rows.shape[1], dtype=rows.dtype, device=rows.device)
+            self._n = 0
+        self._store[self._n:self._n + n_in] = rows
+        self._n += n_in
+        self.pool = self._store[:self._n]
+        if self._n >= batch_size * self.mul:
+            self.full = True
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -233,19 +254,20 @@ def main(argv=None):
         raise RuntimeError("R2L training runs on the HIP path and needs a ROCm GPU")
     datadir_kd = args.datadir_kd.split(":")[1] if ":" in args.datadir_kd else args.datadir_kd
     files = D.list_ray_shards(datadir_kd, args.pseudo_ratio, args.pseudo_data_hold_ratio)
-    loader = D.RayShardLoader(files, args.N_rand, rank=rank, world=world)
+    loader = D.RayShardLoader(files, args.N_rand, rank=rank, world=world, device=device,
+                              threads=max(1, min(args.num_workers, 16)))
     logger.info("Loaded data. Now total #train files: %d (this rank: %d)" % (len(files), len(loader.files)))
     trainer = R2LTrainer(model, point_sampler, lw_rgb=args.lw_rgb)
     if ckpt is not None and args.resume:
         trainer.load_optimizer_state_dict(ckpt["optimizer_state_dict"])
         logger.info("Resume optimizer successfully.")
-    pool = HardRayPool(args.hard_ratio, args.hard_mul) if args.hard_ratio else None
+    pool = HardRayPool(args.hard_ratio, args.hard_mul, seed=1000 + rank) if args.hard_ratio else None
     hist_psnr, t_data, t_batch = 0., 0., 0.
     logger.info("Begin training")
     for i in range(start + 1, args.N_iters + 1):
         t0 = time.time()
         lr = lr_schedule(i, args.lrate, args.lrate_decay, args.warmup_lr)
-        batch = loader.next().to(device, non_blocking=True)  # H2D of 36 B/ray
+        batch = loader.next()  # device tensor; its H2D copy (36 B/ray) ran on the loader's stream during the last step
         rays_o, rays_d, target = batch[:, :3], batch[:, 3:6], batch[:, 6:9]
         batch_size = rays_o.shape[0]
         if pool is not None:

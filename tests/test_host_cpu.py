@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import r2l_oracle as O
@@ -92,10 +93,60 @@ def test_pose_spherical_and_shards(tmp_path, golden_dir):
     assert o.shape == (4096, 3) and torch.equal(torch.cat([o, d, c], -1), torch.from_numpy(rows[:4096]))
     assert data.shard_for_rank(files, 0, 2) + data.shard_for_rank(files, 1, 2) != files  # interleaved
     assert sorted(data.shard_for_rank(files, 0, 2) + data.shard_for_rank(files, 1, 2)) == sorted(files)
-    ld = data.RayShardLoader(files, 2, rank=1, world=2, pin=False)
+    ld = data.RayShardLoader(files, 2, rank=1, world=2, pin=False)  # rank 1 of 2 owns exactly one of the 3 files
     b = ld.next()
     ld.close()
     assert b.shape == (8192, 9)
+    own = np.load(data.shard_for_rank(files, 1, 2)[0])
+    assert np.array_equal(b[:4096].numpy(), own) and np.array_equal(b[4096:].numpy(), own)
+
+
+def test_native_shard_reader(tmp_path):
+    """The reader threads of libr2l_hip.so against np.load: bit-identical payloads, every file exactly once per
+    permutation (InfiniteSampler semantics, main.py:759-767), seeded order, .npy v2 headers, loud shape errors."""
+    from numpy.lib import format as npf
+    from r2l_amd import data
+    n_files, rows = 7, 64
+    files = []
+    for k in range(n_files):
+        a = np.full((rows, 9), float(k), np.float32) + np.arange(rows * 9, dtype=np.float32).reshape(rows, 9) / 1024
+        f = str(tmp_path / ("data_%d.npy" % k))
+        if k % 2:
+            np.save(f, a)
+        else:  # NumPy format 2.0 (4-byte header length)
+            with open(f, "wb") as fp:
+                npf.write_array(fp, a, version=(2, 0))
+        files.append(f)
+    seen = []
+    ld = data.RayShardLoader(files, 3, seed=5, pin=False, threads=3)
+    for _ in range(7):  # 21 shards = 3 full permutations
+        b = ld.next().clone()
+        assert b.shape == (3 * rows, 9)
+        for j in range(3):
+            blk = b[j * rows:(j + 1) * rows].numpy()
+            k = int(blk[0, 0])
+            assert np.array_equal(blk, np.load(files[k]))
+            seen.append(k)
+    assert ld.files_read() >= 21
+    ld.close()
+    for e in range(3):
+        assert sorted(seen[e * 7:(e + 1) * 7]) == list(range(7))
+    assert seen[:7] != seen[7:14] or seen[7:14] != seen[14:21]  # reshuffled between epochs
+    ld2 = data.RayShardLoader(files, 3, seed=5, pin=False, threads=1)
+    again = []
+    for _ in range(2):
+        b = ld2.next()
+        again += [int(b[j * rows, 0]) for j in range(3)]
+    ld2.close()
+    assert again == seen[:6]  # the order depends on the seed only, not on thread timing
+    np.save(str(tmp_path / "data_9.npy"), np.zeros((rows + 1, 9), np.float32))
+    bad = data.RayShardLoader(files[:1] + [str(tmp_path / "data_9.npy")], 2, pin=False)
+    with pytest.raises(RuntimeError, match="expected"):
+        bad.next()
+    bad.close()
+    np.save(str(tmp_path / "data_10.npy"), np.zeros((rows, 9), np.float64))
+    with pytest.raises(RuntimeError, match="float32"):
+        data.RayShardLoader([str(tmp_path / "data_10.npy")], 1, pin=False)
 
 
 def test_load_blender_synthetic(tmp_path):
