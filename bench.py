@@ -74,6 +74,25 @@ def timed(fn, steps, warmup, distributed, device):
     return dt, kernel_ms
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM-side bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary (profiles/
+    rNN_bench_pmc_summary.json, made by tools/profile_gpu.sh in separate counter passes): FETCH_SIZE x 2 (gfx950 tallies
+    the 128-B requests of 16 B/lane loads at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB.
+    PMC passes cannot run inside this process, so the figure is the recorded one, or None if no summary is there."""
+    import glob
+    import json as _json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    files = sorted(glob.glob(os.path.join(root, "r*_bench_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        table = _json.load(f)
+    for name, c in table.items():
+        if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (2. * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024., os.path.relpath(files[-1], os.path.dirname(root))
+    return None, None
+
+
 def cpu_baseline(sd, n_rays=32768):
     """The oracle (CPU restatement of the reference op sequence) timed on the host cores: reported, not a target.
     torch's intra-op pool scales badly past a few dozen threads on these 256x256 GEMMs (measured on the EPYC 9575F box:
@@ -164,6 +183,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    from r2l_amd import build as r2l_build
+    if not os.path.exists(r2l_build.LIB):  # normally prebuilt in-tree by __graft_entry__.build(); never a CPU fallback
+        if local_rank == 0:
+            r2l_build.build(verbose=False)
+        for _ in range(1200):
+            if os.path.exists(r2l_build.LIB):
+                break
+            time.sleep(0.5)
     from r2l_amd.data import pose_spherical
     net, ps, sd = make_model(device)
     # synthetic test poses: pose_spherical(theta, -30, 4), theta = linspace(-180,180,41)[:-1]  (load_blender.py:84-86)
@@ -179,6 +206,7 @@ def main():
     rays = H * W * a.steps * world
     value = rays / dt
     achieved = H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic("void r2l_fwd_kernel<1, false>")
 
     out = {
         "metric": "rays/sec (train+render) W256D88 lego@400x400", "value": value, "unit": "rays/s", "n_gpus": world,
@@ -190,7 +218,9 @@ def main():
                    "rays_per_step_per_gpu": H * W, "parallelism": "frames sharded across %d rank(s), no collective"
                                                                % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
+                     "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
+                                     "bytes per launch = 160000 rays x 12 B out + 24.3 MB weight stream" % traffic_src,
                      "kernel": "r2l_fwd_kernel<MODE_POSE>", "kernel_ms": kernel_ms,
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }

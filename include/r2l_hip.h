@@ -108,6 +108,16 @@ int r2l_raw2outputs(const float* raw, const float* z, const float* rays_d, const
 int r2l_sample_pdf_sort(const float* z, const float* weights, const float* u, int64_t u_stride, float* z_samples,
                         float* z_all, float* z_std, int64_t R, int S, int NI, void* stream);
 
+/* ---- test-set metric ------------------------------------------------------------------------------------------------
+ * out[0] = SSIM(img1, img2): utils/ssim_torch.py:28-56,86-94 as called at main.py:46,254,334 (11x11 Gaussian sigma 1.5,
+ * zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over every pixel and channel), fused into one kernel + a fixed-order
+ * finish.  img1/img2: device [H, W, C] fp32 (the layout render_path holds, no permute).  window_host: host pointer to
+ * the 121 window values (ssim_torch.py:19-25) or NULL to have them computed here.  partial: device scratch of
+ * r2l_ssim_partial_count(H, W, C) floats. */
+int64_t r2l_ssim_partial_count(int H, int W, int C);
+int r2l_ssim(const float* img1, const float* img2, int H, int W, int C, const float* window_host, float* partial,
+             float* out, void* stream);
+
 /* ---- ray-shard reader (host threads; --data_mode rays) ------------------------------------------------------------
  * Replaces BlenderDataset_v2.__getitem__ (dataset/load_blender.py:257-324: np.load of one [4096,9] f32 shard),
  * InfiniteSamplerWrapper (main.py:759-776: random permutations of the file list, forever) and the DataLoader's

@@ -352,3 +352,26 @@ def make_teacher_state_dicts(seed, n_nets=2, D=8, W=256, input_ch=63, input_ch_v
             sd["rgb_linear.weight"], sd["rgb_linear.bias"] = rgb.weight.detach(), rgb.bias.detach()
             out.append(sd)
     return out
+
+
+# ---- SSIM (test-set metric) -------------------------------------------------------------------------------------------
+def ssim_window(window_size=11, sigma=1.5):
+    """utils/ssim_torch.py:11-25: fp32 Gaussian normalised in fp32; 2-D window = outer product (fp32)."""
+    import math
+    g = torch.tensor([math.exp(-(x - window_size // 2)**2 / float(2 * sigma**2)) for x in range(window_size)])
+    g = g / g.sum()
+    return g[:, None] @ g[None, :]
+
+
+def ssim(img1, img2, window_size=11):
+    """utils/ssim_torch.py:28-56 + 86-94 as main.py:46 calls it.  img1, img2: [H, W, C] in [0,1] -> scalar tensor."""
+    import torch.nn.functional as F
+    a, b = img1.permute(2, 0, 1)[None], img2.permute(2, 0, 1)[None]
+    C = a.shape[1]
+    w = ssim_window(window_size).to(a)[None, None].expand(C, 1, window_size, window_size).contiguous()
+    conv = lambda t: F.conv2d(t, w, padding=window_size // 2, groups=C)
+    mu1, mu2 = conv(a), conv(b)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1, s2, s12 = conv(a * a) - mu1_sq, conv(b * b) - mu2_sq, conv(a * b) - mu12
+    C1, C2 = 0.01**2, 0.03**2
+    return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()

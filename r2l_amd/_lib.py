@@ -37,6 +37,8 @@ SIGNATURES = {
     "r2l_stratified_z": (_i, [_p, _p, _i, _p, _p, _p, _l, _i, _p]),
     "r2l_raw2outputs": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p]),
     "r2l_sample_pdf_sort": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
+    "r2l_ssim_partial_count": (_l, [_i, _i, _i]),
+    "r2l_ssim": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "r2l_npy_shape": (_i, [ctypes.c_char_p, _p, _p]),
     "r2l_reader_open": (_i, [_p, _l, _i, _i, ctypes.c_uint64, _p, _i, _p]),
     "r2l_reader_info": (_i, [_p, _p, _p, _p]),

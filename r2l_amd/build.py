@@ -64,10 +64,12 @@ def build(verbose=True, force=False):
     objs = [o for o, _ in results]
     rebuilt = any(c for _, c in results) or not os.path.exists(LIB)
     if rebuilt:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())  # link aside, then rename: other ranks never see a half-written .so
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        os.replace(tmp, LIB)
     if verbose:
         print("[r2l_amd.build] %s (%s)" % (LIB, "rebuilt" if rebuilt else "up to date"))
     return LIB

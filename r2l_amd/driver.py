@@ -14,7 +14,7 @@ import torch.distributed as dist
 from . import data as D
 from .checkpoint import load_ckpt, load_weights_v2, parse_expid_iter, save_ckpt
 from .logger import Logger
-from .metrics import img2mse, mse2psnr, to8b
+from .metrics import img2mse, mse2psnr, ssim, to8b
 from .nerf_raybased import NeRF_v3_2, PointSampler, PositionalEmbedder
 from .options import parse_args, validate_accelerated
 from .train_step import R2LTrainer, lr_schedule
@@ -141,10 +141,10 @@ def render_frame(model, point_sampler, c2w):
 
 def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, savedir=None, rank=0, world=1):
     """Render poses[rank::world]; returns (rgbs [n,H,W,3], misc with test_loss/test_psnr/test_psnr_v2 over ALL frames)
-    — the R2L branch of main.py:189-398 with PSNR as the graded metric (SSIM/LPIPS/FLIP are out of scope)."""
+    and test_ssim — the R2L branch of main.py:189-398 (LPIPS/FLIP need network weights / packages that are absent: out of scope)."""
     model.eval()
     mine = list(range(rank, len(poses), world))
-    rgbs, sq_err, psnrs = [], [], []
+    rgbs, sq_err, psnrs, ssims = [], [], [], []
     for i in mine:
         sync(device)
         t0 = time.time()
@@ -157,6 +157,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             mse = img2mse(rgb, gt)
             sq_err.append(mse)
             psnrs.append(mse2psnr(mse))
+            ssims.append(ssim(rgb, gt))
         if savedir is not None:
             from PIL import Image
             Image.fromarray(to8b(rgb)).save(os.path.join(savedir, "%03d.png" % i))
@@ -165,13 +166,14 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     rgbs = torch.stack(rgbs, 0) if rgbs else torch.empty(0)
     misc = {}
     if gt_imgs is not None:
-        stats = torch.tensor([float(sum(sq_err)) if sq_err else 0., float(sum(psnrs)) if psnrs else 0., len(mine)],
-                             dtype=torch.float64, device=device)
+        stats = torch.tensor([float(sum(sq_err)) if sq_err else 0., float(sum(psnrs)) if psnrs else 0., len(mine),
+                              float(sum(ssims)) if ssims else 0.], dtype=torch.float64, device=device)
         if world > 1:
-            dist.all_reduce(stats)  # host-side metric gather (3 scalars), not on the data path
+            dist.all_reduce(stats)  # host-side metric gather (4 scalars), not on the data path
         misc["test_loss"] = torch.tensor(stats[0].item() / max(stats[2].item(), 1))
         misc["test_psnr"] = mse2psnr(misc["test_loss"].float()).squeeze()
         misc["test_psnr_v2"] = torch.tensor(stats[1].item() / max(stats[2].item(), 1))
+        misc["test_ssim"] = torch.tensor(stats[3].item() / max(stats[2].item(), 1))
     model.train()
     return rgbs, misc
 
@@ -208,8 +210,9 @@ def main(argv=None):
     if args.test_pretrained:
         _, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images, rank=rank,
                               world=world)
-        logger.info("Pretrained test: TestLoss %.4f TestPSNR %.4f TestPSNRv2 %.4f" %
-                    (misc["test_loss"].item(), misc["test_psnr"].item(), misc["test_psnr_v2"].item()))
+        logger.info("Pretrained test: TestLoss %.4f TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" %
+                    (misc["test_loss"].item(), misc["test_psnr"].item(), misc["test_psnr_v2"].item(),
+                     misc["test_ssim"].item()))
 
     if args.render_only:
         logger.info("RENDER ONLY")
@@ -219,7 +222,8 @@ def main(argv=None):
             rgbs, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images,
                                      savedir=logger.gen_img_path if rank == 0 or world > 1 else None, rank=rank,
                                      world=world)
-            logger.info("[TEST] TestPSNR %.4f TestPSNRv2 %.4f" % (misc["test_psnr"].item(), misc["test_psnr_v2"].item()))
+            logger.info("[TEST] TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" %
+                        (misc["test_psnr"].item(), misc["test_psnr_v2"].item(), misc["test_ssim"].item()))
         else:
             rgbs, misc = render_path(video_poses, model, point_sampler, device, logger, savedir=logger.gen_img_path,
                                      rank=rank, world=world)
@@ -293,9 +297,10 @@ def main(argv=None):
                 if rank == 0:
                     save_ckpt(os.path.join(logger.weights_path, "ckpt_best.tar"), i, model,
                               trainer.optimizer_state_dict(lr), best_psnr, best_psnr_step)
-            logger.info("[TEST] Iter %d TestPSNR %.4f TestPSNRv2 %.4f BestPSNRv2 %.4f (Iter %d) TrainHistPSNR %.4f "
-                        "LR %.8f Time %.1fs" % (i, misc["test_psnr"].item(), misc["test_psnr_v2"].item(), best_psnr,
-                                                best_psnr_step, hist_psnr, lr, time.time() - t_))
+            logger.info("[TEST] Iter %d TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f BestPSNRv2 %.4f (Iter %d) "
+                        "TrainHistPSNR %.4f LR %.8f Time %.1fs" %
+                        (i, misc["test_psnr"].item(), misc["test_psnr_v2"].item(), misc["test_ssim"].item(), best_psnr,
+                         best_psnr_step, hist_psnr, lr, time.time() - t_))
         if i % args.i_weights == 0 and rank == 0:
             name = "ckpt_%d.tar" % i if args.save_intermediate_models else "ckpt.tar"
             path = save_ckpt(os.path.join(logger.weights_path, name), i, model, trainer.optimizer_state_dict(lr),

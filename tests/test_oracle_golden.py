@@ -135,3 +135,16 @@ def test_render_rays(golden_dir):
     for tag, ret in (("det", det), ("pytest", rnd)):
         for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
             np.testing.assert_allclose(ret[k].numpy(), g[tag + "/" + k], rtol=2e-5, atol=2e-6, err_msg=tag + k)
+
+
+def test_ssim_matches_reference(golden_dir):
+    """oracle.ssim and the CPU branch of r2l_amd.metrics.ssim against utils/ssim_torch.py outputs (gen_golden_ssim.py)."""
+    from r2l_amd import metrics
+    g = np.load(os.path.join(golden_dir, "ssim.npz"))
+    np.testing.assert_array_equal(O.ssim_window().numpy(), g["window"])
+    np.testing.assert_array_equal(metrics._ssim_window().numpy(), g["window"])
+    for tag in "abc":
+        pred, gt = torch.from_numpy(g["pred_" + tag]), torch.from_numpy(g["gt_" + tag])
+        for fn in (O.ssim, metrics.ssim):
+            assert abs(fn(pred, gt).item() - float(g["ssim_" + tag])) < 2e-6
+            assert abs(fn(gt, gt).item() - 1.0) < 2e-6
