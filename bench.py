@@ -115,6 +115,24 @@ def cpu_baseline(sd, n_rays=32768):
             dt = time.perf_counter() - t0
             if best is None or dt < best:
                 best, best_threads = dt, nt
+    # training step on the host: sample_train + encode + forward + autograd backward + Adam, N = 4096
+    torch.set_num_threads(best_threads)
+    n_tr = 4096
+    o = torch.randn(n_tr, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])
+    d = torch.nn.functional.normalize(torch.randn(n_tr, 3, generator=g), dim=-1)
+    tgt = torch.rand(n_tr, 3, generator=g)
+    p = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    times = []
+    for it in range(1, 5):
+        t0 = time.perf_counter()
+        emb = Or.positional_embed(Or.sample_train(o, d, z, 1.0, t_rand=torch.rand(n_tr, 16, generator=g)), 10)
+        grads = Or.r2l_loss_and_grads(p, emb, tgt)[2]
+        for k in p:
+            p[k], m[k], v2[k] = Or.adam_step(p[k], grads[k], m[k], v2[k], it, 5e-4)
+        times.append(time.perf_counter() - t0)
+    train_s = sorted(times[1:])[1]  # median of 3 after one warm-up
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -125,6 +143,8 @@ def cpu_baseline(sd, n_rays=32768):
     except OSError:
         pass
     return {"value": n_rays / best, "unit": "rays/s", "cores": best_threads, "kind": "port",
+            "train": {"value": n_tr / train_s, "unit": "rays/s", "rays_per_step": n_tr, "cores": best_threads,
+                      "sample": "median of 3 oracle training steps (sample + encode + fwd + autograd bwd + Adam)"},
             "sample": "%d rays of one 400x400 frame: sample + encode + W256D88 forward, fp32 torch CPU ops, best of "
                       "{16,32,64} threads on %d logical CPUs; %s" % (n_rays, ncpu, cpu_model)}, rgb, rows
 
