@@ -60,14 +60,17 @@ int r2l_forward_emb(const float* emb, const float* wstream, const float* params,
  *   generic   (target == NULL): dL/drgb = drgb[N,3] supplied by the caller (autograd bridge).
  * Head input: emb[N,1008] if given, else recomputed from (rays_o, rays_d, t_rand, ztab) exactly as the forward did.
  * save_x/save_t: the stash written by the forward.  Scratch owned by the caller: dpre[N,3], gx[(n_block+1),Np,256],
- * gt[n_block,Np,256] (Np = r2l_padded_rows(N)).  Gradients are ACCUMULATED (fp32 atomics) into `grads` (flat, same layout as params): zero it
- * first unless accumulation is wanted. */
+ * gt[n_block,Np,256] (Np = r2l_padded_rows(N)), dw_slab[r2l_dw_slab_floats()] (per-workgroup partial body-layer
+ * gradients, summed in a fixed order: bit-reproducible; NULL selects fp32 atomics instead, no scratch but run-to-run
+ * rounding differences).  Gradients are ACCUMULATED into `grads` (flat, same layout as params): zero it first unless
+ * accumulation is wanted. */
 int64_t r2l_num_tiles(int64_t N);
 int64_t r2l_padded_rows(int64_t N);
+int64_t r2l_dw_slab_floats(void);
 int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* emb,
                  const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                  const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                 float* gt, float* sqerr_partial, float* grads, int64_t N, void* stream);
+                 float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N, void* stream);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay 0) on flat buffers (main.py:465-467, 1406); `step` counts from 1;
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */

@@ -39,11 +39,12 @@ class R2LEmbFunction(torch.autograd.Function):
         gx = torch.empty((nb + 1) * npad * W, **f)
         gt = torch.empty(max(nb, 1) * npad * W, **f)
         dpre = torch.empty(n * 3, **f)
+        slab = torch.empty(int(lib.r2l_dw_slab_floats()), **f)
         drgb = grad_rgb.reshape(-1, 3).contiguous().float()
         _lib.check(
             lib.r2l_backward(None, None, None, None, _ptr(emb2), _ptr(rgb), None, _ptr(drgb), _ptr(save_x),
                              _ptr(save_t), _ptr(wbwd), _ptr(eng.flat), nb, 0.0, _ptr(dpre), _ptr(gx), _ptr(gt), None,
-                             _ptr(grads), n, _stream()), "r2l_backward")
+                             _ptr(grads), _ptr(slab), n, _stream()), "r2l_backward")
         out, off = [], 0
         for p in eng.params:
             k = p.numel()

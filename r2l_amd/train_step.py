@@ -10,6 +10,8 @@ world_size > 1] -> fused Adam -> re-pack of the MFMA weight streams.  No autogra
 import ctypes
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -36,6 +38,7 @@ class R2LTrainer:
         self.reducer = GradAllReducer(process_group)
         self.step_count = 0
         self.cap = 0
+        self.dw_slab = None
         self._alloc_state()
 
     # ---- buffers --------------------------------------------------------------------------------------------------
@@ -63,6 +66,8 @@ class R2LTrainer:
         self.gt = torch.empty(max(nb, 1) * npad * W, **f)
         self.dpre = torch.empty(n * 3, **f)
         self.sqerr = torch.empty(int(self.lib.r2l_num_tiles(n)), **f)
+        if getattr(self, "dw_slab", None) is None and not os.environ.get("R2L_NO_DW_SLAB"):  # env: A/B diagnostics only
+            self.dw_slab = torch.empty(int(self.lib.r2l_dw_slab_floats()), **f)
 
     def _pack_bwd(self):
         key = self.eng._packed_version
@@ -95,7 +100,7 @@ class R2LTrainer:
             self.lib.r2l_backward(_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target),
                                   None, _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat),
                                   eng.n_block, grad_scale, _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt),
-                                  _ptr(self.sqerr), _ptr(self.grads), n, _stream()), "r2l_backward")
+                                  _ptr(self.sqerr), _ptr(self.grads), _ptr(self.dw_slab), n, _stream()), "r2l_backward")
         _lib.check(
             self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
                                      _ptr(self.loss_out), _stream()), "r2l_loss_finish")
