@@ -712,7 +712,12 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
     }
     const int n_cu = n_cu_cached;
     // 1. dX chain
-    if (r2l_use_coop(N)) {
+    const int variant = r2l_chain_variant(N);
+    if (variant == R2L_VARIANT_COOP16) {
+        const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
+                                           params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
+        if (rc) return rc;
+    } else if (variant == R2L_VARIANT_COOP) {
         const int rc = r2l_coop_backward(rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block, grad_scale, dpre,
                                          gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;

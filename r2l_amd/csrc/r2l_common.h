@@ -310,16 +310,51 @@ int r2l_coop_forward(const float* rays_o, const float* rays_d, const float* t_ra
 int r2l_coop_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream);
-// Which chain variant is faster for N rays: the main kernels need ceil(N/32768) rounds of one tile-time each (1024 wave
-// slots x 32 rays), the cooperative ones ceil(N/8192) rounds (256 workgroups x 32 rays) of ~0.28 tile-times each.
-// R2L_FORCE_VARIANT=main|coop in the environment overrides (tests, A/B).
-static inline bool r2l_use_coop(int64_t N) {
+// ---- 16-ray cooperative variants (r2l_coop16.hip): their own packed streams, appended to the 32-layout ones ------------
+// group16 = [16 tiles of 16 output features][64 lanes][float4]: lane (i = l%16, kk = l/16) component e holds
+// W[16*tile + i][16*G + 4*kk + e] — the A operand of v_mfma_f32_16x16x4_f32 number e of k-group G.
+#define R2L_C16_GROUP_FLOATS 4096
+#define R2L_C16_LAYER_GROUPS 16
+#define R2L_C16_HEAD_GROUPS 63   // 60 trig groups (k' order: coord-major, (sin f, cos f) pairs) + 3 identity groups
+#define R2L_C16_PAD_GROUPS 8     // the weight ring prefetches 8 groups past the end
+__host__ __device__ static inline int64_t r2l_fwd32_stream_floats(int n_block) {
+    return (int64_t)(R2L_FWD_HEAD_GROUPS + 2 * n_block * R2L_FWD_LAYER_GROUPS) * R2L_GROUP_FLOATS + R2L_STREAM_PAD;
+}
+__host__ __device__ static inline int64_t r2l_bwd32_stream_floats(int n_block) {
+    return (int64_t)2 * n_block * R2L_LAYER_FLOATS + R2L_STREAM_PAD;
+}
+__host__ __device__ static inline int64_t r2l_fwd16_stream_floats(int n_block) {
+    return (int64_t)(R2L_C16_HEAD_GROUPS + 2 * n_block * R2L_C16_LAYER_GROUPS + R2L_C16_PAD_GROUPS) * R2L_C16_GROUP_FLOATS;
+}
+__host__ __device__ static inline int64_t r2l_bwd16_stream_floats(int n_block) {
+    return (int64_t)(2 * n_block * R2L_C16_LAYER_GROUPS + R2L_C16_PAD_GROUPS) * R2L_C16_GROUP_FLOATS;
+}
+int r2l_coop16_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                       const float* c2w_host12, int H, int W, float focal, const float* wstream16, const float* params,
+                       int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
+int r2l_coop16_backward(const float* rgb, const float* target, const float* drgb, const float* save_x,
+                        const float* save_t, const float* wstream_bwd16, const float* params, int n_block,
+                        float grad_scale, float* dpre, float* gx, float* gt, float* sqerr_partial, int64_t N,
+                        hipStream_t stream);
+
+// Which chain variant is fastest for N rays.  In units of one main-kernel round (1024 wave slots x 32 rays): main needs
+// ceil(N/32768) rounds; coop (4 waves share a 32-ray tile, 256 workgroups) ceil(N/8192) rounds of ~0.34 (measured: fwd
+// 0.81 ms at 4096 rays, 0.94 ms at 8192); coop16 (4 waves share a 16-ray tile: fills all 256 CUs from 4096 rays)
+// ceil(N/4096) rounds of ~0.174 (0.47 ms at 4096 rays, 0.91 ms at 8192).
+// R2L_FORCE_VARIANT=main|coop|coop16 in the environment overrides (tests, A/B).
+#ifndef R2L_C16_ROUND
+#define R2L_C16_ROUND 0.174
+#endif
+enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP = 1, R2L_VARIANT_COOP16 = 2 };
+static inline int r2l_chain_variant(int64_t N) {
     const char* e = getenv("R2L_FORCE_VARIANT");  // read per call (~100 ns) so tests can flip it
-    if (e && e[0] == 'm') return false;
-    if (e && e[0] == 'c') return true;
+    if (e && e[0] == 'm') return R2L_VARIANT_MAIN;
+    if (e && e[0] == 'c') return (e[1] && e[2] && e[3] && e[4] == '1') ? R2L_VARIANT_COOP16 : R2L_VARIANT_COOP;
     const double main_t = (double)((N + 32767) / 32768);
-    const double coop_t = (double)((N + 8191) / 8192) * 0.28;
-    return coop_t < main_t;
+    const double coop_t = (double)((N + 8191) / 8192) * 0.34;
+    const double c16_t = (double)((N + 4095) / 4096) * R2L_C16_ROUND;
+    if (c16_t < coop_t && c16_t < main_t) return R2L_VARIANT_COOP16;
+    return coop_t < main_t ? R2L_VARIANT_COOP : R2L_VARIANT_MAIN;
 }
 
 // error plumbing shared by the C-ABI translation units

@@ -258,7 +258,11 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.wstream = wstream; a.params = params; a.n_block = n_block;
     a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N;
-    if (N > 0 && r2l_use_coop(N))
+    const int variant = N > 0 ? r2l_chain_variant(N) : R2L_VARIANT_MAIN;
+    if (variant == R2L_VARIANT_COOP16)
+        return r2l_coop16_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream + r2l_fwd32_stream_floats(n_block),
+                                  params, n_block, rgb, save_x, save_t, N, (hipStream_t)stream);
+    if (variant == R2L_VARIANT_COOP)
         return r2l_coop_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream, params, n_block, rgb, save_x,
                                 save_t, N, (hipStream_t)stream);
     return launch_fwd<MODE_RAYS>(a, (hipStream_t)stream);
@@ -271,7 +275,12 @@ extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float foc
     a.H = H; a.Wimg = W; a.focal = focal; a.ztab = ztab;
     a.wstream = wstream; a.params = params; a.n_block = n_block;
     a.rgb = rgb; a.N = (int64_t)H * W;
-    if (a.N > 0 && r2l_use_coop(a.N))
+    const int variant = a.N > 0 ? r2l_chain_variant(a.N) : R2L_VARIANT_MAIN;
+    if (variant == R2L_VARIANT_COOP16)
+        return r2l_coop16_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal,
+                                  wstream + r2l_fwd32_stream_floats(n_block), params, n_block, rgb, nullptr, nullptr, a.N,
+                                  (hipStream_t)stream);
+    if (variant == R2L_VARIANT_COOP)
         return r2l_coop_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, wstream, params, n_block, rgb,
                                 nullptr, nullptr, a.N, (hipStream_t)stream);
     return launch_fwd<MODE_POSE>(a, (hipStream_t)stream);

@@ -64,26 +64,85 @@ __global__ void r2l_pack_bwd_kernel(const float* __restrict__ params, float* __r
     }
 }
 
+// ---- 16-ray cooperative layout (r2l_common.h: group16) -------------------------------------------------------------------
+// forward: 63 head groups in the permuted k' order, then 16 groups per body layer (no bias groups: r2l_coop16.hip reads
+// the biases from the flat parameters).  k' < 960: block B = k'/80 of 4 coordinates, coordinate ci = (k'%80)/20 of it,
+// slot (k'%20): frequency f = slot/2, sin (even) or cos (odd) -> column 21*(4B+ci) + f (+10 for cos) of head.0.weight;
+// k' >= 960: the identity column 21*(k'-960) + 20.
+__global__ void r2l_pack_fwd16_kernel(const float* __restrict__ params, float* __restrict__ out, int n_block) {
+    const int64_t total = (int64_t)(R2L_C16_HEAD_GROUPS + 2 * n_block * R2L_C16_LAYER_GROUPS) * R2L_C16_GROUP_FLOATS;
+    const int64_t padded = r2l_fwd16_stream_floats(n_block);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= total) { out[i] = 0.f; continue; }
+        const int64_t gidx = i / R2L_C16_GROUP_FLOATS;
+        const int rem = (int)(i % R2L_C16_GROUP_FLOATS);
+        const int tile = rem >> 8, lane = (rem & 255) >> 2, e = rem & 3;
+        const int kk = lane >> 4, o = 16 * tile + (lane & 15);
+        float v;
+        if (gidx < R2L_C16_HEAD_GROUPS) {
+            const int kp = 16 * (int)gidx + 4 * kk + e;
+            int col;
+            if (kp < 960) {
+                const int B = kp / 80, off = kp % 80, ci = off / 20, slot = off % 20, f = slot >> 1;
+                col = 21 * (4 * B + ci) + ((slot & 1) ? 10 + f : f);
+            } else {
+                col = 21 * (kp - 960) + 20;
+            }
+            v = params[(int64_t)o * R2L_IN + col];
+        } else {
+            const int64_t gb = gidx - R2L_C16_HEAD_GROUPS;
+            const int layer = (int)(gb / R2L_C16_LAYER_GROUPS), G = (int)(gb % R2L_C16_LAYER_GROUPS);
+            const int in = 16 * G + 4 * kk + e;
+            v = params[pk_off_body_w(layer) + (int64_t)o * R2L_W + in];
+        }
+        out[i] = v;
+    }
+}
+
+// backward (dX): transposed body layers in reverse execution order, 16 groups each
+__global__ void r2l_pack_bwd16_kernel(const float* __restrict__ params, float* __restrict__ out, int n_block) {
+    const int64_t total = (int64_t)2 * n_block * R2L_C16_LAYER_GROUPS * R2L_C16_GROUP_FLOATS;
+    const int64_t padded = r2l_bwd16_stream_floats(n_block);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= total) { out[i] = 0.f; continue; }
+        const int64_t gidx = i / R2L_C16_GROUP_FLOATS;
+        const int rem = (int)(i % R2L_C16_GROUP_FLOATS);
+        const int tile = rem >> 8, lane = (rem & 255) >> 2, e = rem & 3;
+        const int kk = lane >> 4, o = 16 * tile + (lane & 15);
+        const int slot = (int)(gidx / R2L_C16_LAYER_GROUPS), G = (int)(gidx % R2L_C16_LAYER_GROUPS);
+        const int layer = 2 * n_block - 1 - slot;
+        const int in = 16 * G + 4 * kk + e;
+        out[i] = params[pk_off_body_w(layer) + (int64_t)in * R2L_W + o];  // (W^T)[o][in] = W[in][o]
+    }
+}
+
 extern "C" int64_t r2l_param_count(int n_block) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)2 * n_block * (R2L_W * R2L_W + R2L_W) + 3 * R2L_W + 3;
 }
 
+// a stream buffer = [32-ray-tile layout | 16-ray-tile layout]; every chain kernel finds its part by offset
 extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
-    return (int64_t)(R2L_FWD_HEAD_GROUPS + 2 * n_block * R2L_FWD_LAYER_GROUPS) * R2L_GROUP_FLOATS + R2L_STREAM_PAD;
+    return r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
 }
 
 extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
-    return (int64_t)2 * n_block * R2L_LAYER_FLOATS + R2L_STREAM_PAD;
+    return r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
 }
 
 extern "C" int r2l_pack_forward(const float* params, int n_block, float* wstream, void* stream) {
     hipLaunchKernelGGL(r2l_pack_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
+    R2L_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(r2l_pack_fwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
+                       wstream + r2l_fwd32_stream_floats(n_block), n_block);
     R2L_CHECK(hipGetLastError());
     return 0;
 }
 
 extern "C" int r2l_pack_backward(const float* params, int n_block, float* wstream, void* stream) {
     hipLaunchKernelGGL(r2l_pack_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
+    R2L_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(r2l_pack_bwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
+                       wstream + r2l_bwd32_stream_floats(n_block), n_block);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -10,7 +10,7 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coop"])
+@pytest.fixture(autouse=True, params=["main", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
     """Every test runs twice: one-wave-per-tile kernels and the cooperative small-batch kernels (r2l_coop.hip)."""
     monkeypatch.setenv("R2L_FORCE_VARIANT", request.param)
