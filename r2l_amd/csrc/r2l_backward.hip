@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
 // (which remain as the dw_slab == NULL path).  The gradient buffer is zeroed by the caller (accumulation for free).
 // =================================================================================================================
 #define DW_CHUNK 64  // rays per work unit
+#ifndef DW_LONG_TRIP
+#define DW_LONG_TRIP 128  // k-steps per trip of the main loop
+#endif
 
 struct R2LDwArgs {
     const float* save_x;
@@ -365,7 +368,17 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) ld(k, gb[k], ab[k]);
             int64_t s = 0;
-            for (; s + 64 <= nfull; s += 64) {  // two chunks per trip: one vmcnt(0) drain per 1024 MFMAs
+            // hipcc drains vmcnt to 0 at every loop header, which exposes the full HBM latency of the newest load (~2 us):
+            // long trips amortise it (one drain per 2048 / 1024 / 512 MFMAs)
+            for (; s + DW_LONG_TRIP <= nfull; s += DW_LONG_TRIP) {
+#pragma unroll
+                for (int k = 0; k < DW_LONG_TRIP; ++k) {
+                    kstep(gb[k & 3], ab[k & 3]);
+                    ld(s + k + 4, gb[k & 3], ab[k & 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            for (; s + 64 <= nfull; s += 64) {
 #pragma unroll
                 for (int k = 0; k < 64; ++k) {
                     kstep(gb[k & 3], ab[k & 3]);
@@ -394,6 +407,9 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
             if (hh) { gv = f32x4{0.f, 0.f, 0.f, 0.f}; av = gv; }
             kstep(gv, av);
         }
+#ifdef DW_NO_FLUSH  // diagnostics build only
+        if (a.N < 0) dw_flush_slab(acc, bsum, a.slab, wo, wi, lane);
+#else
         if (a.slab != nullptr) {
             dw_flush_slab(acc, bsum, a.slab + ((int64_t)blockIdx.x * 2 + (layer - first_layer)) * DW_SLAB_FLOATS, wo, wi,
                           lane);
@@ -402,6 +418,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
             float* gb = a.grads + b_off_body_b(layer);
             dw_flush(acc, bsum, gw, gb, wo, wi, lane);
         }
+#endif
         u += cend - cu;
     }
 }
