@@ -8,7 +8,9 @@ Per pose the whole stack runs on the GPU through libr2l_hip.so: get_rays -> stra
 RandomState, so the reference's single global np.random replay is distributional, not bitwise.
 """
 import os
+import queue
 import shutil
+import threading
 import time
 
 import numpy as np
@@ -90,20 +92,57 @@ def main(argv=None):
     files_per_flush = (args.create_data_chunk * H * W) // rays_per_file
     flushes = (len(mine) + args.create_data_chunk - 1) // max(args.create_data_chunk, 1)
     next_index = rank * (flushes * files_per_flush)
-    buf, t0, n_rays = [], time.time(), 0
+    # Rows of a flush are copied pose by pose (non-blocking) into one of two pinned staging buffers; a writer thread
+    # shuffles and saves a full buffer while the GPU renders into the other one.  The only host syncs are one per flush.
+    chunk_poses = max(args.create_data_chunk, 1)
+    pin = device.type == "cuda"
+    stage = [torch.empty(chunk_poses * H * W, 9, dtype=torch.float32, pin_memory=pin) for _ in range(2)]
+    jobs, errors = queue.Queue(maxsize=1), []
+    free = [threading.Event(), threading.Event()]  # set while no flush job is reading that staging buffer
+    for ev in free:
+        ev.set()
+
+    def writer():
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            try:
+                rows, seed, first_index, slot = job
+                r = np.random.RandomState(seed)
+                p1, p2 = r.permutation(rows.shape[0]), r.permutation(rows.shape[0])
+                # the reference permutes twice (create_data.py:854-859): rows[p1][p2] == rows[p1[p2]]
+                D.write_ray_shards(rows[p1[p2]], datadir_new, first_index, rays_per_file)
+            except Exception as e:  # surfaced by the main thread
+                errors.append(e)
+            finally:
+                free[job[3]].set()
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    t0, n_rays, k, filled = time.time(), 0, 0, 0
     for j, i in enumerate(mine, 1):
         pose = D.get_rand_pose(rng).to(device)
         focal_ = focal * (1 + rng.rand()) if args.use_rand_focal else focal  # focal x U[1,2) (create_data.py:816)
-        buf.append(render_pose_rows(pose, H, W, focal_, near, far, args.chunk, kwargs).cpu())
+        rows = render_pose_rows(pose, H, W, focal_, near, far, args.chunk, kwargs)
+        if filled == 0:
+            free[k].wait()  # the flush that last used this buffer has been written
+        stage[k][filled:filled + H * W].copy_(rows, non_blocking=True)
+        filled += H * W
         n_rays += H * W
-        if j % args.create_data_chunk == 0 or j == len(mine):
-            rows = torch.cat(buf, 0).numpy()
-            rows = rows[rng.permutation(rows.shape[0])]
-            rows = rows[rng.permutation(rows.shape[0])]  # the reference permutes twice (create_data.py:854-859)
-            next_index = D.write_ray_shards(rows, datadir_new, next_index, rays_per_file)
-            buf = []
-            sync(device)
+        if j % chunk_poses == 0 or j == len(mine):
+            sync(device)  # the staged rows have landed
+            if errors:
+                raise errors[0]
+            free[k].clear()
+            jobs.put((stage[k][:filled].numpy(), int(rng.randint(0, 2**31 - 1)), next_index, k))
+            next_index += filled // rays_per_file
+            k, filled = 1 - k, 0
             dt = time.time() - t0
             logger.info("[%d/%d poses on rank %d] %d rays in %.1fs = %.0f rays/s; shards up to data_%d.npy" %
                         (j, len(mine), rank, n_rays, dt, n_rays / dt, next_index - 1))
+    jobs.put(None)
+    th.join()
+    if errors:
+        raise errors[0]
     return {"n_rays": n_rays, "datadir": datadir_new, "logger": logger}

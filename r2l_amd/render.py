@@ -152,7 +152,7 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
             np.random.seed(0)
             noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std)
         else:
-            noise = torch.randn(raw[..., 3].shape) * raw_noise_std
+            noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std
         noise = noise.to(raw.device)
     if not raw.is_cuda:
         dists = z_vals[..., 1:] - z_vals[..., :-1]
@@ -180,8 +180,10 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     return rgb_map, disp, acc, weights, depth
 
 
-def _uniforms(shape, N_samples, det, pytest):
-    """The u of sample_pdf (helpers:291-307): linspace if det, numpy's seeded draws if pytest, else torch.rand."""
+def _uniforms(shape, N_samples, det, pytest, device=None):
+    """The u of sample_pdf (helpers:291-307): linspace if det, numpy's seeded draws if pytest, else torch.rand — drawn on
+    `device` (the reference runs with a CUDA default tensor type, main.py; a host draw + pageable copy per 32 768-ray
+    chunk would serialise the host with the GPU)."""
     if pytest:
         np.random.seed(0)
         if det:
@@ -189,7 +191,7 @@ def _uniforms(shape, N_samples, det, pytest):
         return torch.Tensor(np.random.rand(*(list(shape) + [N_samples])))
     if det:
         return torch.linspace(0., 1., steps=N_samples).expand(list(shape) + [N_samples])
-    return torch.rand(list(shape) + [N_samples])
+    return torch.rand(list(shape) + [N_samples], device=device)
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
@@ -200,7 +202,7 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
     if u is None:
-        u = _uniforms(cdf.shape[:-1], N_samples, det, pytest)
+        u = _uniforms(cdf.shape[:-1], N_samples, det, pytest, device=cdf.device)
     u = u.to(cdf.device).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp(inds - 1, min=0)
@@ -217,8 +219,8 @@ def sample_pdf_sort(z_vals, weights, N_importance, det=False, pytest=False, u=No
     (create_data.py:505-515) fused on the GPU."""
     R, S = z_vals.shape
     if u is None:
-        u = torch.linspace(0., 1., steps=N_importance) if (det and not pytest) else _uniforms((R,), N_importance, det,
-                                                                                                pytest)
+        u = torch.linspace(0., 1., steps=N_importance) if (det and not pytest) else _uniforms(
+            (R,), N_importance, det, pytest, device=z_vals.device)
     if not z_vals.is_cuda:
         z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
         uu = u if u.dim() == 2 else u.expand(R, N_importance)
@@ -251,7 +253,7 @@ def _coarse_z(near, far, N_samples, lindisp, perturb, pytest, t_rand=None):
             np.random.seed(0)
             t_rand = torch.Tensor(np.random.rand(R, N_samples))
         else:
-            t_rand = torch.rand(R, N_samples)
+            t_rand = torch.rand(R, N_samples, device=dev)  # on the rays' device (see _uniforms)
     if perturb <= 0.:
         t_rand = None
     if not near.is_cuda:
