@@ -38,10 +38,15 @@ __host__ __device__ static inline TOff t_offsets() {
     return o;
 }
 
-// xyz-embedding column fed by k-step s of half-wave h (or -1 = zero padding):
-//   s < 30 : frequency 5h + s/6, slot s%6 (0..2 sin x,y,z ; 3..5 cos x,y,z);  s = 30..32 : identity (half 0 only)
+// xyz-embedding column fed by k-step s of half-wave h (or -1 = zero padding).  The k order is ours to choose (the pack
+// kernel follows it): (sin, cos) PAIRS, so that a group of 4 k-steps needs exactly two sincos evaluations and the
+// kernel can generate them group by group instead of holding all 36 values (which spilled to scratch):
+//   s < 30 : pair q = s/2 -> frequency 5h + q/3, axis q%3; even s = sin, odd s = cos;  s = 30..32 : identity (half 0 only)
 __host__ __device__ static inline int t_xyz_col(int s, int h) {
-    if (s < 30) return 3 + (5 * h + s / 6) * 6 + (s % 6);
+    if (s < 30) {
+        const int q = s >> 1, fl = q / 3, ax = q % 3;
+        return 3 + (5 * h + fl) * 6 + ((s & 1) ? 3 + ax : ax);
+    }
     if (s < 33) return h == 0 ? s - 30 : -1;
     return -1;
 }
@@ -52,19 +57,21 @@ __host__ __device__ static inline int t_dir_col(int s, int h) {
 }
 
 // stream layout (units: load-groups of 8 float4 per lane = 2048 floats); "B*" = bias group (r2l_common.h)
-//   [B0][L0 pe x9] {[B_i][L_i x32]} i=1..4  [B5][L5 pe x9][L5 h x32] [B6][L6 x32] [B7][L7 x32] [BF][feature x32]
+//   [B0][L0 pe x9] {[B_i][L_i x32]} i=1..4  [B5][L5 pe x9 + zero group][L5 h x32] [B6][L6 x32] [B7][L7 x32] [BF][feature x32]
 //   [BV][views(feature part) x16][views(dir part) x2]
 #define TG_B0 0
 #define TG_L0 1
 #define TG_BODY (TG_L0 + T_PE_GROUPS)                 // 10: layers 1..4, 33 groups each (bias + 32)
 #define TG_B5 (TG_BODY + 4 * 33)                      // 142
 #define TG_L5PE (TG_B5 + 1)
-#define TG_L5H (TG_L5PE + T_PE_GROUPS)                // 152
-#define TG_L67F (TG_L5H + 32)                         // 184: layers 6, 7, feature: 33 groups each
-#define TG_BV (TG_L67F + 3 * 33)                      // 283
+#define T_PE5_GROUPS 10                               // layer 5's embedding part: 9 groups + 1 all-zero group, so that every
+                                                      // trip of the layer-pair loop has an even number of groups (ring of 2)
+#define TG_L5H (TG_L5PE + T_PE5_GROUPS)               // 153
+#define TG_L67F (TG_L5H + 32)                         // 185: layers 6, 7, feature: 33 groups each
+#define TG_BV (TG_L67F + 3 * 33)                      // 284
 #define TG_VIEWS (TG_BV + 1)                          // 32 k-groups x 4 tiles = 16 load-groups
 #define TG_VDIR (TG_VIEWS + 16)                       // 4 k-groups x 4 tiles = 2 load-groups
-#define TG_TOTAL (TG_VDIR + 2)                        // 302
+#define TG_TOTAL (TG_VDIR + 2)                        // 303
 
 __global__ void r2l_pack_teacher_kernel(const float* __restrict__ params, float* __restrict__ out) {
     const TOff off = t_offsets();
@@ -135,21 +142,49 @@ struct TeacherArgs {
     int S;
 };
 
-// k-steps of the xyz embedding for this lane's half-wave
-__device__ __forceinline__ void t_xyz_feats(const float (&p)[3], int h, float (&f)[T_PE_STEPS]) {
+#ifndef T_RING
+#define T_RING 1  // depth of the weight ring (1 or 2; same-box A/B: 2 is 0.6 % slower here); slot of group i = i & (T_RING - 1)
+#endif
+typedef WRingT<T_RING> TRing;
+#define T_SLOT(i) ((i) & (T_RING - 1))
+
+// the 4 B-operand values of embedding group g (k-steps 4g .. 4g+3) for this lane's half-wave: two sincos per group
+template <int g>
+__device__ __forceinline__ f32x4 t_xyz_group(const float (&p)[3], int h) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float base = h ? 32.0f : 1.0f;
 #pragma unroll
-    for (int fl = 0; fl < 5; ++fl)
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) r2l_sincos(p[ax] * (base * (float)(1 << fl)), f[fl * 6 + ax], f[fl * 6 + 3 + ax]);
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) f[30 + ax] = h ? 0.f : p[ax];
-    f[33] = f[34] = f[35] = 0.f;
+    for (int j = 0; j < 4; j += 2) {
+        constexpr int s0 = 4 * g;
+        const int s = s0 + j;
+        if (s < 30) {
+            const int q = s >> 1, fl = q / 3, ax = q % 3;
+            float sn, cs;
+            r2l_sincos(p[ax] * (base * (float)(1 << fl)), sn, cs);
+            v[j] = sn;
+            v[j + 1] = cs;
+        } else if (s < 33) {
+            v[j] = h ? 0.f : p[s - 30];
+            if (s + 1 < 33) v[j + 1] = h ? 0.f : p[s + 1 - 30];
+        }
+    }
+    return v;
 }
 
-__device__ __forceinline__ void t_pe_gemm(f32x16 (&acc)[R2L_NT], const float (&f)[T_PE_STEPS], WStream& ws) {
-#pragma unroll
-    for (int g = 0; g < T_PE_GROUPS; ++g) mfma_group(acc, ws, f[4 * g + 0], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+// NG groups of embedding k-steps, the first one in ring slot T_SLOT(BASE).  Software pipeline: the values of group g+1
+// are evaluated (VALU) under the MFMAs of group g.
+template <int BASE, int g, int NG>
+__device__ __forceinline__ void t_pe_steps(f32x16 (&acc)[R2L_NT], const float (&p)[3], int h, TRing& ws, f32x4 cur) {
+    if constexpr (g < NG) {
+        f32x4 nxt = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (g + 1 < NG && g + 1 < T_PE_GROUPS) nxt = t_xyz_group<g + 1>(p, h);
+        mfma_group<T_SLOT(BASE + g), 0, 0, 12>(acc, ws, cur[0], cur[1], cur[2], cur[3]);
+        t_pe_steps<BASE, g + 1, NG>(acc, p, h, ws, nxt);
+    }
+}
+template <int BASE, int NG>
+__device__ __forceinline__ void t_pe_gemm(f32x16 (&acc)[R2L_NT], const float (&p)[3], int h, TRing& ws) {
+    t_pe_steps<BASE, 0, NG>(acc, p, h, ws, t_xyz_group<0>(p, h));
 }
 
 __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherArgs a) {
@@ -171,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
             vd[k] = a.viewdirs[ray * 3 + k];
         }
     }
-    WStream ws;
+    TRing ws;
     ws.init(a.wstream, lane);
     const float* P = a.params;
 
@@ -179,23 +214,24 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
     const float one_h0 = h ? 0.f : 1.f;  // B operand of the bias k-steps
     // layer 0 (x holds PRE-activations from here on: every consumer applies the ReLU to its B operands on the fly)
     {
-        float f[T_PE_STEPS];
-        t_xyz_feats(p, h, f);
-        mfma_bias_group<true>(x, ws, one_h0);
-        t_pe_gemm(x, f, ws);
+        mfma_bias_group<true, 0>(x, ws, one_h0);
+        t_pe_gemm<1, T_PE_GROUPS>(x, p, h, ws);  // 1 + 9 groups: the loop below starts at an even group index
     }
     // (L1,L2) (L3,L4) (L5,L6) (L7,feature): t = W_odd relu(x) [+ W5pe pe] + b ; x = W_even relu(t) + b
     float alpha = 0.f;
     NoHook nh;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        mfma_bias_group<true>(t, ws, one_h0);
-        if (k == 2) {
-            float f[T_PE_STEPS];
-            t_xyz_feats(p, h, f);
-            t_pe_gemm(t, f, ws);
+        mfma_bias_group<true, 0>(t, ws, one_h0);
+        if (k == 2) {  // 10 groups (the last one all zero): slot parity unchanged
+            // opaque copy: hipcc would otherwise hoist the (loop-invariant) sin/cos values out of the layer loop and
+            // keep 33 of them in scratch across it; their reloads then queue behind the weight prefetches (in-order vmcnt)
+            float pp[3] = {p[0], p[1], p[2]};
+            int hh = h;  // (the per-half frequency scales too)
+            asm volatile("" : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(hh));
+            t_pe_gemm<1, T_PE5_GROUPS>(t, pp, hh, ws);
         }
-        gemm256x<true>(t, x, ws, nh);
+        gemm256x<true, T_SLOT(1)>(t, x, ws, nh);
         if (k == 3) {  // alpha_linear on relu(layer 7)
             float acc = 0.f;
 #pragma unroll
@@ -209,8 +245,8 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
             acc += __shfl_xor(acc, 32);
             alpha = acc + P[off.alpha_b];
         }
-        mfma_bias_group<true>(x, ws, one_h0);
-        gemm256x<true>(x, t, ws, nh);  // k == 3: x = feature_linear(relu(layer 7)), consumed WITHOUT a ReLU below
+        mfma_bias_group<true, T_SLOT(1)>(x, ws, one_h0);
+        gemm256x<true, 0>(x, t, ws, nh);  // k == 3: x = feature_linear(relu(layer 7)), consumed WITHOUT a ReLU below
     }
     // views layer: v[128] = Wv [feature, dir-embedding] + bv   (4 output tiles; ReLU applied by the rgb head)
     f32x16 v[4];
@@ -232,7 +268,8 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
                              x[Ga >> 2][(Ga & 3) * 4 + 3]};
         const float bb[4] = {x[Gb >> 2][(Gb & 3) * 4 + 0], x[Gb >> 2][(Gb & 3) * 4 + 1], x[Gb >> 2][(Gb & 3) * 4 + 2],
                              x[Gb >> 2][(Gb & 3) * 4 + 3]};
-        mfma_group4x2(v, ws, ba, bb);
+        if (G2 & 1) mfma_group4x2<0>(v, ws, ba, bb);  // the views bias group sat in slot 0
+        else mfma_group4x2<T_SLOT(1)>(v, ws, ba, bb);
     }
     {
         float fd[T_DIR_STEPS];
@@ -249,7 +286,8 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
         for (int G2 = 0; G2 < 2; ++G2) {
             const float ba[4] = {fd[8 * G2 + 0], fd[8 * G2 + 1], fd[8 * G2 + 2], fd[8 * G2 + 3]};
             const float bb[4] = {fd[8 * G2 + 4], fd[8 * G2 + 5], fd[8 * G2 + 6], fd[8 * G2 + 7]};
-            mfma_group4x2(v, ws, ba, bb);
+            if (G2 & 1) mfma_group4x2<0>(v, ws, ba, bb);
+            else mfma_group4x2<T_SLOT(1)>(v, ws, ba, bb);
         }
     }
     // rgb = Wrgb relu(v) + b
