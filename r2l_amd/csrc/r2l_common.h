@@ -166,6 +166,14 @@ struct NoHook {
 #ifndef R2L_HOOK_BUFFER
 #define R2L_HOOK_BUFFER 0  // ride-along stores / mask loads: 64-bit pointers (0) or buffer descriptors (1); same-box A/B: 0 is 0.3 % faster
 #endif
+// Stash / gradient stores.  Non-temporal stores (`global_store ... nt`) are acknowledged sooner, which matters because
+// stores retire through the same in-order vmcnt queue as the weight prefetches — but only for stores that cover whole
+// cache lines: the 32- / 64-byte fragment pieces of the chain kernels rely on L2 to merge partial lines (same-box A/B
+// with nt on those: 98 304-ray step 25.2 -> 34 ms).  Whole-row stores (r2l_coop16.hip): 462 -> 446 us with nt.
+__device__ __forceinline__ void r2l_stash_store(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void r2l_stash_store_nt(float* p, const f32x4& v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
 template <bool RELU = false, class Act = IdentityAct>
 struct StoreHookT {
     static constexpr int RD = 0, WR = 1;
@@ -197,7 +205,7 @@ struct StoreHookT {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc,
                                                voff + (unsigned)(32 * T + 8 * (G & 3)) * 4u, 0, 0);
 #else
-        *reinterpret_cast<f32x4*>(row + 32 * T + 8 * (G & 3)) = v;
+        r2l_stash_store(row + 32 * T + 8 * (G & 3), v);
 #endif
     }
 };
@@ -273,7 +281,7 @@ __device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t row
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {a[T][4 * q + 0], a[T][4 * q + 1], a[T][4 * q + 2], a[T][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(r + 32 * T + 8 * q) = v;
+            r2l_stash_store(r + 32 * T + 8 * q, v);
         }
 }
 

@@ -113,6 +113,16 @@ __device__ __forceinline__ void lds_write_slice(float* act, int lane, int wave, 
         }
 }
 // slice <-> row-major [N][256] global tensors (stash / gradients)
+// Whole rows of the tile from the LDS activation buffer to a row-major [N][256] tensor: wave w moves rays 8w .. 8w+7, one
+// 1 KiB row per instruction (full cache lines -> non-temporal stores pay off, r2l_common.h: r2l_stash_store_nt).
+__device__ __forceinline__ void rows_lds_to_global(const float* act, float* base, int64_t tile_row0, int lane, int wave) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int ray = 8 * wave + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(act + ray * COOP_LD + 4 * lane);
+        r2l_stash_store_nt(base + (tile_row0 + ray) * R2L_W + 4 * lane, v);
+    }
+}
 __device__ __forceinline__ void g_store_slice(float* base, int64_t ray, int lane, int wave, const f32x16 (&v)[2]) {
     float* row = base + ray * R2L_W + 64 * wave + 4 * (lane >> 5);
 #pragma unroll
@@ -120,7 +130,7 @@ __device__ __forceinline__ void g_store_slice(float* base, int64_t ray, int lane
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 o = {v[t][4 * q + 0], v[t][4 * q + 1], v[t][4 * q + 2], v[t][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = o;
+            r2l_stash_store(row + 32 * t + 8 * q, o);
         }
 }
 __device__ __forceinline__ void g_load_slice(const float* base, int64_t ray, int lane, int wave, f32x16 (&v)[2]) {
@@ -174,7 +184,8 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_coop_kernel(const CoopFwdArgs 
     __shared__ float tailred[4][32][4];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
-    const int64_t ray = (int64_t)blockIdx.x * R2L_TILE_RAYS + (lane & 31);
+    const int64_t tile_row0 = (int64_t)blockIdx.x * R2L_TILE_RAYS;
+    const int64_t ray = tile_row0 + (lane & 31);
     const bool valid = ray < a.N;
     const int64_t rc = valid ? ray : a.N - 1;
     const int64_t Np = R2L_PAD_ROWS(a.N);
@@ -261,7 +272,6 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_coop_kernel(const CoopFwdArgs 
             x0[t][c] = xo[t][c];
         }
     lds_write_slice(act[0], lane, wave, xo);
-    if constexpr (SAVE) g_store_slice(a.save_x, ray, lane, wave, xo);
     // widen the ring to 8 groups: r2 holds body-layer-0 groups 0 and 1 (slots 0, 1)
     CRing<8> r8;
     r8.p = r2.p;
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_coop_kernel(const CoopFwdArgs 
         // t = relu(W1 x + b1): B operands = x from act[0]
         __syncthreads();
         lds_read_bops(act[0], lane, bop);
+        if constexpr (SAVE) rows_lds_to_global(act[0], a.save_x + (int64_t)b * Np * R2L_W, tile_row0, lane, wave);  // x_b
         slice_bias<false>(acc, bias, lane, wave);
         clayer<true>(acc, bop, r8);
 #pragma unroll
@@ -289,15 +300,18 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_coop_kernel(const CoopFwdArgs 
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[t][c] = fmaxf(acc[t][c], 0.f);
         lds_write_slice(act[1], lane, wave, acc);
-        if constexpr (SAVE) g_store_slice(a.save_t + (int64_t)b * Np * R2L_W, ray, lane, wave, acc);
         // x += W2 t + b2: B operands = t from act[1]
         __syncthreads();
         lds_read_bops(act[1], lane, bop);
+        if constexpr (SAVE) rows_lds_to_global(act[1], a.save_t + (int64_t)b * Np * R2L_W, tile_row0, lane, wave);  // t_b
         slice_bias<true>(xo, bias + (R2L_W * R2L_W + R2L_W), lane, wave);
         clayer<true>(xo, bop, r8);
         lds_write_slice(act[0], lane, wave, xo);
-        if constexpr (SAVE) g_store_slice(a.save_x + (int64_t)(b + 1) * Np * R2L_W, ray, lane, wave, xo);
         bias += 2 * (R2L_W * R2L_W + R2L_W);
+    }
+    if constexpr (SAVE) {  // x_n (the loop stored x_0 .. x_{n-1} at the top of each trip)
+        __syncthreads();
+        rows_lds_to_global(act[0], a.save_x + (int64_t)a.n_block * Np * R2L_W, tile_row0, lane, wave);
     }
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt), partial dot products per wave, reduced through LDS ----------------------
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_coop_kernel(const CoopBwdArgs 
             }
     }
     lds_write_slice(act[0], lane, wave, g);
-    g_store_slice(a.gx + (int64_t)a.n_block * Np * R2L_W, ray, lane, wave, g);
+    const int64_t tile_row0 = tile * R2L_TILE_RAYS;
 
     f32x16 bop[R2L_NT];
 #pragma unroll 1
@@ -425,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_coop_kernel(const CoopBwdArgs 
         // u = (W2^T g) * [t_b > 0]
         __syncthreads();
         lds_read_bops(act[0], lane, bop);
+        rows_lds_to_global(act[0], a.gx + (int64_t)(b + 1) * Np * R2L_W, tile_row0, lane, wave);  // g = dL/dx_{b+1}
         f32x16 tm[2];
         g_load_slice(a.save_t + (int64_t)b * Np * R2L_W, ray, lane, wave, tm);
 #pragma unroll
@@ -437,13 +452,12 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_coop_kernel(const CoopBwdArgs 
 #pragma unroll
             for (int c = 0; c < 16; ++c) u[t][c] = tm[t][c] > 0.f ? u[t][c] : 0.f;
         lds_write_slice(act[1], lane, wave, u);
-        g_store_slice(a.gt + (int64_t)b * Np * R2L_W, ray, lane, wave, u);
         // g += W1^T u
         __syncthreads();
         lds_read_bops(act[1], lane, bop);
+        rows_lds_to_global(act[1], a.gt + (int64_t)b * Np * R2L_W, tile_row0, lane, wave);  // u_b
         clayer<false>(g, bop, r8);
         lds_write_slice(act[0], lane, wave, g);
-        if (b > 0) g_store_slice(a.gx + (int64_t)b * Np * R2L_W, ray, lane, wave, g);
     }
     // head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0)
     f32x16 xm[2];

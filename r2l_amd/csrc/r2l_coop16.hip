@@ -126,12 +126,22 @@ __device__ __forceinline__ void lds_write_slice16(float* act, int lane, int wave
 __device__ __forceinline__ void g_store_slice16(float* base, int64_t ray, int lane, int wave, const f32x4 (&v)[4]) {
     float* row = base + ray * R2L_W + 64 * wave + 4 * (lane >> 4);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(row + 16 * t) = v[t];
+    for (int t = 0; t < 4; ++t) r2l_stash_store(row + 16 * t, v[t]);
 }
 __device__ __forceinline__ void g_load_slice16(const float* base, int64_t ray, int lane, int wave, f32x4 (&v)[4]) {
     const float* row = base + ray * R2L_W + 64 * wave + 4 * (lane >> 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4*>(row + 16 * t);
+}
+// Whole rows of the tile from the LDS activation buffer to a row-major [N][256] tensor: wave w moves rays 4w .. 4w+3,
+// one 1 KiB row per instruction (64 lanes x 16 B: full cache lines, unlike the 64-byte pieces of a fragment store).
+__device__ __forceinline__ void rows_lds_to_global(const float* act, float* base, int64_t tile_row0, int lane, int wave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ray = 4 * wave + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(act + ray * C16_LD + 4 * lane);
+        r2l_stash_store_nt(base + (tile_row0 + ray) * R2L_W + 4 * lane, v);
+    }
 }
 __device__ __forceinline__ float sel4(int kk, float a0, float a1, float a2, float a3) {
     const float lo = kk == 1 ? a1 : a0, hi = kk == 3 ? a3 : a2;
@@ -185,7 +195,8 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_c16_kernel(const C16FwdArgs a)
     __shared__ float zl[4][C16_RAYS][20];  // per-wave copy of the sample depths (indexed by the runtime sample number)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kk = lane >> 4;
-    const int64_t ray = (int64_t)blockIdx.x * C16_RAYS + j;  // < r2l_padded_rows(N): padding rows are computed too
+    const int64_t tile_row0 = (int64_t)blockIdx.x * C16_RAYS;
+    const int64_t ray = tile_row0 + j;  // < r2l_padded_rows(N): padding rows are computed too
     const bool valid = ray < a.N;
     const int64_t rc = valid ? ray : a.N - 1;
     const int64_t Np = R2L_PAD_ROWS(a.N);
@@ -291,7 +302,6 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_c16_kernel(const C16FwdArgs a)
             x0[t][c] = xo[t][c];
         }
     lds_write_slice16(act[0], lane, wave, xo);
-    if constexpr (SAVE) g_store_slice16(a.save_x, ray, lane, wave, xo);
     // widen the ring to 8: r5 holds stream groups 63..67 (= body layer 0, groups 0..4) in slots 3, 4, 0, 1, 2
     Ring16<8> r8;
     r8.rsrc = r5.rsrc;
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_c16_kernel(const C16FwdArgs a)
         // t = relu(W1 x + b1): B operands = x from act[0]
         __syncthreads();
         lds_read_bops16(act[0], lane, bop);
+        if constexpr (SAVE) rows_lds_to_global(act[0], a.save_x + (int64_t)b * Np * R2L_W, tile_row0, lane, wave);  // x_b
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = bn[t];
         layer16(acc, bop, r8, bias + C16_BIAS_STRIDE, bn);
@@ -330,17 +341,20 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_c16_kernel(const C16FwdArgs a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[t][c] = fmaxf(acc[t][c], 0.f);
         lds_write_slice16(act[1], lane, wave, acc);
-        if constexpr (SAVE) g_store_slice16(a.save_t + (int64_t)b * Np * R2L_W, ray, lane, wave, acc);
         // x += W2 t + b2: B operands = t from act[1]
         __syncthreads();
         lds_read_bops16(act[1], lane, bop);
+        if constexpr (SAVE) rows_lds_to_global(act[1], a.save_t + (int64_t)b * Np * R2L_W, tile_row0, lane, wave);  // t_b
 #pragma unroll
         for (int t = 0; t < 4; ++t) xo[t] += bn[t];
         // prefetch b1 of the next block (behind the last block: re-read the current one, never used)
         layer16(xo, bop, r8, b + 1 < a.n_block ? bias + 2 * C16_BIAS_STRIDE : bias, bn);
         lds_write_slice16(act[0], lane, wave, xo);
-        if constexpr (SAVE) g_store_slice16(a.save_x + (int64_t)(b + 1) * Np * R2L_W, ray, lane, wave, xo);
         bias += 2 * C16_BIAS_STRIDE;
+    }
+    if constexpr (SAVE) {  // x_n (the loop stored x_0 .. x_{n-1} at the top of each trip)
+        __syncthreads();
+        rows_lds_to_global(act[0], a.save_x + (int64_t)a.n_block * Np * R2L_W, tile_row0, lane, wave);
     }
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt): partial dots per lane, reduced over kk (shuffles) and waves (LDS) -------
@@ -478,14 +492,15 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_c16_kernel(const C16BwdArgs a)
         }
     }
     lds_write_slice16(act[0], lane, wave, g);
-    g_store_slice16(a.gx + (int64_t)a.n_block * Np * R2L_W, ray, lane, wave, g);
 
     f32x4 bop[16];
+    const int64_t tile_row0 = tile * C16_RAYS;
 #pragma unroll 1
     for (int b = a.n_block - 1; b >= 0; --b) {
         // u = (W2^T g) * [t_b > 0]
         __syncthreads();
         lds_read_bops16(act[0], lane, bop);
+        rows_lds_to_global(act[0], a.gx + (int64_t)(b + 1) * Np * R2L_W, tile_row0, lane, wave);  // g = dL/dx_{b+1}
         f32x4 tm[4];
         g_load_slice16(a.save_t + (int64_t)b * Np * R2L_W, ray, lane, wave, tm);
 #pragma unroll
@@ -496,13 +511,12 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_c16_kernel(const C16BwdArgs a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) u[t][c] = tm[t][c] > 0.f ? u[t][c] : 0.f;
         lds_write_slice16(act[1], lane, wave, u);
-        g_store_slice16(a.gt + (int64_t)b * Np * R2L_W, ray, lane, wave, u);
         // g += W1^T u
         __syncthreads();
         lds_read_bops16(act[1], lane, bop);
+        rows_lds_to_global(act[1], a.gt + (int64_t)b * Np * R2L_W, tile_row0, lane, wave);  // u_b
         layer16_plain(g, bop, r8);
         lds_write_slice16(act[0], lane, wave, g);
-        if (b > 0) g_store_slice16(a.gx + (int64_t)b * Np * R2L_W, ray, lane, wave, g);
     }
     // head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0)
     f32x4 xm[4];

@@ -11,7 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
     tr = R2LTrainer(m, ps)
     out = {}
-    for n in (2048, 4096, 8192, 16384, 24576, 40000):
+    for n in (2048, 4096, 8192, 12288, 16384, 24576, 40000):
         o = torch.randn(n, 3, device="cuda"); d = torch.randn(n, 3, device="cuda"); t = torch.rand(n, 3, device="cuda")
         with torch.no_grad():
             for _ in range(2): m.forward_rays(o, d, ps)
@@ -26,12 +26,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     res = {}
-    for v in ("main", "coop"):
+    for v in ("main", "coop", "coop16"):
         env = dict(os.environ, R2L_FORCE_VARIANT=v)
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         res[v] = json.loads(r.stdout.strip().splitlines()[-1])
-    print("%8s | %10s %10s | %10s %10s" % ("rays", "fwd main", "fwd coop", "step main", "step coop"))
+    print("%8s | %10s %10s %10s | %10s %10s %10s" % ("rays", "fwd main", "fwd coop", "fwd c16", "step main", "step coop",
+                                                       "step c16"))
     for n in res["main"]:
-        print("%8s | %8.3f ms %8.3f ms | %8.3f ms %8.3f ms   step speed-up %.2fx  (%.2f M rays/s)" % (
-            n, res["main"][n][0], res["coop"][n][0], res["main"][n][1], res["coop"][n][1],
-            res["main"][n][1] / res["coop"][n][1], int(n) / res["coop"][n][1] / 1e3))
+        print("%8s | %8.3f ms %8.3f ms %8.3f ms | %8.3f ms %8.3f ms %8.3f ms" % (
+            n, res["main"][n][0], res["coop"][n][0], res["coop16"][n][0], res["main"][n][1], res["coop"][n][1],
+            res["coop16"][n][1]))
