@@ -30,6 +30,8 @@ SIGNATURES = {
     "r2l_dw_slab_floats": (_l, []),
     "r2l_backward": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
+    "r2l_adam_hyper": (_i, [_p, _f, _f, _f, _i, _p]),
+    "r2l_adam_step_dev": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _p]),
     "r2l_loss_finish": (_i, [_p, _l, _f, _p, _p]),
     "r2l_teacher_param_count": (_l, []),
     "r2l_teacher_stream_floats": (_l, []),

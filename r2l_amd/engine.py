@@ -105,6 +105,11 @@ class R2LEngine:
         """Call after writing the parameters behind autograd's back (fused Adam through the C ABI)."""
         self._dirty += 1
 
+    def pack_now(self):
+        """Unconditional re-pack (used inside captured graphs, where the host-side version check does not replay)."""
+        _lib.check(self.lib.r2l_pack_forward(_ptr(self.flat), self.n_block, _ptr(self.wstream), _stream()),
+                   "r2l_pack_forward")
+
     def ensure_packed(self):
         if not self._aliased():
             self.flatten(self.params[0].device)
