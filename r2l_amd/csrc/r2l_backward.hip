@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
 // (which remain as the dw_slab == NULL path).  The gradient buffer is zeroed by the caller (accumulation for free).
 // =================================================================================================================
 #define DW_CHUNK 64  // rays per work unit
+#ifndef DW_DEPTH
+#define DW_DEPTH 4  // rotating operand buffers = k-steps of load latency covered (must divide 32)
+#endif
 #ifndef DW_LONG_TRIP
 #define DW_LONG_TRIP 128  // k-steps per trip of the main loop
 #endif
@@ -364,33 +367,33 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
             // 4 rotating operand buffers, each reloaded right after the k-step that consumed it: every load is issued
             // three k-steps (3072 MFMA cycles) before its use, with no register copies.  The loop body is a whole
             // 64-ray chunk (32 k-steps) because hipcc drains vmcnt to 0 at every loop header.
-            f32x4 gb[4], ab[4];
+            f32x4 gb[DW_DEPTH], ab[DW_DEPTH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ld(k, gb[k], ab[k]);
+            for (int k = 0; k < DW_DEPTH; ++k) ld(k, gb[k], ab[k]);
             int64_t s = 0;
             // hipcc drains vmcnt to 0 at every loop header, which exposes the full HBM latency of the newest load (~2 us):
             // long trips amortise it (one drain per 2048 / 1024 / 512 MFMAs)
             for (; s + DW_LONG_TRIP <= nfull; s += DW_LONG_TRIP) {
 #pragma unroll
                 for (int k = 0; k < DW_LONG_TRIP; ++k) {
-                    kstep(gb[k & 3], ab[k & 3]);
-                    ld(s + k + 4, gb[k & 3], ab[k & 3]);
+                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
+                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             for (; s + 64 <= nfull; s += 64) {
 #pragma unroll
                 for (int k = 0; k < 64; ++k) {
-                    kstep(gb[k & 3], ab[k & 3]);
-                    ld(s + k + 4, gb[k & 3], ab[k & 3]);
+                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
+                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             for (; s + 32 <= nfull; s += 32) {
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
-                    kstep(gb[k & 3], ab[k & 3]);
-                    ld(s + k + 4, gb[k & 3], ab[k & 3]);
+                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
+                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
