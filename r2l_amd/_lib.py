@@ -22,6 +22,9 @@ SIGNATURES = {
     "r2l_bwd_stream_floats": (_l, [_i]),
     "r2l_pack_forward": (_i, [_p, _i, _p, _p]),
     "r2l_pack_backward": (_i, [_p, _i, _p, _p]),
+    "r2l_variant_for": (_i, [_l]),
+    "r2l_pack_forward_layout": (_i, [_p, _i, _p, _i, _p]),
+    "r2l_pack_backward_layout": (_i, [_p, _i, _p, _i, _p]),
     "r2l_forward_rays": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _p]),
     "r2l_forward_pose": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
     "r2l_forward_emb": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p]),

@@ -70,20 +70,24 @@ class R2LTrainer:
         if getattr(self, "dw_slab", None) is None and not os.environ.get("R2L_NO_DW_SLAB"):  # env: A/B diagnostics only
             self.dw_slab = torch.empty(int(self.lib.r2l_dw_slab_floats()), **f)
 
-    def _pack_bwd(self):
-        key = self.eng._packed_version
-        if self._bwd_packed != key:
-            _lib.check(self.lib.r2l_pack_backward(_ptr(self.eng.flat), self.eng.n_block, _ptr(self.wstream_bwd),
-                                                  _stream()), "r2l_pack_backward")
-            self._bwd_packed = key
+    def _pack_bwd(self, n):
+        """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
+        eng = self.eng
+        ver, layout = eng.version(), eng.layout_for(n)
+        if self._bwd_packed is None:
+            self._bwd_packed = {16: None, 32: None}
+        if self._bwd_packed[layout] != ver:
+            _lib.check(self.lib.r2l_pack_backward_layout(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), layout,
+                                                         _stream()), "r2l_pack_backward_layout")
+            self._bwd_packed[layout] = ver
 
     # ---- one optimisation step --------------------------------------------------------------------------------------
     def forward_backward(self, rays_o, rays_d, target, perturb=0., t_rand=None, zero_grad=True):
         """Forward + backward on this rank's rays; leaves d(loss)/d(params) in self.grads. Returns rgb [N,3]."""
         eng = self.eng
-        eng.ensure_packed()
-        self._pack_bwd()
         n = rays_o.shape[0]
+        eng.ensure_packed(n)
+        self._pack_bwd(n)
         self._ensure_capacity(n)
         rays_o = rays_o.contiguous().float()
         rays_d = rays_d.contiguous().float()
@@ -192,8 +196,7 @@ class R2LTrainer:
             eng.pack_now()
             _lib.check(self.lib.r2l_pack_backward(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), _stream()),
                        "r2l_pack_backward")
-            eng._packed_version = sum(p._version for p in eng.params) + eng._dirty  # no re-pack inside forward_rays
-            self._bwd_packed = eng._packed_version
+            self._bwd_packed = {16: eng.version(), 32: eng.version()}  # (pack_now marked the forward stream current)
             gs["rgb"] = self.forward_backward(gs["o"], gs["d"], gs["t"], perturb)
             _lib.check(
                 self.lib.r2l_adam_step_dev(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
