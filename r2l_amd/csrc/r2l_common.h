@@ -12,7 +12,7 @@
 // B[k = l>>5][j = l&31]: register (T,c) supplies k-pair {f_lo, f_lo+4}), so activations never leave
 // the register file: no LDS round trip, no transposes, no barriers.  The weights are re-packed on the
 // device (r2l_pack.hip) into the exact per-lane A-operand order, as ONE contiguous stream in
-// consumption order, so every wave streams them with fully coalesced 1 KiB global_load_dwordx4.
+// consumption order, so every wave streams them with fully coalesced 1 KiB (16 B per lane) buffer loads.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -51,9 +51,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // along in training would otherwise stall the weight loads queued behind them.  The ring slot of every group is a
 // compile-time constant (SLOT), which is why loops over groups are arranged to have even trip lengths.
 // ---------------------------------------------------------------------------------------------
-// The stream pointer is kept as a wave-uniform base (SGPR pair) + a constant per-lane byte offset (one VGPR), so the
-// loads select the `global_load_dwordx4 v, v_off, s[base]` form: no 64-bit VALU address arithmetic, half the address
-// VGPR traffic per VMEM issue.
+// The stream is read through a BUFFER DESCRIPTOR (4 SGPRs) + one constant per-lane byte offset (VGPR) + a wave-uniform
+// scalar offset: `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen offset:imm`.  Measured on gfx950: the 64-bit
+// VGPR-address form (`global_load_dwordx4 v, v[addr:addr+1], off`) costs ~16 cycles of MFMA issue per load, this
+// form none — the largest single lever of round 1.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct WPtr {
     __amdgpu_buffer_rsrc_t rsrc;  // buffer descriptor of the whole stream (4 SGPRs, wave-uniform by construction)
