@@ -193,3 +193,17 @@ def test_convert_images_to_ray_shards(tmp_path):
     assert {tuple(np.round(r, 4)) for r in rows[:, :3]} == centres
     files = data.list_ray_shards(savedir, pseudo_ratio=-1)
     assert len(files) == 2  # 'train_*' files count as original data in BlenderDataset_v2's selection rule
+
+
+def test_all_blender_scene_configs_parse():
+    """configs/: teacher and student files for the 8 NeRF-synthetic scenes at 400x400 and 800x800 (tools/gen_configs.py)."""
+    from r2l_amd.options import parse_args
+    scenes = ["chair", "drums", "ficus", "hotdog", "lego", "materials", "mic", "ship"]
+    for scene in scenes:
+        for student in (False, True):
+            for full in (False, True):
+                name = scene + ("_noview" if student else "") + ("_800x800" if full else "") + ".txt"
+                a = parse_args(["--config", os.path.join(ROOT, "configs", name)])
+                assert a.datadir.endswith("nerf_synthetic/" + scene) and a.dataset_type == "blender"
+                assert a.half_res == (not full) and a.use_viewdirs == (not student) and a.white_bkgd
+                assert (a.N_samples, a.N_importance, a.lrate_decay) == (64, 128, 500)
