@@ -108,3 +108,25 @@ def test_teacher_frame_properties():
     assert full["raw"].shape == (H * W, 192, 4)
     assert (full["depth_map"] >= 0).all() and (full["depth_map"] <= 6.0 * (acc + 1e-3)).all()
     assert (full["z_std"] >= 0).all()
+
+
+def test_render_800x800_frame_vs_oracle(net):
+    """The `_800x800` configs (half_res off): one 640 000-ray frame, pose mode; 4096 sampled pixels against the oracle's
+    sample_test + encode + forward, and against the explicit-ray entry point on the same pixels."""
+    from model.nerf_raybased import PointSampler
+    sd, m = net
+    H = W = 800
+    focal = 1111.1110311937682  # 0.5 * 800 / tan(0.5 * 0.6911112070083618): lego camera_angle_x
+    ps = PointSampler(H, W, focal, 16, 2., 6.)
+    c2w = torch.from_numpy(O.pose_spherical(63., -30., 4.)[:3, :4])
+    with torch.no_grad():
+        rgb = m.render_pose(c2w, ps).cpu()
+    assert rgb.shape == (H * W, 3) and torch.isfinite(rgb).all()
+    rows = torch.randperm(H * W, generator=torch.Generator().manual_seed(1))[:4096]
+    pts = O.sample_test(O.pixel_dirs(H, W, focal), O.z_vals(16, 2., 6.), c2w)[rows]
+    ref = O.r2l_forward(sd, O.positional_embed(pts, 10))
+    assert (rgb[rows] - ref).abs().max().item() < 1e-4
+    ro, rd = O.rays_from_pose(O.pixel_dirs(H, W, focal), c2w)
+    with torch.no_grad():
+        rgb_rays = m.forward_rays(ro.reshape(-1, 3)[rows].cuda(), rd.reshape(-1, 3)[rows].cuda(), ps, perturb=0.).cpu()
+    assert (rgb_rays - rgb[rows]).abs().max().item() < 2e-6
