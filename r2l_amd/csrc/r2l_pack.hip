@@ -120,9 +120,10 @@ extern "C" int64_t r2l_param_count(int n_block) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)2 * n_block * (R2L_W * R2L_W + R2L_W) + 3 * R2L_W + 3;
 }
 
-// a stream buffer = [32-ray-tile layout | 16-ray-tile layout]; every chain kernel finds its part by offset
+// a stream buffer = [32-ray-tile layout | 16-ray-tile layout | bf16x3 stages (forward only)]; every kernel finds its part
+// by offset
 extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
-    return r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
+    return r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) + r2l_fwd3_stream_floats(n_block);
 }
 
 extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
@@ -132,6 +133,14 @@ extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
 // launches use (r2l_variant_for) can skip the other half of the stream: 10 us each, 3 % of a 4096-ray step.
 extern "C" int r2l_variant_for(int64_t N) { return r2l_chain_variant(N); }
+// stream layout a forward launch with N rays reads: 16 / 32 (chain variants, also every training launch) or 3 (the
+// bf16x3 forward-only kernel, r2l_fwd3.hip)
+extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
+    const int v = r2l_chain_variant(N);
+    if (v == R2L_VARIANT_COOP16) return 16;
+    if (v == R2L_VARIANT_MAIN && !with_stash && r2l_use_fwd3()) return 3;
+    return 32;
+}
 extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream) {
     if (layout == 0 || layout == 32) {
         hipLaunchKernelGGL(r2l_pack_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
@@ -141,6 +150,11 @@ extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* 
         hipLaunchKernelGGL(r2l_pack_fwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
                            wstream + r2l_fwd32_stream_floats(n_block), n_block);
         R2L_CHECK(hipGetLastError());
+    }
+    if (layout == 0 || layout == 3) {
+        const int rc = r2l_fwd3_pack(params, n_block, wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block),
+                                     (hipStream_t)stream);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -163,7 +177,8 @@ extern "C" int r2l_pack_forward(const float* params, int n_block, float* wstream
     hipLaunchKernelGGL(r2l_pack_fwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
                        wstream + r2l_fwd32_stream_floats(n_block), n_block);
     R2L_CHECK(hipGetLastError());
-    return 0;
+    return r2l_fwd3_pack(params, n_block, wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block),
+                         (hipStream_t)stream);
 }
 
 extern "C" int r2l_pack_backward(const float* params, int n_block, float* wstream, void* stream) {

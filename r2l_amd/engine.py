@@ -109,26 +109,27 @@ class R2LEngine:
         """Changes whenever the parameters may have changed (autograd version counters + mark_dirty)."""
         return sum(p._version for p in self.params) + self._dirty
 
-    def layout_for(self, n):
-        """Which half of the packed streams a launch with n rays reads: 16 (16-ray cooperative kernels) or 32."""
-        return 16 if self.lib.r2l_variant_for(int(n)) == 2 else 32
+    def layout_for(self, n, with_stash=True):
+        """Which part of the packed forward stream a launch with n rays reads: 16 (16-ray cooperative kernels), 32
+        (one-wave-per-tile / 32-ray cooperative kernels, every training launch) or 3 (the bf16x3 forward-only kernel)."""
+        return self.lib.r2l_forward_layout_for(int(n), 1 if with_stash else 0)
 
     def pack_now(self):
         """Unconditional re-pack of both layouts (used inside captured graphs, where the host-side version check does
         not replay)."""
         _lib.check(self.lib.r2l_pack_forward(_ptr(self.flat), self.n_block, _ptr(self.wstream), _stream()),
                    "r2l_pack_forward")
-        self._packed_version = {16: self.version(), 32: self.version()}
+        self._packed_version = {16: self.version(), 32: self.version(), 3: self.version()}
 
-    def ensure_packed(self, n=None):
+    def ensure_packed(self, n=None, with_stash=True):
         """Re-pack the weight stream if the parameters changed since it was packed.  With n given only the layout that a
-        launch with n rays reads (the other half stays stale until someone asks for it)."""
+        launch with n rays reads (the other parts stay stale until someone asks for them)."""
         if not self._aliased():
             self.flatten(self.params[0].device)
         ver = self.version()
         if self._packed_version is None:
-            self._packed_version = {16: None, 32: None}
-        for layout in ((16, 32) if n is None else (self.layout_for(n),)):
+            self._packed_version = {16: None, 32: None, 3: None}
+        for layout in ((16, 32, 3) if n is None else (self.layout_for(n, with_stash),)):
             if self._packed_version[layout] != ver:
                 _lib.check(self.lib.r2l_pack_forward_layout(_ptr(self.flat), self.n_block, _ptr(self.wstream), layout,
                                                             _stream()), "r2l_pack_forward_layout")
@@ -160,7 +161,7 @@ class R2LEngine:
         rays_o = rays_o.contiguous().float()
         rays_d = rays_d.contiguous().float()
         n = rays_o.shape[0]
-        self.ensure_packed(n)
+        self.ensure_packed(n, with_stash=save is not None)
         if perturb > 0 and t_rand is None:
             t_rand = torch.rand(n, N_SAMPLE, device=self.device)
         if perturb <= 0:
@@ -177,7 +178,7 @@ class R2LEngine:
 
     def forward_pose(self, c2w, H, Wimg, focal, z_vals):
         """rgb[H*W,3] for the frame seen from c2w[3,4] (PointSampler.sample_test fused in front of the chain)."""
-        self.ensure_packed(int(H) * int(Wimg))
+        self.ensure_packed(int(H) * int(Wimg), with_stash=False)
         c = torch.as_tensor(c2w, dtype=torch.float32).detach().cpu()[:3, :4].contiguous()
         host = (ctypes.c_float * 12)(*c.reshape(-1).tolist())
         rgb = torch.empty(H * Wimg, 3, dtype=torch.float32, device=self.device)
