@@ -22,7 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 #define F3_STAGE_BYTES 24576  // 3 splits x 8 tiles x 64 lanes x 16 B
-#define F3_NBUF 4
+#define F3_NBUF 6
 
 __host__ __device__ static inline int64_t f3_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
 __host__ __device__ static inline int64_t f3_off_body_w(int layer) {
@@ -126,7 +126,7 @@ struct F3Args {
 
 // one LDS-DMA load: 64 lanes x 16 B from (rsrc, voff + soff) to LDS at lds_addr + 16*lane.  Inline asm on purpose: the
 // compiler's waitcnt insertion treats the builtin form conservatively (vmcnt(0) before every LDS read), which would
-// collapse the three-stage prefetch; the waits are placed by hand (F3_STAGE_BEGIN).
+// collapse the multi-stage prefetch; the waits are placed by hand (F3Pipe::sync_next).
 __device__ __forceinline__ void f3_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
@@ -134,68 +134,188 @@ __device__ __forceinline__ void f3_dma16(u32x4 rsrc, unsigned voff, unsigned sof
                  : "memory");
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 struct F3Split {
     bf16x8 h, m, l;
 };
-// v = h + m + l exactly (three bf16 values per fp32 value), round-to-nearest-even at each step
-__device__ __forceinline__ F3Split f3_split8(const float (&v)[8]) {
-    F3Split r;
-    f32x8 x;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = v[k];
-    r.h = __builtin_convertvector(x, bf16x8);
-    const f32x8 r1 = x - __builtin_convertvector(r.h, f32x8);
-    r.m = __builtin_convertvector(r1, bf16x8);
-    const f32x8 r2 = r1 - __builtin_convertvector(r.m, f32x8);
-    r.l = __builtin_convertvector(r2, bf16x8);
-    return r;
-}
+struct F3A4 {  // A operands (bf16 triples) of four output tiles
+    bf16x8 h[4], m[4], l[4];
+};
 
-// acc[8 tiles] += W_block . b   for one k-block (16 features): per output tile six bf16 MFMAs, small terms first.
-// lb: this lane's base inside the stage buffer (buffer + 16*lane); A operand of (split sp, tile T) at lb + (8 sp + T) KiB.
-__device__ __forceinline__ void f3_kblock(f32x16 (&acc)[R2L_NT], const float (&bv)[8], const unsigned char* lb) {
-    const F3Split b = f3_split8(bv);
+// The work that rides along the 24 MFMAs of one half stage, cut into six steps (one per group of four MFMAs):
+//   * the twelve LDS reads of the A operands needed NEXT (two per step),
+//   * four B values of the next stage and their split into bf16 (hi, mid, lo): gather, cvt, sub, cvt, sub, cvt.
+// hipcc would issue all of it as one burst in front of the MFMAs (with one wave per SIMD nothing else feeds the matrix
+// pipe meanwhile) and its sched_group_barrier solver does not terminate on this kernel, so the interleave is written out
+// and fenced with sched_barrier(0).
+template <bool BIAS_A, class Gather>
+struct F3Side {
+    F3A4& a;                  // destination of the A operands
+    const unsigned char* lb;  // lane base of the stage buffer they come from
+    int half;                 // which four tiles
+    Gather gather;            // fills v[4] with the next stage's B values (lo or hi half)
+    bool want_b;
+    f32x4v x, r1;
+    bf16x4 h, m, l;
+    __device__ __forceinline__ void loads(int i) {  // A operand loads 2i, 2i+1 of the twelve (bias stage: of the four)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        bf16x8 ah[4], am[4], al[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int T = 4 * half + t;
-            ah[t] = *reinterpret_cast<const bf16x8*>(lb + (0 * 8 + T) * 1024);
-            am[t] = *reinterpret_cast<const bf16x8*>(lb + (1 * 8 + T) * 1024);
-            al[t] = *reinterpret_cast<const bf16x8*>(lb + (2 * 8 + T) * 1024);
+        for (int k = 2 * i; k < 2 * i + 2; ++k) {
+            if (BIAS_A && k >= 4) continue;
+            const int tt = BIAS_A ? k : k / 3, sp = BIAS_A ? 0 : k % 3;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(lb + (sp * 8 + 4 * half + tt) * 1024);
+            if (sp == 0) a.h[tt] = v;
+            else if (sp == 1) a.m[tt] = v;
+            else a.l[tt] = v;
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], b.h, acc[4 * half + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], b.l, acc[4 * half + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], b.m, acc[4 * half + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], b.h, acc[4 * half + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], b.m, acc[4 * half + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], b.h, acc[4 * half + t], 0, 0, 0);
     }
-}
+    __device__ __forceinline__ void step(int i) {
+        loads(i);
+        if (!want_b) return;
+        if (i == 0) {
+            float v[4];
+            gather(v);
+            x = f32x4v{v[0], v[1], v[2], v[3]};
+        } else if (i == 1) {
+            h = __builtin_convertvector(x, bf16x4);
+        } else if (i == 2) {
+            r1 = x - __builtin_convertvector(h, f32x4v);
+        } else if (i == 3) {
+            m = __builtin_convertvector(r1, bf16x4);
+        } else if (i == 4) {
+            r1 = r1 - __builtin_convertvector(m, f32x4v);
+        } else {
+            l = __builtin_convertvector(r1, bf16x4);
+        }
+    }
+};
 
-// acc (=|+=) bias: one MFMA per tile (hi, mid, lo of the bias in k slots 0..2 of half 0 against ones)
-template <bool ZERO_INIT>
-__device__ __forceinline__ void f3_bias(f32x16 (&acc)[R2L_NT], const unsigned char* lb, const bf16x8& ones_h0) {
+// acc[4 tiles of `half`] (+)= W . b: six bf16 MFMAs per tile, small terms first, term-major so that an accumulator is
+// touched every fourth MFMA; after every group of four MFMAs one step of `side`.  BIAS stage: one MFMA per tile (hi,
+// mid, lo of the bias in k slots 0..2 against ones), then all the side work.
+template <bool BIAS, bool ZERO_INIT, class Side>
+__device__ __forceinline__ void f3_mfma_half(f32x16 (&acc)[R2L_NT], int half, const F3A4& a, const F3Split& b, Side& side) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (BIAS) {
 #pragma unroll
-    for (int T = 0; T < R2L_NT; ++T) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lb + T * 1024);
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones_h0, ZERO_INIT ? zero : acc[T], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+            acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[t], b.h, ZERO_INIT ? zero : acc[4 * half + t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) side.step(i);
+        return;
+    }
+#define F3_GROUP(AA, BB, I)                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[4 * half + t] =                                                   \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[t], BB, acc[4 * half + t], 0, 0, 0);                                  \
+    side.step(I);                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+    F3_GROUP(a.l, b.h, 0)
+    F3_GROUP(a.h, b.l, 1)
+    F3_GROUP(a.m, b.m, 2)
+    F3_GROUP(a.m, b.h, 3)
+    F3_GROUP(a.h, b.m, 4)
+    F3_GROUP(a.h, b.h, 5)
+#undef F3_GROUP
+}
+
+// state of the weight-staging pipeline (everything wave-uniform except lane-derived offsets)
+struct F3Pipe {
+    u32x4 rs;            // buffer descriptor of the stage stream
+    unsigned lds0;       // LDS address of buffer 0
+    unsigned voff, wq;   // lane * 16 ; this wave's quarter of a stage
+    const unsigned char* base;  // generic pointer to buffer 0
+    int lane;
+    int gb;              // buffer of the stage being consumed
+    int gq, gqb;         // next stage to request and its buffer
+    const unsigned char* lb;    // this lane's base in the current stage's buffer
+    F3A4 a1, a2;         // A operands: first / second half of the current stage
+    F3Split sb;          // B triple of the current stage
+    F3Split ones;
+    __device__ __forceinline__ void issue() {
+        const unsigned so = (unsigned)gq * F3_STAGE_BYTES + wq;
+        const unsigned la = lds0 + (unsigned)gqb * F3_STAGE_BYTES + wq;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) f3_dma16(rs, voff, so + i * 1024u, la + i * 1024u);
+        ++gq;
+        gqb = (gqb == F3_NBUF - 1) ? 0 : gqb + 1;
+    }
+    // publish the next stage (k+1), refill the buffer everybody has left, advance the buffer cursor.  vmcnt retires in
+    // order: `vmcnt(18)` (at most 18 outstanding) covers the own loads of stage k+1, which have the 18 loads of stages
+    // k+2..k+4 behind them; loads the compiler knows about only make its own waits stricter.
+    __device__ __forceinline__ void sync_next() {
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        __syncthreads();
+        issue();
+        gb = (gb == F3_NBUF - 1) ? 0 : gb + 1;
+        lb = base + gb * F3_STAGE_BYTES + lane * 16;
+    }
+};
+
+// One stage: acc (+)= stage k.  Entry: P.a1 = A(tiles 0-3) and P.sb = B triple of stage k.  glo / ghi fill the B values
+// 0-3 / 4-7 of stage k+1; BIAS_NEXT: stage k+1 is a bias stage (only the `hi` A operands exist, B = ones).
+// The barrier that publishes stage k+1 sits in the MIDDLE of stage k: behind it the first-half A operands of stage k+1
+// are read from LDS while the second half of stage k still feeds the matrix pipe.
+template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
+__device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], F3Pipe& P, GLo glo, GHi ghi) {
+    F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT};
+    f3_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    P.sync_next();
+    F3Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT};
+    f3_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (BIAS_NEXT) {
+        P.sb = P.ones;
+    } else {
+        P.sb.h = __builtin_shufflevector(sa.h, sb2.h, 0, 1, 2, 3, 4, 5, 6, 7);
+        P.sb.m = __builtin_shufflevector(sa.m, sb2.m, 0, 1, 2, 3, 4, 5, 6, 7);
+        P.sb.l = __builtin_shufflevector(sa.l, sb2.l, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
-// (sin, cos) of x * 2^f for four consecutive frequencies f0 .. f0+3 -> 8 B values in stream order
-__device__ __forceinline__ void f3_trig4(float x, int f0, float (&out)[8]) {
+// gatherers of four B values
+template <bool RELU>
+struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile
+    const f32x16& frag;
+    int c0;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r2l_sincos(x * (float)(1 << (f0 + k)), out[2 * k], out[2 * k + 1]);
-}
+        for (int s = 0; s < 4; ++s) v[s] = RELU ? fmaxf(frag[c0 + s], 0.f) : frag[c0 + s];
+    }
+};
+struct F3Trig2 {  // (sin, cos) of x * 2^f0 and x * 2^(f0+1)
+    float x;
+    int f0;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        r2l_sincos(x * (float)(1 << f0), v[0], v[1]);
+        r2l_sincos(x * (float)(1 << (f0 + 1)), v[2], v[3]);
+    }
+};
+struct F3Ident4 {  // identity features: coordinates e0 .. e0+3 of this half-wave (point = o + d * z)
+    const float (&o)[3];
+    const float (&d)[3];
+    const float (&z)[8];
+    int e0;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = o[(e0 + s) % 3] + d[(e0 + s) % 3] * z[(e0 + s) / 3];
+    }
+};
+struct F3TrigOrIdent {  // last stage of a head trip: first block of the next trip, or the first identity block
+    bool ident;
+    F3Trig2 tr;
+    F3Ident4 id;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        float w[4];
+        tr(v);
+        id(w);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = ident ? w[s] : v[s];
+    }
+};
+struct F3None {
+    __device__ __forceinline__ void operator()(float (&v)[4]) const { v[0] = v[1] = v[2] = v[3] = 0.f; }
+};
 
 template <bool POSE>
 __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
@@ -208,33 +328,6 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     const int64_t ray = tile * R2L_TILE_RAYS + (lane & 31);
     const bool valid = ray < a.N;
     const int64_t rc = valid ? ray : a.N - 1;
-
-    // ---- weight staging ----------------------------------------------------------------------------------------------
-    const unsigned long long sa = (unsigned long long)a.stream;
-    const u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu,
-                      0x00020000u};
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&wbuf[0][0];
-    const unsigned voff = (unsigned)lane * 16u;
-    const unsigned wq = (unsigned)wave * 6144u;  // this wave stages a quarter of every stage
-    auto issue = [&](int gq) {
-        const unsigned so = (unsigned)gq * F3_STAGE_BYTES + wq;
-        const unsigned la = lds0 + (unsigned)(gq & (F3_NBUF - 1)) * F3_STAGE_BYTES + wq;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) f3_dma16(rs, voff, so + i * 1024u, la + i * 1024u);
-    };
-    int g = 0;  // stage counter (wave-uniform)
-    issue(0);
-    issue(1);
-    issue(2);
-// own stage-g loads have landed (12 = the loads of stages g+1, g+2 may still fly), everybody's have after the barrier;
-// then the buffer read during stage g-1 is refilled with stage g+3
-#define F3_STAGE_BEGIN()                                                                       \
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                          \
-    __syncthreads();                                                                           \
-    issue(g + 3);                                                                              \
-    const unsigned char* lb = &wbuf[0][0] + (g & (F3_NBUF - 1)) * F3_STAGE_BYTES + lane * 16;  \
-    ++g;
 
     // ---- rays -----------------------------------------------------------------------------------------------------------
     float o[3], d[3];
@@ -269,77 +362,86 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
             for (int k = 0; k < 4; ++k) { z[k] = lo0[k] + sp0[k] * u0[k]; z[4 + k] = lo1[k] + sp1[k] * u1[k]; }
         }
     }
-    // vmcnt bookkeeping: counters retire in order, so `vmcnt(12)` at a stage start (at most 12 operations outstanding)
-    // always covers the stage's own DMA loads, which have at least the 12 loads of the next two stages behind them; loads
-    // the compiler knows about (rays above, tail weights below) only make its own waits stricter.
 
-    bf16x8 ones_h0;
+    // ---- weight staging: stage g of the stream is DMA'd into LDS buffer g % 6 by the four waves (a quarter each) ----------
+    F3Pipe P;
+    {
+        const unsigned long long sa = (unsigned long long)a.stream;
+        P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        P.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&wbuf[0][0];
+        P.voff = (unsigned)lane * 16u;
+        P.wq = (unsigned)wave * 6144u;
+        P.base = &wbuf[0][0];
+        P.lane = lane;
+        P.gb = 0;
+        P.gq = 0;
+        P.gqb = 0;
+    }
+    P.issue(); P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..4
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ones_h0[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
+    for (int k = 0; k < 8; ++k) P.ones.h[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
+    P.ones.m = P.ones.h;
+    P.ones.l = P.ones.h;
 
     f32x16 x[R2L_NT], t[R2L_NT], x0[R2L_NT];
-    // ---- head ---------------------------------------------------------------------------------------------------------
+    // prologue: stage 0 (head bias) becomes current
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __syncthreads();
+    P.lb = P.base + lane * 16;
     {
-        F3_STAGE_BEGIN()
-        f3_bias<true>(x, lb, ones_h0);
+        F3None none;
+        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s0.step(i);
     }
+    P.sb = P.ones;
+
+    // ---- head ---------------------------------------------------------------------------------------------------------
+    // per coordinate pair (xa, xb) five k-blocks: [xa f0-3] [xa f4-7] [xa f8,9 | xb f0,1] [xb f2-5] [xb f6-9]
     auto zsel = [&](int s) {
         float zz = z[0];
 #pragma unroll
         for (int k = 1; k < 8; ++k) zz = (s == k) ? z[k] : zz;
         return zz;
     };
-#pragma unroll 1
-    for (int it2 = 0; it2 < 4; ++it2) {  // two samples = six coordinates = three pairs = 15 k-blocks per trip
-        const float za = zsel(2 * it2), zb = zsel(2 * it2 + 1);
-        float xc[6];
+    float xc[6];
+    {
+        const float za = z[0], zb = z[1];
 #pragma unroll
         for (int ci = 0; ci < 6; ++ci) xc[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
+    }
+    f3_stage<true, true, false>(x, P, F3Trig2{xc[0], 0}, F3Trig2{xc[0], 2});
+#pragma unroll 1
+    for (int it2 = 0; it2 < 4; ++it2) {  // two samples = six coordinates = three pairs = 15 k-blocks per trip
+        // coordinates of the NEXT trip (the last stage of this trip prepares the first B triple of the next one)
+        float xn[6];
+        {
+            const float za = zsel(2 * it2 + 2), zb = zsel(2 * it2 + 3);
+#pragma unroll
+            for (int ci = 0; ci < 6; ++ci) xn[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const float xa = xc[2 * p], xb = xc[2 * p + 1];
-            float bv[8];
-            {
-                f3_trig4(xa, 0, bv);
-                F3_STAGE_BEGIN()
-                f3_kblock(x, bv, lb);
-            }
-            {
-                f3_trig4(xa, 4, bv);
-                F3_STAGE_BEGIN()
-                f3_kblock(x, bv, lb);
-            }
-            {
-                r2l_sincos(xa * 256.0f, bv[0], bv[1]);
-                r2l_sincos(xa * 512.0f, bv[2], bv[3]);
-                r2l_sincos(xb, bv[4], bv[5]);
-                r2l_sincos(xb * 2.0f, bv[6], bv[7]);
-                F3_STAGE_BEGIN()
-                f3_kblock(x, bv, lb);
-            }
-            {
-                f3_trig4(xb, 2, bv);
-                F3_STAGE_BEGIN()
-                f3_kblock(x, bv, lb);
-            }
-            {
-                f3_trig4(xb, 6, bv);
-                F3_STAGE_BEGIN()
-                f3_kblock(x, bv, lb);
+            f3_stage<false, false, false>(x, P, F3Trig2{xa, 4}, F3Trig2{xa, 6});
+            f3_stage<false, false, false>(x, P, F3Trig2{xa, 8}, F3Trig2{xb, 0});
+            f3_stage<false, false, false>(x, P, F3Trig2{xb, 2}, F3Trig2{xb, 4});
+            f3_stage<false, false, false>(x, P, F3Trig2{xb, 6}, F3Trig2{xb, 8});
+            if (p < 2) {
+                f3_stage<false, false, false>(x, P, F3Trig2{xc[2 * p + 2], 0}, F3Trig2{xc[2 * p + 2], 2});
+            } else {
+                f3_stage<false, false, false>(x, P, F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 0}, F3Ident4{o, d, z, 0}},
+                                              F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 2}, F3Ident4{o, d, z, 4}});
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {  // identity features: coordinates 8j .. 8j+7 of the half
-        float bv[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int e = 8 * j + s;
-            bv[s] = o[e % 3] + d[e % 3] * z[e / 3];
-        }
-        F3_STAGE_BEGIN()
-        f3_kblock(x, bv, lb);
+        for (int ci = 0; ci < 6; ++ci) xc[ci] = xn[ci];
     }
+    // identity features: coordinates 8j .. 8j+7 of the half
+    f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 8}, F3Ident4{o, d, z, 12});
+    f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 16}, F3Ident4{o, d, z, 20});
+    f3_stage<false, false, true>(x, P, F3None{}, F3None{});
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
@@ -351,32 +453,21 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     // ---- body -----------------------------------------------------------------------------------------------------------
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
-        {  // t = W1 x + b1   (its ReLU is applied where t is consumed)
-            F3_STAGE_BEGIN()
-            f3_bias<true>(t, lb, ones_h0);
-        }
+        // t = W1 x + b1   (its ReLU is applied where t is consumed)
+        f3_stage<true, true, false>(t, P, F3Take4<false>{x[0], 0}, F3Take4<false>{x[0], 4});
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            float bv[8];
+        for (int kb = 0; kb < 15; ++kb)
+            f3_stage<false, false, false>(t, P, F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
+                                          F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+        f3_stage<false, false, true>(t, P, F3None{}, F3None{});
+        // x += W2 relu(t) + b2
+        f3_stage<true, false, false>(x, P, F3Take4<true>{t[0], 0}, F3Take4<true>{t[0], 4});
 #pragma unroll
-            for (int s = 0; s < 8; ++s) bv[s] = x[kb >> 1][8 * (kb & 1) + s];
-            F3_STAGE_BEGIN()
-            f3_kblock(t, bv, lb);
-        }
-        {  // x += W2 relu(t) + b2
-            F3_STAGE_BEGIN()
-            f3_bias<false>(x, lb, ones_h0);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            float bv[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) bv[s] = fmaxf(t[kb >> 1][8 * (kb & 1) + s], 0.f);
-            F3_STAGE_BEGIN()
-            f3_kblock(x, bv, lb);
-        }
+        for (int kb = 0; kb < 15; ++kb)
+            f3_stage<false, false, false>(x, P, F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
+                                          F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+        f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
     }
-#undef F3_STAGE_BEGIN
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt) on the VALU -------------------------------------------------------------
     const float* tw = a.params + f3_off_tail_w(a.n_block) + 4 * h;
