@@ -26,6 +26,7 @@ import torch.distributed as dist  # noqa: E402
 FWD_FLOP_PER_RAY = 2 * (1008 * 256 + 86 * 256 * 256 + 256 * 3)  # 11 789 824
 TRAIN_FLOP_PER_RAY = 2 * (3 * 5894912 - 258048)  # 34 853 376: fwd + dX + dW, no dX for the head
 PEAK_FP32_MFMA = 157.3  # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md chip table (exact-fp32 MFMA)
+PEAK_BF16_MFMA = 2500.0  # TFLOP/s dense bf16 MFMA (same guide; the sparsity-inflated headline figure is not used)
 H = W = 400
 FOCAL = 555.5555155968841
 
@@ -226,22 +227,30 @@ def main():
     rays = H * W * a.steps * world
     value = rays / dt
     achieved = H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic("void r2l_fwd_kernel<1, false>")
+    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # default path: fp32-accurate products on the bf16 MFMA
+    traffic, traffic_src = pmc_traffic("void r2l_fwd3_kernel<true>" if fwd3 else "void r2l_fwd_kernel<1, false>")
+    # every fp32 product costs six bf16 MFMA products on that path: its matrix-pipe peak in algorithmic FLOP/s is the
+    # dense bf16 peak / 6; the exact-fp32 MFMA peak is kept beside it for reference
+    peak = PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA
 
     out = {
         "metric": "rays/sec (train+render) W256D88 lego@400x400", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (products as 6 bf16 MFMA terms of exact bf16 hi/mid/lo splits, fp32 accumulate)" if fwd3 else "f32",
+        "data": "synthetic",
         "config": {"workload": "R2L W256D88 render_test 400x400 testskip=1: 1 frame (160000 rays, 16 samples/ray, "
                                "L=10) per GPU per step, fused sample+encode+ResMLP forward; seeded weights, "
                                "pose_spherical poses",
                    "rays_per_step_per_gpu": H * W, "parallelism": "frames sharded across %d rank(s), no collective"
                                                                % world},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "peak_fp32_mfma": PEAK_FP32_MFMA,
+                     "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA, "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
-                                     "bytes per launch = 160000 rays x 12 B out + 24.3 MB weight stream" % traffic_src,
-                     "kernel": "r2l_fwd_kernel<MODE_POSE>", "kernel_ms": kernel_ms,
+                                     "bytes per launch = 160000 rays x 12 B out + the packed weight stream (37.6 MB of "
+                                     "bf16 triples / 24.3 MB fp32)" % traffic_src,
+                     "kernel": "r2l_fwd3_kernel<POSE>" if fwd3 else "r2l_fwd_kernel<MODE_POSE>", "kernel_ms": kernel_ms,
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }
 

@@ -149,6 +149,11 @@ struct F3A4 {  // A operands (bf16 triples) of four output tiles
 // hipcc would issue all of it as one burst in front of the MFMAs (with one wave per SIMD nothing else feeds the matrix
 // pipe meanwhile) and its sched_group_barrier solver does not terminate on this kernel, so the interleave is written out
 // and fenced with sched_barrier(0).
+struct F3Dma {  // one stage request, issued one 1 KiB piece per step (dma.on: this side issues it)
+    bool on;
+    u32x4 rs;
+    unsigned voff, so, la;
+};
 template <bool BIAS_A, class Gather>
 struct F3Side {
     F3A4& a;                  // destination of the A operands
@@ -156,6 +161,7 @@ struct F3Side {
     int half;                 // which four tiles
     Gather gather;            // fills v[4] with the next stage's B values (lo or hi half)
     bool want_b;
+    F3Dma dma;
     f32x4v x, r1;
     bf16x4 h, m, l;
     __device__ __forceinline__ void loads(int i) {  // A operand loads 2i, 2i+1 of the twelve (bias stage: of the four)
@@ -171,6 +177,7 @@ struct F3Side {
     }
     __device__ __forceinline__ void step(int i) {
         loads(i);
+        if (dma.on) f3_dma16(dma.rs, dma.voff, dma.so + i * 1024u, dma.la + i * 1024u);
         if (!want_b) return;
         if (i == 0) {
             float v[4];
@@ -245,9 +252,15 @@ struct F3Pipe {
     __device__ __forceinline__ void sync_next() {
         asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         __syncthreads();
-        issue();
         gb = (gb == F3_NBUF - 1) ? 0 : gb + 1;
         lb = base + gb * F3_STAGE_BYTES + lane * 16;
+    }
+    // the next request as six pieces for the side work of the second half stage (instead of a burst behind the barrier)
+    __device__ __forceinline__ F3Dma request() {
+        F3Dma d{true, rs, voff, (unsigned)gq * F3_STAGE_BYTES + wq, lds0 + (unsigned)gqb * F3_STAGE_BYTES + wq};
+        ++gq;
+        gqb = (gqb == F3_NBUF - 1) ? 0 : gqb + 1;
+        return d;
     }
 };
 
@@ -257,11 +270,11 @@ struct F3Pipe {
 // are read from LDS while the second half of stage k still feeds the matrix pipe.
 template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
 __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], F3Pipe& P, GLo glo, GHi ghi) {
-    F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT};
+    F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}};
     f3_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
     P.sync_next();
-    F3Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT};
+    F3Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request()};
     f3_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     P.lb = P.base + lane * 16;
     {
         F3None none;
-        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false};
+        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}};
 #pragma unroll
         for (int i = 0; i < 6; ++i) s0.step(i);
     }

@@ -10,11 +10,17 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
-    """Every test runs twice: one-wave-per-tile kernels and the cooperative small-batch kernels (r2l_coop.hip)."""
-    monkeypatch.setenv("R2L_FORCE_VARIANT", request.param)
-    return request.param
+    """Every test runs under each forward kernel family: one wave per tile on the bf16x3 matrix path (r2l_fwd3.hip) and
+    on the fp32 MFMA (r2l_forward.hip, R2L_NO_FWD3=1), and the two cooperative small-batch families."""
+    name = request.param
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
+    if name == "main-f32mfma":
+        monkeypatch.setenv("R2L_NO_FWD3", "1")
+    else:
+        monkeypatch.delenv("R2L_NO_FWD3", raising=False)
+    return name
 T = torch.from_numpy
 TOL = 1e-4  # north_star: RGB within 1e-4 abs of the reference PyTorch path
 
