@@ -162,8 +162,16 @@ struct F3Side {
     Gather gather;            // fills v[4] with the next stage's B values (lo or hi half)
     bool want_b;
     F3Dma dma;
-    f32x4v x, r1;
-    bf16x4 h, m, l;
+    float x[4], r1[4];
+    unsigned uh[2], um[2], ul[2];  // packed bf16 pairs: values (0,1) and (2,3)
+    // two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32), and back (shift / mask)
+    static __device__ __forceinline__ unsigned pk(float a0, float a1) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+    }
+    static __device__ __forceinline__ float lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+    static __device__ __forceinline__ float hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
     __device__ __forceinline__ void loads(int i) {  // A operand loads 2i, 2i+1 of the twelve (bias stage: of the four)
 #pragma unroll
         for (int k = 2 * i; k < 2 * i + 2; ++k) {
@@ -180,19 +188,22 @@ struct F3Side {
         if (dma.on) f3_dma16(dma.rs, dma.voff, dma.so + i * 1024u, dma.la + i * 1024u);
         if (!want_b) return;
         if (i == 0) {
-            float v[4];
-            gather(v);
-            x = f32x4v{v[0], v[1], v[2], v[3]};
+            gather(x);
         } else if (i == 1) {
-            h = __builtin_convertvector(x, bf16x4);
+            uh[0] = pk(x[0], x[1]);
+            uh[1] = pk(x[2], x[3]);
         } else if (i == 2) {
-            r1 = x - __builtin_convertvector(h, f32x4v);
+            r1[0] = x[0] - lo(uh[0]); r1[1] = x[1] - hi(uh[0]);
+            r1[2] = x[2] - lo(uh[1]); r1[3] = x[3] - hi(uh[1]);
         } else if (i == 3) {
-            m = __builtin_convertvector(r1, bf16x4);
+            um[0] = pk(r1[0], r1[1]);
+            um[1] = pk(r1[2], r1[3]);
         } else if (i == 4) {
-            r1 = r1 - __builtin_convertvector(m, f32x4v);
+            r1[0] -= lo(um[0]); r1[1] -= hi(um[0]);
+            r1[2] -= lo(um[1]); r1[3] -= hi(um[1]);
         } else {
-            l = __builtin_convertvector(r1, bf16x4);
+            ul[0] = pk(r1[0], r1[1]);
+            ul[1] = pk(r1[2], r1[3]);
         }
     }
 };
@@ -280,9 +291,9 @@ __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], F3Pipe& P, GLo g
     if (BIAS_NEXT) {
         P.sb = P.ones;
     } else {
-        P.sb.h = __builtin_shufflevector(sa.h, sb2.h, 0, 1, 2, 3, 4, 5, 6, 7);
-        P.sb.m = __builtin_shufflevector(sa.m, sb2.m, 0, 1, 2, 3, 4, 5, 6, 7);
-        P.sb.l = __builtin_shufflevector(sa.l, sb2.l, 0, 1, 2, 3, 4, 5, 6, 7);
+        P.sb.h = __builtin_bit_cast(bf16x8, u32x4{sa.uh[0], sa.uh[1], sb2.uh[0], sb2.uh[1]});
+        P.sb.m = __builtin_bit_cast(bf16x8, u32x4{sa.um[0], sa.um[1], sb2.um[0], sb2.um[1]});
+        P.sb.l = __builtin_bit_cast(bf16x8, u32x4{sa.ul[0], sa.ul[1], sb2.ul[0], sb2.ul[1]});
     }
 }
 
