@@ -352,7 +352,8 @@ __host__ __device__ static inline int64_t r2l_fwd3_stages(int n_block) { return 
 __host__ __device__ static inline int64_t r2l_fwd3_stream_floats(int n_block) {
     return (r2l_fwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
 }
-// forward-only launches big enough for the one-wave-per-tile kernels take the bf16x3 kernel (R2L_NO_FWD3=1: fp32 MFMA)
+// forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
+// kernel (R2L_NO_FWD3=1: fp32 MFMA)
 static inline bool r2l_use_fwd3() {
     const char* e = getenv("R2L_NO_FWD3");
     return !(e && e[0] && e[0] != '0');
@@ -360,7 +361,7 @@ static inline bool r2l_use_fwd3() {
 int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,
-                     int n_block, float* rgb, int64_t N, hipStream_t stream);
+                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
 
 // Which chain variant is fastest for N rays.  In units of one main-kernel round (1024 wave slots x 32 rays): main needs
 // ceil(N/32768) rounds; coop (4 waves share a 32-ray tile, 256 workgroups) ceil(N/8192) rounds of ~0.34 (measured: fwd

@@ -265,10 +265,10 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
     if (variant == R2L_VARIANT_COOP)
         return r2l_coop_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream, params, n_block, rgb, save_x,
                                 save_t, N, (hipStream_t)stream);
-    if (N > 0 && save_x == nullptr && r2l_use_fwd3())
+    if (N > 0 && r2l_use_fwd3())
         return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f,
                                 wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block), params,
-                                n_block, rgb, N, (hipStream_t)stream);
+                                n_block, rgb, save_x, save_t, N, (hipStream_t)stream);
     return launch_fwd<MODE_RAYS>(a, (hipStream_t)stream);
 }
 
@@ -290,7 +290,7 @@ extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float foc
     if (a.N > 0 && r2l_use_fwd3())
         return r2l_fwd3_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal,
                                 wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block), params,
-                                n_block, rgb, a.N, (hipStream_t)stream);
+                                n_block, rgb, nullptr, nullptr, a.N, (hipStream_t)stream);
     return launch_fwd<MODE_POSE>(a, (hipStream_t)stream);
 }
 

@@ -121,6 +121,8 @@ struct F3Args {
     const float* params;
     int n_block;
     float* rgb;
+    float* save_x;  // training: [(n_block+1)][Np][256] X_0 .. X_n and [n_block][Np][256] relu(hidden) (r2l_forward.hip), or
+    float* save_t;  //           nullptr
     int64_t N;
 };
 
@@ -260,6 +262,8 @@ struct F3Pipe {
     // publish the next stage (k+1), refill the buffer everybody has left, advance the buffer cursor.  vmcnt retires in
     // order: `vmcnt(18)` (at most 18 outstanding) covers the own loads of stage k+1, which have the 18 loads of stages
     // k+2..k+4 behind them; loads the compiler knows about only make its own waits stricter.
+    // (training: the ride-along stash stores sit between the DMA loads in the queue; `vmcnt(18)` stays sufficient — it then
+    // also waits for a few of the oldest of them — and never becomes too weak, whatever their number)
     __device__ __forceinline__ void sync_next() {
         asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         __syncthreads();
@@ -299,12 +303,16 @@ __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], F3Pipe& P, GLo g
 
 // gatherers of four B values
 template <bool RELU>
-struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile
+struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile (tile T given for the stash address)
     const f32x16& frag;
     int c0;
+    float* stash;  // training: this lane's row in the stash slot of the layer input (+4h), or nullptr; piece (T, c0/4)
+    int T;
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = RELU ? fmaxf(frag[c0 + s], 0.f) : frag[c0 + s];
+        // the B values ARE the layer input (x_b, relu(t_b)): the stash store rides along, one 16-byte piece per half stage
+        if (stash != nullptr) *reinterpret_cast<f32x4*>(stash + 32 * T + 8 * (c0 >> 2)) = f32x4{v[0], v[1], v[2], v[3]};
     }
 };
 struct F3Trig2 {  // (sin, cos) of x * 2^f0 and x * 2^(f0+1)
@@ -341,7 +349,7 @@ struct F3None {
     __device__ __forceinline__ void operator()(float (&v)[4]) const { v[0] = v[1] = v[2] = v[3] = 0.f; }
 };
 
-template <bool POSE>
+template <bool POSE, bool SAVE>
 __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F3_NBUF][F3_STAGE_BYTES];
 
@@ -475,22 +483,42 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
         }
 
     // ---- body -----------------------------------------------------------------------------------------------------------
+    // training (SAVE): the B values of every stage are the layer's input, so the stash (x_b for the first layer of a block,
+    // relu(t_b) for the second) is stored by the gatherers, two 16-byte pieces per stage
+    const int64_t Np = R2L_PAD_ROWS(a.N);
+    // rows of the padding rays of the last tile exist (Np rows per slot); a wave whose whole tile lies past the end only
+    // takes part in the staging and must not store
+    const bool tile_live = tile * R2L_TILE_RAYS < a.N;
+    float* sx = (SAVE && tile_live) ? a.save_x + ray * R2L_W + 4 * h : nullptr;
+    float* st = (SAVE && tile_live) ? a.save_t + ray * R2L_W + 4 * h : nullptr;
+    const int64_t slot = Np * R2L_W;
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
-        f3_stage<true, true, false>(t, P, F3Take4<false>{x[0], 0}, F3Take4<false>{x[0], 4});
+        f3_stage<true, true, false>(t, P, F3Take4<false>{x[0], 0, sx, 0}, F3Take4<false>{x[0], 4, sx, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(t, P, F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                          F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+            f3_stage<false, false, false>(t, P, F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
+                                          F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
         f3_stage<false, false, true>(t, P, F3None{}, F3None{});
         // x += W2 relu(t) + b2
-        f3_stage<true, false, false>(x, P, F3Take4<true>{t[0], 0}, F3Take4<true>{t[0], 4});
+        f3_stage<true, false, false>(x, P, F3Take4<true>{t[0], 0, st, 0}, F3Take4<true>{t[0], 4, st, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                          F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+            f3_stage<false, false, false>(x, P, F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
+                                          F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1});
         f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
+        if (SAVE && tile_live) {
+            sx += slot;
+            st += slot;
+        }
+    }
+    if (SAVE && tile_live) {  // X_n
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(sx + 32 * T + 8 * q) = f32x4{x[T][4 * q], x[T][4 * q + 1], x[T][4 * q + 2], x[T][4 * q + 3]};
     }
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt) on the VALU -------------------------------------------------------------
@@ -533,16 +561,17 @@ int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t
 
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,
-                     int n_block, float* rgb, int64_t N, hipStream_t stream) {
+                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream) {
     F3Args a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.stream = reinterpret_cast<const unsigned char*>(wstream3); a.params = params;
-    a.n_block = n_block; a.rgb = rgb; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
+    a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (c2w_host12) hipLaunchKernelGGL((r2l_fwd3_kernel<true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((r2l_fwd3_kernel<false>), grid, block, 0, stream, a);
+    if (c2w_host12) hipLaunchKernelGGL((r2l_fwd3_kernel<true, false>), grid, block, 0, stream, a);
+    else if (save_x) hipLaunchKernelGGL((r2l_fwd3_kernel<false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((r2l_fwd3_kernel<false, false>), grid, block, 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

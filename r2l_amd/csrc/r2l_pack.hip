@@ -133,12 +133,13 @@ extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
 // launches use (r2l_variant_for) can skip the other half of the stream: 10 us each, 3 % of a 4096-ray step.
 extern "C" int r2l_variant_for(int64_t N) { return r2l_chain_variant(N); }
-// stream layout a forward launch with N rays reads: 16 / 32 (chain variants, also every training launch) or 3 (the
-// bf16x3 forward-only kernel, r2l_fwd3.hip)
+// stream layout a forward launch with N rays reads: 16 / 32 (cooperative variants / fp32-MFMA kernels) or 3 (the bf16x3
+// kernel, r2l_fwd3.hip: every one-wave-per-tile forward, with or without the training stash)
 extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
-    if (v == R2L_VARIANT_MAIN && !with_stash && r2l_use_fwd3()) return 3;
+    (void)with_stash;
+    if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return 3;
     return 32;
 }
 extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream) {

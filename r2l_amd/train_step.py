@@ -73,7 +73,7 @@ class R2LTrainer:
     def _pack_bwd(self, n):
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
-        ver, layout = eng.version(), eng.layout_for(n)
+        ver, layout = eng.version(), (16 if self.lib.r2l_variant_for(int(n)) == 2 else 32)
         if self._bwd_packed is None:
             self._bwd_packed = {16: None, 32: None}
         if self._bwd_packed[layout] != ver:
