@@ -318,12 +318,19 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher_mlp_kernel(const TeacherAr
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int64_t r2l_teacher_param_count(void) { return t_offsets().total; }
-extern "C" int64_t r2l_teacher_stream_floats(void) { return (int64_t)TG_TOTAL * R2L_GROUP_FLOATS + R2L_STREAM_PAD; }
+// r2l_teacher3.hip: the same network on the bf16 matrix pipe (fp32-accurate); its stage stream follows the fp32 one
+int64_t r2l_teacher3_stream_floats(void);
+int r2l_teacher3_pack(const float* tparams, float* wstream3, hipStream_t stream);
+int r2l_teacher3_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
+                     const float* wstream3, const float* tparams, float* raw, int64_t n_pts, int S, hipStream_t stream);
+static inline int64_t t_stream32_floats() { return (int64_t)TG_TOTAL * R2L_GROUP_FLOATS + R2L_STREAM_PAD; }
+
+extern "C" int64_t r2l_teacher_stream_floats(void) { return t_stream32_floats() + r2l_teacher3_stream_floats(); }
 
 extern "C" int r2l_pack_teacher(const float* params, float* wstream, void* stream) {
     hipLaunchKernelGGL(r2l_pack_teacher_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, params, wstream);
     R2L_CHECK(hipGetLastError());
-    return 0;
+    return r2l_teacher3_pack(params, wstream + t_stream32_floats(), (hipStream_t)stream);
 }
 
 extern "C" int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
@@ -332,6 +339,9 @@ extern "C" int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const f
     a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.z = z; a.wstream = wstream; a.params = params;
     a.raw = raw; a.n_pts = R * (int64_t)S; a.S = S;
     if (a.n_pts <= 0) return 0;
+    if (r2l_use_fwd3())  // default: fp32-accurate products on the bf16 matrix pipe (R2L_NO_FWD3=1: fp32 MFMA)
+        return r2l_teacher3_mlp(rays_o, rays_d, viewdirs, z, wstream + t_stream32_floats(), params, raw, a.n_pts, S,
+                                (hipStream_t)stream);
     const int64_t tiles = (a.n_pts + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     hipLaunchKernelGGL(r2l_teacher_mlp_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     R2L_CHECK(hipGetLastError());
