@@ -174,10 +174,14 @@ def teacher_leg(device, world, rank, distributed, frames=2):
     dt, step_ms = timed(step, frames, 1, distributed, device)
     flop_per_ray = 2 * 593408 * 256  # 303.82 MFLOP/ray
     achieved = H * W * flop_per_ray / (step_ms * 1e-3) / 1e12
+    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # point network on the bf16 matrix pipe (6 products per fp32 one)
+    peak = PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA
     return {"value": H * W * frames * world / dt, "unit": "rays/s", "ms_per_frame": dt / frames * 1e3,
             "workload": "NeRF teacher render 400x400, 64+128 samples/ray, perturb=1, chunk 32768 (create_data rand)",
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA, "flop_per_ray": flop_per_ray}}
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_fp32_mfma": PEAK_FP32_MFMA, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
+                         "kernel": "r2l_teacher3_kernel" if fwd3 else "r2l_teacher_mlp_kernel",
+                         "flop_per_ray": flop_per_ray}}
 
 
 def main():

@@ -741,6 +741,12 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         const int rc = r2l_coop_backward(rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block, grad_scale, dpre,
                                          gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;
+    } else if (r2l_use_fwd3() && !getenv("R2L_NO_BWD3")) {
+        // one-wave-per-tile dX chain on the bf16 matrix pipe (fp32-accurate products): r2l_bwd3.hip
+        const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t,
+                                         wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
+                                         params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
+        if (rc) return rc;
     } else {
         R2LBwdArgs a{};
         a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t; a.wstream = wstream_bwd;

@@ -1,0 +1,301 @@
+// r2l_bwd3.hip — the dX chain of the R2L student backward at fp32 accuracy on the bf16 matrix pipe (same scheme as
+// r2l_fwd3.hip, machinery in r2l_f3.h): one wave = 32 rays, per block  u = (W2^T g) * [t_b > 0],  g += W1^T u,  writing
+// g (-> gx[b+1]) and the masked u (-> gt[b]) for the weight-gradient GEMMs.
+//   * stage stream: per block (last block first) [zero stage, 16 k-blocks of W2^T, zero stage, 16 k-blocks of W1^T].  The
+//     all-zero "bias" stages cost 8 MFMAs each and buy what the bias stages give the forward: u is zero-initialised by the
+//     matrix pipe, and the B values of a GEMM's first k-block are gathered AFTER the previous GEMM has finished;
+//   * the B values of every stage are exactly what has to be stashed (g, masked u): the stores ride along the gathers;
+//   * the ReLU mask of the block is read from the forward stash save_t[b] without any register load: one 1 KiB tile piece
+//     per half stage is DMA'd into a per-wave LDS ring during the first GEMM, folded into 128 mask bits per lane eight half
+//     stages later (by then the staging pipeline's own `vmcnt` waits have guaranteed its arrival), and applied when u is
+//     gathered as the B operand of the second GEMM;
+//   * dy (the outer-residual branch) waits in scratch for the head.
+#include "r2l_f3.h"
+
+#define B3_NBUF 5
+#define B3_RING 8  // mask pieces in flight per wave
+
+__host__ __device__ static inline int64_t b3_off_body_w(int layer) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
+}
+__host__ __device__ static inline int64_t b3_off_tail_w(int n_block) { return b3_off_body_w(2 * n_block); }
+
+// =================================================================================================================
+// pack: stage g = 34 * slot + r, slot = n_block-1-b;  r = 0 / 17: zero stages;  r = 1..16: k-block r-1 of W2^T (layer 2b+1);
+// r = 18..33: k-block r-18 of W1^T (layer 2b).  Element (split, tile t, lane (i,h), slot s): (W^T)[32t+i][feature(kb,h,s)]
+// =================================================================================================================
+__global__ void r2l_pack_bwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
+    const int64_t stages = r2l_bwd3_stages(n_block);
+    const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
+        const int64_t g = idx >> 12;
+        const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
+        unsigned short* st = out + g * (F3_STAGE_BYTES / 2);
+        unsigned short v0 = 0, v1 = 0, v2 = 0;
+        if (g < stages) {
+            const int slot = (int)(g / 34), r = (int)(g % 34), b = n_block - 1 - slot;
+            if (r != 0 && r != 17) {
+                const int layer = r < 17 ? 2 * b + 1 : 2 * b, kb = r < 17 ? r - 1 : r - 18;
+                const int T = kb >> 1, rr = kb & 1;
+                const int in = 32 * T + 8 * (2 * rr + (s >> 2)) + 4 * h + (s & 3);
+                const float w = params[b3_off_body_w(layer) + (int64_t)in * R2L_W + o];  // (W^T)[o][in] = W[in][o]
+                v0 = f3_bf16_rne(w);
+                const float r1 = w - f3_bf16_to_f(v0);
+                v1 = f3_bf16_rne(r1);
+                v2 = f3_bf16_rne(r1 - f3_bf16_to_f(v1));
+            }
+        }
+        const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
+        st[e] = v0;
+        st[8 * 64 * 8 + e] = v1;
+        st[2 * 8 * 64 * 8 + e] = v2;
+    }
+}
+
+// =================================================================================================================
+// kernel
+// =================================================================================================================
+struct B3Args {
+    const float* rgb;
+    const float* target;
+    const float* drgb;
+    const float* save_x;
+    const float* save_t;
+    const unsigned char* stream;
+    const float* params;
+    int n_block;
+    float grad_scale;
+    float* dpre;
+    float* gx;
+    float* gt;
+    float* sqerr_partial;
+    int64_t N;
+};
+
+// mask piece pi = 4T + q of the block (fragment registers 4q .. 4q+3 of tile T) -> bits (T&1)*16 + 4q .. +3 of word T>>1
+__device__ __forceinline__ void b3_fold(unsigned (&mb)[4], const unsigned char* ring_lane, int pi) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(ring_lane + (pi % B3_RING) * 1024);
+    const unsigned bits = (p[0] > 0.f ? 1u : 0u) | (p[1] > 0.f ? 2u : 0u) | (p[2] > 0.f ? 4u : 0u) | (p[3] > 0.f ? 8u : 0u);
+    const int T = pi >> 2, q = pi & 3;
+    mb[T >> 1] |= bits << ((T & 1) * 16 + 4 * q);
+}
+// gatherers: four B values of the next stage (+ their stash store, + the mask piece that is due in this half stage)
+struct B3TakeG {  // g values (identity), stored to gx[b+1]
+    const f32x16& frag;
+    int c0;
+    float* stash;  // lane row (+4h) in the gx slot
+    int T;
+    unsigned (&mb)[4];
+    const unsigned char* ring_lane;
+    int fold_pi;  // mask piece to fold here, or -1
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        if (fold_pi >= 0) b3_fold(mb, ring_lane, fold_pi);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = frag[c0 + s];
+        *reinterpret_cast<f32x4*>(stash + 32 * T + 8 * (c0 >> 2)) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+struct B3TakeU {  // u values masked by relu'(t_b), stored to gt[b]
+    const f32x16& frag;
+    int c0;
+    float* stash;
+    int T;
+    unsigned (&mb)[4];
+    const unsigned char* ring_lane;
+    int fold_pi;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        if (fold_pi >= 0) b3_fold(mb, ring_lane, fold_pi);
+        const unsigned w = mb[T >> 1] >> ((T & 1) * 16 + c0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = ((w >> s) & 1u) ? frag[c0 + s] : 0.f;
+        *reinterpret_cast<f32x4*>(stash + 32 * T + 8 * (c0 >> 2)) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+
+__global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[B3_NBUF][F3_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
+
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // a wave whose tile lies past the end recomputes the last live tile (identical values to identical addresses): nothing in
+    // the chain is conditional
+    const int64_t n_tiles = (a.N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile > n_tiles - 1) tile = n_tiles - 1;
+    const int64_t ray = tile * R2L_TILE_RAYS + (lane & 31);
+    const bool valid = ray < a.N;
+    const int64_t rc = valid ? ray : a.N - 1;
+    const int64_t Np = R2L_PAD_ROWS(a.N);
+    const int64_t rowc = ray;
+
+    // ---- loss gradient through the sigmoid, per-tile squared error (as r2l_bwd_chain_kernel) ---------------------------
+    float dp[3], se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float r = a.rgb[rc * 3 + c];
+        float dl;
+        if (a.target != nullptr) {
+            const float e = r - a.target[rc * 3 + c];
+            se += e * e;
+            dl = a.grad_scale * e;
+        } else {
+            dl = a.drgb[rc * 3 + c];
+        }
+        dp[c] = valid ? dl * (r * (1.0f - r)) : 0.f;
+    }
+    if (!valid) se = 0.f;
+    if (valid && h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.dpre[ray * 3 + c] = dp[c];
+    }
+    if (a.sqerr_partial != nullptr) {
+        float s = (h == 0) ? se : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) a.sqerr_partial[tile] = s;
+    }
+    // g = dy = Wt^T dpre   (tail Linear(256,3))
+    f32x16 g[R2L_NT], u[R2L_NT], dy[R2L_NT];
+    {
+        const float* tw = a.params + b3_off_tail_w(a.n_block);
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 wv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = wv[0][j] * dp[0];
+                    v = __builtin_fmaf(wv[1][j], dp[1], v);
+                    v = __builtin_fmaf(wv[2][j], dp[2], v);
+                    g[T][4 * q + j] = v;
+                    dy[T][4 * q + j] = v;
+                }
+            }
+    }
+
+    // ---- weight staging (5 buffers: 32 KiB of LDS go to the mask ring) --------------------------------------------------------
+    typedef F3PipeT<B3_NBUF> Pipe;
+    Pipe P;
+    {
+        const unsigned long long sa = (unsigned long long)a.stream;
+        P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        P.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&wbuf[0][0];
+        P.voff = (unsigned)lane * 16u;
+        P.wq = (unsigned)wave * 6144u;
+        P.base = &wbuf[0][0];
+        P.lane = lane;
+        P.gb = 0;
+        P.gq = 0;
+        P.gqb = 0;
+    }
+    P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..3
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P.ones.h[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
+    P.ones.m = P.ones.h;
+    P.ones.l = P.ones.h;
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    __syncthreads();
+    P.lb = P.base + lane * 16;
+    {
+        F3None none;
+        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s0.step(i);
+    }
+    P.sb = P.ones;
+
+    // mask ring of this wave: LDS address for the DMA, generic pointer (+16*lane) for the reads
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&mring[0][0][0] +
+                              (unsigned)wave * (B3_RING * 1024u);
+    const unsigned char* ring_lane = &mring[0][0][0] + wave * (B3_RING * 1024) + lane * 16;
+    const unsigned mvoff = (unsigned)(rowc * (R2L_W * 4) + 16 * h);  // byte offset of this lane's row (+4h floats) in a slot
+    const int64_t slot = Np * R2L_W;
+
+#pragma unroll 1
+    for (int b = a.n_block - 1; b >= 0; --b) {
+        unsigned mb[4] = {0u, 0u, 0u, 0u};
+        // descriptor of save_t[b] (per block: 32-bit offsets inside the slot)
+        const unsigned long long ta = (unsigned long long)(a.save_t + (int64_t)b * slot);
+        const u32x4 trs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ta >> 32)) & 0xffffu, 0xffffffffu,
+                           0x00020000u};
+        float* gxs = a.gx + (int64_t)(b + 1) * slot + ray * R2L_W + 4 * h;
+        float* gts = a.gt + (int64_t)b * slot + ray * R2L_W + 4 * h;
+        // half stage rho of the block (0..67): DMA of mask piece issue_pi(rho), fold of piece fold_pi(rho)
+        //   issue: piece pi at rho = pi (pi < 24) or pi + 2 (the half stages 24, 25 are skipped: see fold);
+        //   fold:  eight half stages after the issue -> rho = pi + 8 (pi < 24), pi + 10 (pi >= 24): never in the half stages
+        //          32, 33 (stage 16 gathers nothing: its successor is a zero stage);  first use of piece pi: rho = 34 + pi
+#define B3_ISSUE(RHO) ((RHO) < 24 ? (RHO) : (((RHO) >= 26 && (RHO) < 34) ? (RHO) - 2 : -1))
+#define B3_FOLD(RHO) (((RHO) >= 8 && (RHO) < 32) ? (RHO) - 8 : (((RHO) >= 34 && (RHO) < 42) ? (RHO) - 10 : -1))
+#define B3_EXTRA(RHO)                                                                                                   \
+    F3Dma{B3_ISSUE(RHO) >= 0, trs, mvoff, (unsigned)(32 * (B3_ISSUE(RHO) >> 2) + 8 * (B3_ISSUE(RHO) & 3)) * 4u,         \
+          ring_lds + (unsigned)((B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) % B3_RING) * 1024u}
+        // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
+        f3_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0, mb, ring_lane, B3_FOLD(0)},
+                                    B3TakeG{g[0], 4, gxs, 0, mb, ring_lane, B3_FOLD(1)}, B3_EXTRA(0), B3_EXTRA(1));
+#pragma unroll
+        for (int kb = 0; kb < 15; ++kb)
+            f3_stage<false, false, false>(
+                u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 2)},
+                B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 3)},
+                B3_EXTRA(2 * kb + 2), B3_EXTRA(2 * kb + 3));
+        f3_stage<false, false, true>(u, P, F3None{}, F3None{}, B3_EXTRA(32), B3_EXTRA(33));
+        // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
+        f3_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb, ring_lane, B3_FOLD(34)},
+                                     B3TakeU{u[0], 4, gts, 0, mb, ring_lane, B3_FOLD(35)});
+#pragma unroll
+        for (int kb = 0; kb < 15; ++kb)
+            f3_stage<false, false, false>(
+                g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(36 + 2 * kb)},
+                B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(37 + 2 * kb)});
+        f3_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
+#undef B3_EXTRA
+#undef B3_FOLD
+#undef B3_ISSUE
+    }
+
+    // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] ---------------------------------------------------------
+    {
+        const float* r = a.save_x + ray * R2L_W + 4 * h;
+        float* o = a.gx + ray * R2L_W + 4 * h;
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(r + 32 * T + 8 * q);
+                f32x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? g[T][4 * q + j] + dy[T][4 * q + j] : 0.f;
+                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = ov;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream) {
+    hipLaunchKernelGGL(r2l_pack_bwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
+                       reinterpret_cast<unsigned short*>(wstream3), n_block);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                      const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream) {
+    B3Args a{};
+    a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
+    a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
+    a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
+    const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    hipLaunchKernelGGL(r2l_bwd3_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}

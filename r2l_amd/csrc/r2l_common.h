@@ -352,6 +352,14 @@ __host__ __device__ static inline int64_t r2l_fwd3_stages(int n_block) { return 
 __host__ __device__ static inline int64_t r2l_fwd3_stream_floats(int n_block) {
     return (r2l_fwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
 }
+__host__ __device__ static inline int64_t r2l_bwd3_stages(int n_block) { return 34 * (int64_t)n_block; }
+__host__ __device__ static inline int64_t r2l_bwd3_stream_floats(int n_block) {
+    return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
+}
+int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
+int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                      const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream);
 // forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
 // kernel (R2L_NO_FWD3=1: fp32 MFMA)
 static inline bool r2l_use_fwd3() {

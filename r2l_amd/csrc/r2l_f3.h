@@ -60,6 +60,7 @@ struct F3Side {
     Gather gather;            // fills v[4] with the next stage's B values (lo or hi half)
     bool want_b;
     F3Dma dma;
+    F3Dma extra = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};  // one more 1 KiB piece, issued with step 5 (backward: mask tile)
     float x[4], r1[4];
     unsigned uh[2], um[2], ul[2];  // packed bf16 pairs: values (0,1) and (2,3)
     // two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32), and back (shift / mask)
@@ -84,6 +85,7 @@ struct F3Side {
     __device__ __forceinline__ void step(int i) {
         loads(i);
         if (dma.on) f3_dma16(dma.rs, dma.voff, dma.so + i * 1024u, dma.la + i * 1024u);
+        if (i == 5 && extra.on) f3_dma16(extra.rs, extra.voff, extra.so, extra.la);
         if (!want_b) return;
         if (i == 0) {
             gather(x);
@@ -125,7 +127,14 @@ __device__ __forceinline__ void f3_mfma_half(f32x16 (&acc)[R2L_NT], int half, co
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[t], BB, acc[4 * half + t], 0, 0, 0);                                  \
     side.step(I);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);
-    F3_GROUP(a.l, b.h, 0)
+    if (ZERO_INIT) {  // first k-block of a GEMM without bias: C = 0 (inline constant) in the first group
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[t], b.h, zero, 0, 0, 0);
+        side.step(0);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        F3_GROUP(a.l, b.h, 0)
+    }
     F3_GROUP(a.h, b.l, 1)
     F3_GROUP(a.m, b.m, 2)
     F3_GROUP(a.m, b.h, 3)
@@ -135,7 +144,8 @@ __device__ __forceinline__ void f3_mfma_half(f32x16 (&acc)[R2L_NT], int half, co
 }
 
 // state of the weight-staging pipeline (everything wave-uniform except lane-derived offsets)
-struct F3Pipe {
+template <int NBUF>
+struct F3PipeT {
     u32x4 rs;            // buffer descriptor of the stage stream
     unsigned lds0;       // LDS address of buffer 0
     unsigned voff, wq;   // lane * 16 ; this wave's quarter of a stage
@@ -153,7 +163,7 @@ struct F3Pipe {
 #pragma unroll
         for (int i = 0; i < 6; ++i) f3_dma16(rs, voff, so + i * 1024u, la + i * 1024u);
         ++gq;
-        gqb = (gqb == F3_NBUF - 1) ? 0 : gqb + 1;
+        gqb = (gqb == NBUF - 1) ? 0 : gqb + 1;
     }
     // publish the next stage (k+1), refill the buffer everybody has left, advance the buffer cursor.  vmcnt retires in
     // order: `vmcnt(18)` (at most 18 outstanding) covers the own loads of stage k+1, which have the 18 loads of stages
@@ -161,16 +171,19 @@ struct F3Pipe {
     // (training: the ride-along stash stores sit between the DMA loads in the queue; `vmcnt(18)` stays sufficient — it then
     // also waits for a few of the oldest of them — and never becomes too weak, whatever their number)
     __device__ __forceinline__ void sync_next() {
-        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        // NBUF buffers: stages k+2 .. k+NBUF-2 (6 loads each) may still fly behind the loads of stage k+1
+        if (NBUF == 6) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        static_assert(NBUF == 6 || NBUF == 5, "wait immediates are written for 6 or 5 buffers");
         __syncthreads();
-        gb = (gb == F3_NBUF - 1) ? 0 : gb + 1;
+        gb = (gb == NBUF - 1) ? 0 : gb + 1;
         lb = base + gb * F3_STAGE_BYTES + lane * 16;
     }
     // the next request as six pieces for the side work of the second half stage (instead of a burst behind the barrier)
     __device__ __forceinline__ F3Dma request() {
         F3Dma d{true, rs, voff, (unsigned)gq * F3_STAGE_BYTES + wq, lds0 + (unsigned)gqb * F3_STAGE_BYTES + wq};
         ++gq;
-        gqb = (gqb == F3_NBUF - 1) ? 0 : gqb + 1;
+        gqb = (gqb == NBUF - 1) ? 0 : gqb + 1;
         return d;
     }
 };
@@ -179,13 +192,16 @@ struct F3Pipe {
 // 0-3 / 4-7 of stage k+1; BIAS_NEXT: stage k+1 is a bias stage (only the `hi` A operands exist, B = ones).
 // The barrier that publishes stage k+1 sits in the MIDDLE of stage k: behind it the first-half A operands of stage k+1
 // are read from LDS while the second half of stage k still feeds the matrix pipe.
-template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
-__device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], F3Pipe& P, GLo glo, GHi ghi) {
-    F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}};
+typedef F3PipeT<F3_NBUF> F3Pipe;
+
+template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class Pipe, class GLo, class GHi>
+__device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], Pipe& P, GLo glo, GHi ghi, F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
+                                         F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u}) {
+    F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, extra_a};
     f3_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
     P.sync_next();
-    F3Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request()};
+    F3Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), extra_b};
     f3_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {
@@ -198,7 +214,7 @@ __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], F3Pipe& P, GLo g
 }
 
 // gatherers of four B values
-template <bool RELU>
+template <bool RELU, bool STASH = false>
 struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile (tile T given for the stash address)
     const f32x16& frag;
     int c0;
@@ -208,7 +224,8 @@ struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile 
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = RELU ? fmaxf(frag[c0 + s], 0.f) : frag[c0 + s];
         // the B values ARE the layer input (x_b, relu(t_b)): the stash store rides along, one 16-byte piece per half stage
-        if (stash != nullptr) *reinterpret_cast<f32x4*>(stash + 32 * T + 8 * (c0 >> 2)) = f32x4{v[0], v[1], v[2], v[3]};
+        // (unconditional when STASH: a data-dependent branch per piece would cut the half stage's schedule in two)
+        if (STASH) *reinterpret_cast<f32x4*>(stash + 32 * T + 8 * (c0 >> 2)) = f32x4{v[0], v[1], v[2], v[3]};
     }
 };
 struct F3None {

@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    // every wave of the workgroup takes part in the weight staging and the barriers, also when its tile is past the end
+    // every wave of the workgroup takes part in the weight staging and the barriers: a wave whose tile lies past the end
+    // recomputes the last live tile (identical values to identical addresses), so nothing in the chain is conditional
+    const int64_t n_tiles = (a.N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile > n_tiles - 1) tile = n_tiles - 1;
     const int64_t ray = tile * R2L_TILE_RAYS + (lane & 31);
     const bool valid = ray < a.N;
     const int64_t rc = valid ? ray : a.N - 1;
@@ -277,34 +280,32 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     // training (SAVE): the B values of every stage are the layer's input, so the stash (x_b for the first layer of a block,
     // relu(t_b) for the second) is stored by the gatherers, two 16-byte pieces per stage
     const int64_t Np = R2L_PAD_ROWS(a.N);
-    // rows of the padding rays of the last tile exist (Np rows per slot); a wave whose whole tile lies past the end only
-    // takes part in the staging and must not store
-    const bool tile_live = tile * R2L_TILE_RAYS < a.N;
-    float* sx = (SAVE && tile_live) ? a.save_x + ray * R2L_W + 4 * h : nullptr;
-    float* st = (SAVE && tile_live) ? a.save_t + ray * R2L_W + 4 * h : nullptr;
+    // (rows of the padding rays of the last tile exist: Np rows per slot)
+    float* sx = SAVE ? a.save_x + ray * R2L_W + 4 * h : nullptr;
+    float* st = SAVE ? a.save_t + ray * R2L_W + 4 * h : nullptr;
     const int64_t slot = Np * R2L_W;
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
-        f3_stage<true, true, false>(t, P, F3Take4<false>{x[0], 0, sx, 0}, F3Take4<false>{x[0], 4, sx, 0});
+        f3_stage<true, true, false>(t, P, F3Take4<false, SAVE>{x[0], 0, sx, 0}, F3Take4<false, SAVE>{x[0], 4, sx, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(t, P, F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
-                                          F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
+            f3_stage<false, false, false>(t, P, F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
+                                          F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
         f3_stage<false, false, true>(t, P, F3None{}, F3None{});
         // x += W2 relu(t) + b2
-        f3_stage<true, false, false>(x, P, F3Take4<true>{t[0], 0, st, 0}, F3Take4<true>{t[0], 4, st, 0});
+        f3_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0}, F3Take4<true, SAVE>{t[0], 4, st, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
-                                          F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1});
+            f3_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
+                                          F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1});
         f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
-        if (SAVE && tile_live) {
+        if (SAVE) {
             sx += slot;
             st += slot;
         }
     }
-    if (SAVE && tile_live) {  // X_n
+    if (SAVE) {  // X_n
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll

@@ -127,7 +127,7 @@ extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
 }
 
 extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
-    return r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
+    return r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block) + r2l_bwd3_stream_floats(n_block);
 }
 
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
@@ -169,6 +169,11 @@ extern "C" int r2l_pack_backward_layout(const float* params, int n_block, float*
                            wstream + r2l_bwd32_stream_floats(n_block), n_block);
         R2L_CHECK(hipGetLastError());
     }
+    if (layout == 0 || layout == 3) {
+        const int rc = r2l_bwd3_pack(params, n_block, wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
+                                     (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -188,5 +193,6 @@ extern "C" int r2l_pack_backward(const float* params, int n_block, float* wstrea
     hipLaunchKernelGGL(r2l_pack_bwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
                        wstream + r2l_bwd32_stream_floats(n_block), n_block);
     R2L_CHECK(hipGetLastError());
-    return 0;
+    return r2l_bwd3_pack(params, n_block, wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
+                         (hipStream_t)stream);
 }

@@ -73,9 +73,9 @@ class R2LTrainer:
     def _pack_bwd(self, n):
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
-        ver, layout = eng.version(), (16 if self.lib.r2l_variant_for(int(n)) == 2 else 32)
+        ver, layout = eng.version(), eng.layout_for(n)  # 16 / 32 / 3: same choice as the forward (r2l_backward dispatches alike)
         if self._bwd_packed is None:
-            self._bwd_packed = {16: None, 32: None}
+            self._bwd_packed = {16: None, 32: None, 3: None}
         if self._bwd_packed[layout] != ver:
             _lib.check(self.lib.r2l_pack_backward_layout(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), layout,
                                                          _stream()), "r2l_pack_backward_layout")
@@ -196,7 +196,7 @@ class R2LTrainer:
             eng.pack_now()
             _lib.check(self.lib.r2l_pack_backward(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), _stream()),
                        "r2l_pack_backward")
-            self._bwd_packed = {16: eng.version(), 32: eng.version()}  # (pack_now marked the forward stream current)
+            self._bwd_packed = {16: eng.version(), 32: eng.version(), 3: eng.version()}  # (pack_now did the forward stream)
             gs["rgb"] = self.forward_backward(gs["o"], gs["d"], gs["t"], perturb)
             _lib.check(
                 self.lib.r2l_adam_step_dev(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),

@@ -9,6 +9,17 @@ import torch
 from oracle import r2l_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["bf16x3", "f32mfma"])
+def mlp_path(request, monkeypatch):
+    """Every test runs on both point-network kernels: r2l_teacher3.hip (fp32-accurate products on the bf16 matrix pipe,
+    the default) and r2l_teacher_mlp.hip (exact-fp32 MFMA, R2L_NO_FWD3=1)."""
+    if request.param == "f32mfma":
+        monkeypatch.setenv("R2L_NO_FWD3", "1")
+    else:
+        monkeypatch.delenv("R2L_NO_FWD3", raising=False)
+    return request.param
 T = torch.from_numpy
 
 
