@@ -12,11 +12,17 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
-    """Every test runs twice: one-wave-per-tile kernels and the cooperative small-batch kernels (r2l_coop.hip)."""
-    monkeypatch.setenv("R2L_FORCE_VARIANT", request.param)
-    return request.param
+    """Every test runs under each chain kernel family: one wave per tile on the bf16x3 matrix path (r2l_fwd3.hip /
+    r2l_bwd3.hip) and on the fp32 MFMA (R2L_NO_FWD3=1), and the two cooperative small-batch families."""
+    name = request.param
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
+    if name == "main-f32mfma":
+        monkeypatch.setenv("R2L_NO_FWD3", "1")
+    else:
+        monkeypatch.delenv("R2L_NO_FWD3", raising=False)
+    return name
 T = torch.from_numpy
 
 
