@@ -427,6 +427,146 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
 }
 
 // =================================================================================================================
+// The same GEMMs on the bf16 matrix pipe at fp32 accuracy (scheme of r2l_fwd3.hip: every fp32 operand value is the exact sum
+// of three bf16 numbers, six bf16 products stand for one fp32 product).  Both operands are activations, so both are split
+// here, on the VALU: one k-step is 16 rays; a lane loads the 4-feature pieces of its 8 rays for both operands (16 x 16 B),
+// splits the 64 values (packed v_cvt_pk_bf16_f32 + shift/mask + subtract) and issues 16 tiles x 6 = 96 MFMAs.  The rows
+// past N of a slot are exact zeros in the gradient operands (the chains write zero gradients for padding rays), so the k
+// loop simply runs to the padded row count: no tails, no predicates.  Work split, accumulator layout and the slab flush are
+// those of r2l_dw_body_kernel.
+// =================================================================================================================
+typedef __bf16 dw3_bf16x8 __attribute__((ext_vector_type(8)));
+struct Dw3Split {
+    dw3_bf16x8 h, m, l;
+};
+__device__ __forceinline__ unsigned dw3_pk(float a0, float a1) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+}
+__device__ __forceinline__ float dw3_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float dw3_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+// component e of the eight loaded pieces (8 rays) -> bf16 (hi, mid, lo) operand registers
+__device__ __forceinline__ Dw3Split dw3_split(const f32x4 (&v)[8], int e) {
+    u32x4 uh, um, ul;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = v[2 * p][e], x1 = v[2 * p + 1][e];
+        const unsigned h = dw3_pk(x0, x1);
+        const float r0 = x0 - dw3_lo(h), r1 = x1 - dw3_hi(h);
+        const unsigned m = dw3_pk(r0, r1);
+        const unsigned l = dw3_pk(r0 - dw3_lo(m), r1 - dw3_hi(m));
+        uh[p] = h; um[p] = m; ul[p] = l;
+    }
+    Dw3Split s;
+    s.h = __builtin_bit_cast(dw3_bf16x8, uh);
+    s.m = __builtin_bit_cast(dw3_bf16x8, um);
+    s.l = __builtin_bit_cast(dw3_bf16x8, ul);
+    return s;
+}
+
+__global__ __launch_bounds__(256, 1) void r2l_dw_body3_kernel(const R2LDwArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wo = wave >> 1, wi = wave & 1;
+    const int hh = lane >> 5, jl = lane & 31;
+    const int64_t total = a.units_per_layer * 2 * a.n_block;
+    int64_t u0 = (int64_t)blockIdx.x * a.units_per_wg;
+    int64_t u1 = u0 + a.units_per_wg;
+    if (u1 > total) u1 = total;
+    if (u0 >= u1) return;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+        for (int ei = 0; ei < 4; ++ei)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[eo][ei][c] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const int64_t Np = R2L_PAD_ROWS(a.N);
+
+    int64_t u = u0;
+    const int first_layer = (int)(u0 / a.units_per_layer);
+    while (u < u1) {
+        const int layer = (int)(u / a.units_per_layer);
+        const int64_t cu = u % a.units_per_layer;
+        int64_t cend = cu + (u1 - u);
+        if (cend > a.units_per_layer) cend = a.units_per_layer;
+        const int b = layer >> 1;
+        const float* G = (layer & 1) ? a.gx + (int64_t)(b + 1) * Np * R2L_W : a.gt + (int64_t)b * Np * R2L_W;
+        const float* A = (layer & 1) ? a.save_t + (int64_t)b * Np * R2L_W : a.save_x + (int64_t)b * Np * R2L_W;
+        const int64_t r0 = cu * DW_CHUNK;
+        int64_t r1 = cend * DW_CHUNK;
+        if (r1 > Np) r1 = Np;
+        const int64_t nsteps = (r1 - r0) / 16;  // Np is a multiple of 32
+        const __amdgpu_buffer_rsrc_t grs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G + r0 * R2L_W), 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ars =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + r0 * R2L_W), 0, 0xffffffff, 0x00020000);
+        // lane (jl, hh): rays 8hh .. 8hh+7 of the 16-ray step, features 4jl .. 4jl+3 of the wave's 128-feature slice
+        const unsigned gvo = (unsigned)(8 * hh * R2L_W + wo * 128 + 4 * jl) * 4u;
+        const unsigned avo = (unsigned)(8 * hh * R2L_W + wi * 128 + 4 * jl) * 4u;
+        auto ld = [&](int64_t s, f32x4 (&gv)[8], f32x4 (&av)[8]) {
+            const int64_t sc = s < nsteps ? s : nsteps - 1;  // the prefetch behind the last step re-reads it
+            const unsigned so = (unsigned)sc * (16u * R2L_W * 4u);
+            // rows r < 4 via the instruction's 12-bit offset field, rows 4..7 through the scalar offset (+4096); the opaque
+            // copies keep hipcc from materialising voff + const in 16 loop-invariant VGPRs
+            unsigned gq = gvo, aq = avo;
+            asm volatile("" : "+v"(gq), "+v"(aq));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned ro = (unsigned)(r & 3) * (R2L_W * 4u), sx = so + (unsigned)(r >> 2) * 4096u;
+                gv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, gq + ro, sx, 0));
+                av[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, aq + ro, sx, 0));
+            }
+        };
+        auto kstep = [&](const f32x4 (&gv)[8], const f32x4 (&av)[8]) {
+            Dw3Split bs[4];
+#pragma unroll
+            for (int ei = 0; ei < 4; ++ei) bs[ei] = dw3_split(av, ei);
+#pragma unroll
+            for (int eo = 0; eo < 4; ++eo) {
+                const Dw3Split as = dw3_split(gv, eo);
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.l, bs[ei].h, acc[eo][ei], 0, 0, 0);
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h, bs[ei].l, acc[eo][ei], 0, 0, 0);
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.m, bs[ei].m, acc[eo][ei], 0, 0, 0);
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.m, bs[ei].h, acc[eo][ei], 0, 0, 0);
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h, bs[ei].m, acc[eo][ei], 0, 0, 0);
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h, bs[ei].h, acc[eo][ei], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bsum += gv[r];
+        };
+        if (nsteps > 0) {
+            f32x4 g0[8], x0[8], g1[8], x1[8];
+            ld(0, g0, x0);
+            int64_t s = 0;
+            for (; s + 2 <= nsteps; s += 2) {  // two steps per trip: the buffers swap roles without register copies
+                ld(s + 1, g1, x1);
+                kstep(g0, x0);
+                ld(s + 2, g0, x0);
+                kstep(g1, x1);
+            }
+        }
+        if (a.slab != nullptr) {
+            dw_flush_slab(acc, bsum, a.slab + ((int64_t)blockIdx.x * 2 + (layer - first_layer)) * DW_SLAB_FLOATS, wo, wi,
+                          lane);
+        } else {
+            float* gw = a.grads + b_off_body_w(layer);
+            float* gb = a.grads + b_off_body_b(layer);
+            dw_flush(acc, bsum, gw, gb, wo, wi, lane);
+        }
+        u += cend - cu;
+    }
+}
+
+// =================================================================================================================
 // Head weight gradient:  dWh[o][k] = sum_r Gh[r][o] * PE[r][k]   (k in 1008, padded to 1024), dbh[o] = sum_r Gh[r][o]
 // The encoding is recomputed from the rays (never stored: 4 KB/ray).  Workgroup (kq, slice): kq selects 256 encoding
 // columns; wave w of it owns columns kq*256 + w*64 .. +63 (two 32-column tiles) x all 256 output rows (8 tiles).
@@ -768,7 +908,9 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         wgs = (total + a.units_per_wg - 1) / a.units_per_wg;
         // units_per_wg <= units_per_layer whenever wgs >= 2*n_block (always, for n_block <= 128): a range touches <= 2 layers
         a.slab = (a.units_per_wg <= a.units_per_layer) ? dw_slab : nullptr;
-        hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        // default: both activation operands split into bf16 triples on the fly (R2L_NO_FWD3 / R2L_NO_DW3: fp32 MFMA)
+        if (r2l_use_fwd3() && !getenv("R2L_NO_DW3")) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());
         if (a.slab != nullptr) {
             hipLaunchKernelGGL(r2l_dw_reduce_kernel, dim3((DW_SLAB_FLOATS / 4 + 255) / 256, 2 * n_block), dim3(256), 0, stream,
