@@ -250,13 +250,33 @@ def main():
                                                                % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_fp32_mfma": PEAK_FP32_MFMA,
-                     "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA, "traffic": traffic,
+                     "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
+                     "peak_note": ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); the default kernel evaluates "
+                                   "every fp32 product as 6 bf16 MFMA products (exact bf16 hi/mid/lo splits), so its matrix-pipe "
+                                   "peak in algorithmic FLOP/s is the dense bf16 MFMA peak 2500 TF / 6; under that load the chip "
+                                   "runs at ~1.9 GHz instead of the nominal 2.4 GHz the peak assumes (profiles/r01_summary.md)")
+                     if fwd3 else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                     "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
                                      "bytes per launch = 160000 rays x 12 B out + the packed weight stream (37.6 MB of "
                                      "bf16 triples / 24.3 MB fp32)" % traffic_src,
                      "kernel": "r2l_fwd3_kernel<POSE>" if fwd3 else "r2l_fwd_kernel<MODE_POSE>", "kernel_ms": kernel_ms,
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }
+
+    if fwd3 and rank == 0 and world == 1:
+        # the same frame on the exact-fp32 MFMA kernel (r2l_forward.hip), for reference: the C side reads the switch per call
+        os.environ["R2L_NO_FWD3"] = "1"
+        try:
+            dt32, k32 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
+        finally:
+            del os.environ["R2L_NO_FWD3"]
+        n32 = max(3, a.steps // 4)
+        a32 = H * W * FWD_FLOP_PER_RAY / (k32 * 1e-3) / 1e12
+        out["render_fp32_mfma"] = {"value": H * W * n32 / dt32, "unit": "rays/s", "ms_per_step": dt32 / n32 * 1e3,
+                                   "roofline": {"bound": "mfma", "achieved": a32, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+                                                "frac": a32 / PEAK_FP32_MFMA, "kernel": "r2l_fwd_kernel<MODE_POSE>",
+                                                "kernel_ms": k32}}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb, rgb_cpu, rows = cpu_baseline(sd)

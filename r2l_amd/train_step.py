@@ -283,10 +283,22 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
 
     dt, step_ms = timed(train_step, steps, warm, distributed, device)
     achieved = n * flop_per_ray / (step_ms * 1e-3) / 1e12
+    # which matrix path the step's GEMM kernels take: one-wave-per-tile launches run forward, dX chain and dW GEMMs with
+    # fp32-accurate products on the bf16 MFMA (6 bf16 products per fp32 product: peak = bf16 dense / 6); the cooperative
+    # small-batch chains stay on the fp32 MFMA (only their dW GEMMs use the bf16 path)
+    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")
+    big = tr.lib.r2l_variant_for(int(n)) == 0
+    peak_fp32 = peak
+    if fwd3 and big:
+        peak = 2500.0 / 6.
     return {"value": n * steps * world / dt, "unit": "rays/s", "steps": steps, "warmup": warm,
             "ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": n,
             "workload": "distillation step (fwd + bwd + Adam + weight re-pack), %d rays/GPU/step, perturb=1; "
                         "grad all-reduce over %d rank(s)" % (n, world),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "flop_per_ray": flop_per_ray, "step_ms_device": step_ms},
+                         "frac": achieved / peak, "peak_fp32_mfma": peak_fp32,
+                         "frac_of_fp32_mfma_peak": achieved / peak_fp32,
+                         "matrix_path": ("bf16x3 (fwd, dX chain, dW)" if (fwd3 and big) else
+                                         ("fp32 MFMA chains + bf16x3 dW" if fwd3 else "fp32 MFMA")),
+                         "flop_per_ray": flop_per_ray, "step_ms_device": step_ms},
             "final_loss": tr.loss_out[0].item()}
