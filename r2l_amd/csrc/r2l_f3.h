@@ -26,7 +26,7 @@ __host__ __device__ static inline float f3_bf16_to_f(unsigned short b) {
 // compiler's waitcnt insertion treats the builtin form conservatively (vmcnt(0) before every LDS read), which would
 // collapse the multi-stage prefetch; the waits are placed by hand (F3Pipe::sync_next).
 __device__ __forceinline__ void f3_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory");
