@@ -124,7 +124,10 @@ def main(argv=None):
     for j, i in enumerate(mine, 1):
         pose = D.get_rand_pose(rng).to(device)
         focal_ = focal * (1 + rng.rand()) if args.use_rand_focal else focal  # focal x U[1,2) (create_data.py:816)
-        rows = render_pose_rows(pose, H, W, focal_, near, far, args.chunk, kwargs)
+        # whole frame per launch on the GPU: --chunk (32 768 rays in the reference's configs) is a memory work-around of
+        # the op-by-op path; the fused kernels need 0.5 GB of scratch for a 400x400 frame at 192 samples
+        chunk = max(args.chunk, H * W) if device.type == "cuda" else args.chunk
+        rows = render_pose_rows(pose, H, W, focal_, near, far, chunk, kwargs)
         if filled == 0:
             free[k].wait()  # the flush that last used this buffer has been written
         stage[k][filled:filled + H * W].copy_(rows, non_blocking=True)

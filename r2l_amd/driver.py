@@ -144,7 +144,7 @@ class _FrameWriter:
     non-blocking into a pinned buffer, and a small thread pool waits for the copy and encodes (zlib releases the GIL).
     At 13 ms per rendered frame, encoding two 400x400 PNGs inline (~2 x 15 ms) would triple the wall time."""
 
-    def __init__(self, device, workers=4, slots=8):
+    def __init__(self, device, workers=4, slots=8):  # (8 workers measured slower: they compete with the launch thread)
         from concurrent.futures import ThreadPoolExecutor
         self.device, self.pool, self.pending = device, ThreadPoolExecutor(max_workers=workers), []
         self.slots, self.bufs = slots, {}
