@@ -31,6 +31,7 @@ SIGNATURES = {
     "r2l_forward_emb": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p]),
     "r2l_num_tiles": (_l, [_l]),
     "r2l_padded_rows": (_l, [_l]),
+    "r2l_stash_slot_floats": (_l, [_l]),
     "r2l_dw_slab_floats": (_l, []),
     "r2l_backward": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),

@@ -567,6 +567,244 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3_kernel(const R2LDwArgs a)
 }
 
 // =================================================================================================================
+// The same GEMMs fed from the SPLIT stash of the bf16x3 chains (r2l_common.h): the chains stored every operand value as the
+// bf16 (hi, mid, lo) triple they used themselves, so no VALU work is left here.  What is left is a transpose: the stash is
+// feature-contiguous per ray (the chains' k runs over features), the weight gradient's k runs over rays.
+//   * one k-step = 16 rays (half a tile).  Per operand the 48 pieces (k-block kb, split) of the half tile, 512 B each, are
+//     copied to LDS by DMA (buffer_load ... lds, 1 KiB = two pieces per instruction, all four waves share the image; three
+//     step buffers, one barrier per step);
+//   * the MFMA operands (lane = feature, 8 consecutive rays in its 16 bytes) come out of LDS through ds_read_b64_tr_b16:
+//     within a 16-lane group lane L = 4*row + q supplies the address of four consecutive bf16 (ray row, feature quad q) and
+//     lane l receives rows 0..3 of column l — 4 rays of feature l (measured: tools/tr_probe.hip).  A k-block holds 16
+//     features as quads (s>>2, h): q = 2*(s>>2) + h gives output lane l = feature 16 kb + l, the natural order;
+//   * LDS image of a piece (kb, split), pc = 3 kb + split: [h][pos][16 B] with pos = (ray + 8 h + 4 (pc & 1)) & 15 — the
+//     rotation spreads the 32 lanes of a read pass (two k-blocks x two h x four rays) over all banks;
+//   * db: the G operands unpacked and added on the VALU (waves wi == 0).
+// Work split, accumulators and the slab reduce are those of r2l_dw_body_kernel; tile eo of a wave's 128-feature slice is
+// features 32 eo .. 32 eo + 31 here (row m of the MFMA result = feature 32 eo + m).
+// =================================================================================================================
+#define DW3S_OP_BYTES 24576   // one operand, one step: 48 pieces x 512 B
+#define DW3S_BUF_BYTES 49152  // G image, A image
+#define DW3S_NBUF 3
+typedef short dw3s_s16x4 __attribute__((ext_vector_type(4)));
+
+// 8 rays of this lane's feature: two transposing reads (rays 8hh + 0..3 at p0, 8hh + 4..7 at p1), byte offset off (a constant
+// after unrolling: it ends up in the instruction's offset field)
+__device__ __forceinline__ dw3_bf16x8 dw3s_read(unsigned p0, unsigned p1, unsigned off) {
+    typedef __attribute__((address_space(3))) dw3s_s16x4 lds_v;
+    const dw3s_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(size_t)(p0 + off));
+    const dw3s_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(size_t)(p1 + off));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(dw3_bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+// the operand registers of one k-step: gs = tiles of the gradient operand (MFMA A), xs = tiles of the activation operand
+struct Dw3sRegs {
+    Dw3Split gs[4], xs[4];
+};
+// fragment F of a step's 24 (F < 12: activation tile F/3, split F%3; else gradient tile (F-12)/3, split (F-12)%3);
+// gp / ap [v][t]: lane bases in the G / A image for rotation variant v = split & 1 and ray quad t
+__device__ __forceinline__ void dw3s_frag(int F, Dw3sRegs& R, const unsigned (&gp)[2][2], const unsigned (&ap)[2][2]) {
+    const bool grad = F >= 12;
+    const int f = grad ? F - 12 : F, e = f / 3, sp = f % 3, v = sp & 1;
+    const dw3_bf16x8 val = grad ? dw3s_read(gp[v][0], gp[v][1], (unsigned)(e * 3072 + sp * 512))
+                                : dw3s_read(ap[v][0], ap[v][1], (unsigned)(e * 3072 + sp * 512));
+    Dw3Split& d = grad ? R.gs[e] : R.xs[e];
+    if (sp == 0) d.h = val;
+    else if (sp == 1) d.m = val;
+    else d.l = val;
+}
+// (v_dot2c_f32_bf16 against (1, 1) would be one instruction per pair, but its result is not the fp32 sum: measured 20-40 %
+// off on the bias gradients; unpack and add instead — the VALU is idle beside the MFMAs)
+__device__ __forceinline__ float dw3s_colsum(const Dw3Split& g, int d, float acc) {  // dword d: two of the lane's 8 rays
+    const u32x4 l = __builtin_bit_cast(u32x4, g.l), m = __builtin_bit_cast(u32x4, g.m), h = __builtin_bit_cast(u32x4, g.h);
+    const float v0 = (dw3_lo(l[d]) + dw3_lo(m[d])) + dw3_lo(h[d]);
+    const float v1 = (dw3_hi(l[d]) + dw3_hi(m[d])) + dw3_hi(h[d]);
+    acc += v0;
+    acc += v1;
+    return acc;
+}
+__device__ __forceinline__ void dw3s_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char img[DW3S_NBUF][DW3S_BUF_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wo = wave >> 1, wi = wave & 1;
+    const int64_t total = a.units_per_layer * 2 * a.n_block;
+    int64_t u0 = (int64_t)blockIdx.x * a.units_per_wg;
+    int64_t u1 = u0 + a.units_per_wg;
+    if (u1 > total) u1 = total;
+    if (u0 >= u1) return;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+        for (int ei = 0; ei < 4; ++ei)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[eo][ei][c] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t Np = R2L_PAD_ROWS(a.N);
+    const int64_t slot = Np * R2L_SPLIT_ROW;
+
+    // DMA source of LDS unit u = lane of an instruction (two pieces): piece parity pp, half h, rotated position pos
+    const unsigned dvoff = [&] {
+        const int pp = lane >> 5, hq = (lane >> 4) & 1, pos = lane & 15;
+        return (unsigned)(pp * 1024 + (hq * 32 + ((pos - 8 * hq - 4 * pp) & 15)) * 16);
+    }();
+    const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&img[0][0];
+    // read bases: 16-lane group g = (hh, par): k-block parity par inside the tile, rays 8hh..; lane L = 4*row + q in it
+    unsigned gb0[2][2], ab0[2][2];
+    {
+        const int g = lane >> 4, L = lane & 15, par = g & 1, hh = g >> 1, hf = L & 1, sh = (L >> 1) & 1, row = L >> 2;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned base = (unsigned)(par * 1536 + hf * 256 + ((8 * hh + 4 * t + row + 8 * hf + 4 * ((par + v) & 1)) & 15) * 16 + sh * 8);
+                gb0[v][t] = img_lds + base + (unsigned)wo * 12288u;
+                ab0[v][t] = img_lds + DW3S_OP_BYTES + base + (unsigned)wi * 12288u;
+            }
+    }
+
+    int64_t u = u0;
+    const int first_layer = (int)(u0 / a.units_per_layer);
+    while (u < u1) {
+        const int layer = (int)(u / a.units_per_layer);
+        const int64_t cu = u % a.units_per_layer;
+        int64_t cend = cu + (u1 - u);
+        if (cend > a.units_per_layer) cend = a.units_per_layer;
+        const int b = layer >> 1;
+        const float* G = (layer & 1) ? a.gx + (int64_t)(b + 1) * slot : a.gt + (int64_t)b * slot;
+        const float* A = (layer & 1) ? a.save_t + (int64_t)b * slot : a.save_x + (int64_t)b * slot;
+        const int64_t r0 = cu * DW_CHUNK;  // a multiple of 64 rays: two whole tiles
+        int64_t r1 = cend * DW_CHUNK;
+        if (r1 > Np) r1 = Np;
+        const int nsteps = (int)((r1 - r0) / 16);  // Np is a multiple of 32
+        // descriptors based at the first tile of the segment
+        const unsigned long long ga = (unsigned long long)(reinterpret_cast<const unsigned char*>(G) + (r0 / 32) * R2L_SPLIT_TILE_BYTES);
+        const unsigned long long aa = (unsigned long long)(reinterpret_cast<const unsigned char*>(A) + (r0 / 32) * R2L_SPLIT_TILE_BYTES);
+        const u32x4 grs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        const u32x4 ars = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)aa),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(aa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        // this wave's share of a step image: instructions wave, wave + 4, .. of the 24 of each operand = 12 pieces, piece k:
+        // operand k & 1, instruction wave + 4 (k >> 1).  Steps past the end are clamped to the last one (harmless reloads:
+        // every step issues exactly 12 loads, which keeps the vmcnt arithmetic uniform)
+        auto piece = [&](int s, int buf, int k) {
+            const int sc = s < nsteps ? s : nsteps - 1;
+            const unsigned so = (unsigned)(sc >> 1) * (unsigned)R2L_SPLIT_TILE_BYTES + (unsigned)(sc & 1) * 256u +
+                                (unsigned)wave * 2048u + (unsigned)(k >> 1) * 8192u;
+            const unsigned la = img_lds + (unsigned)buf * DW3S_BUF_BYTES + (unsigned)wave * 1024u + (unsigned)(k >> 1) * 4096u;
+            if (k & 1) dw3s_dma16(ars, dvoff, so, la + DW3S_OP_BYTES);
+            else dw3s_dma16(grs, dvoff, so, la);
+        };
+        // One k-step: 96 MFMAs on the registers C (read from LDS during the previous step); riding along, one per group of
+        // four MFMAs: a fragment of step s+1 (LDS -> registers Nx), every other group a DMA piece of step s+3 (HBM -> the
+        // LDS buffer step s occupied: every wave finished reading it before this step's barrier).
+        auto step = [&](Dw3sRegs& C, Dw3sRegs& Nx, int s, int buf) {
+            // the own pieces of step s+1 (the 12 of step s+2 may still fly), then everybody's; lgkmcnt(0) is part of the
+            // barrier: nobody's reads of buffer `buf` are pending any more
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            __syncthreads();
+            const unsigned bo = (unsigned)(buf == DW3S_NBUF - 1 ? 0 : buf + 1) * DW3S_BUF_BYTES;  // image of step s+1
+            unsigned gp[2][2], ap[2][2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    gp[v][t] = gb0[v][t] + bo;
+                    ap[v][t] = ab0[v][t] + bo;
+                }
+#pragma unroll
+            for (int g = 0; g < 24; ++g) {
+                const int eo = g / 6, term = g % 6;
+                // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+                const dw3_bf16x8& ga = (term == 0) ? C.gs[eo].l : (term == 2 || term == 3) ? C.gs[eo].m : C.gs[eo].h;
+#pragma unroll
+                for (int ei = 0; ei < 4; ++ei) {
+                    const dw3_bf16x8& xb = (term == 1) ? C.xs[ei].l : (term == 2 || term == 4) ? C.xs[ei].m : C.xs[ei].h;
+                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb, acc[eo][ei], 0, 0, 0);
+                }
+                dw3s_frag(g, Nx, gp, ap);
+                if ((g & 1) == 0) piece(s + 3, buf, g >> 1);
+                if (wi == 0 && term < 4) bsum[eo] = dw3s_colsum(C.gs[eo], term, bsum[eo]);  // a quarter per group
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (nsteps > 0) {  // (always even: 64-ray units, Np a multiple of 32)
+            Dw3sRegs RA, RB;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) piece(0, 0, k);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) piece(1, 1, k);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) piece(2, 2, k);
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int F = 0; F < 24; ++F) dw3s_frag(F, RA, gb0, ab0);  // step 0 from buffer 0
+            int buf = 0;
+            for (int s = 0; s < nsteps; s += 2) {
+                step(RA, RB, s, buf);
+                buf = (buf == DW3S_NBUF - 1) ? 0 : buf + 1;
+                step(RB, RA, s + 1, buf);
+                buf = (buf == DW3S_NBUF - 1) ? 0 : buf + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // the images are dead (and the clamped reloads landed) before the next segment refills them
+        }
+        // flush: D[m][n] of tile (eo, ei): m = 8 (c>>2) + 4 hh + (c&3) -> output feature wo*128 + 32 eo + m, n = lane & 31 ->
+        // input feature wi*128 + 32 ei + n
+        {
+            const int n = lane & 31, hh = lane >> 5;
+            float* sl = (a.slab != nullptr) ? a.slab + ((int64_t)blockIdx.x * 2 + (layer - first_layer)) * DW_SLAB_FLOATS : nullptr;
+            float* gw = a.grads + b_off_body_w(layer);
+            float* gbias = a.grads + b_off_body_b(layer);
+            float* rowp = (sl != nullptr ? sl : gw) + (wo * 128 + 4 * hh) * R2L_W + wi * 128 + n;
+            if (sl != nullptr) {
+#pragma unroll
+                for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+                    for (int ei = 0; ei < 4; ++ei)
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c];
+                            acc[eo][ei][c] = 0.f;
+                        }
+            } else {
+#pragma unroll
+                for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+                    for (int ei = 0; ei < 4; ++ei)
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c]);
+                            acc[eo][ei][c] = 0.f;
+                        }
+            }
+            if (wi == 0) {
+#pragma unroll
+                for (int eo = 0; eo < 4; ++eo) {
+                    const float sv = bsum[eo] + __shfl_xor(bsum[eo], 32);
+                    if (hh == 0) {
+                        if (sl != nullptr) sl[R2L_W * R2L_W + wo * 128 + 32 * eo + n] = sv;
+                        else atomicAdd(gbias + wo * 128 + 32 * eo + n, sv);
+                    }
+                    bsum[eo] = 0.f;
+                }
+            }
+        }
+        u += cend - cu;
+    }
+}
+
+// =================================================================================================================
 // Head weight gradient:  dWh[o][k] = sum_r Gh[r][o] * PE[r][k]   (k in 1008, padded to 1024), dbh[o] = sum_r Gh[r][o]
 // The encoding is recomputed from the rays (never stored: 4 KB/ray).  Workgroup (kq, slice): kq selects 256 encoding
 // columns; wave w of it owns columns kq*256 + w*64 .. +63 (two 32-column tiles) x all 256 output rows (8 tiles).
@@ -799,7 +1037,7 @@ __global__ __launch_bounds__(256) void r2l_dw_tail_kernel(const float* __restric
     if (r1 > N) r1 = N;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
-        const float y = xn[r * R2L_W + f] + x0[r * R2L_W + f];
+        const float y = x0 != nullptr ? xn[r * R2L_W + f] + x0[r * R2L_W + f] : xn[r * R2L_W + f];  // x0 == nullptr: xn holds y
         const float d0 = dpre[r * 3 + 0], d1 = dpre[r * 3 + 1], d2 = dpre[r * 3 + 2];
         s0 = __builtin_fmaf(d0, y, s0);
         s1 = __builtin_fmaf(d1, y, s1);
@@ -852,6 +1090,7 @@ __global__ __launch_bounds__(256) void r2l_tail_reduce_kernel(const float* __res
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS; }
+extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_PAD_ROWS(N) * (int64_t)R2L_SPLIT_ROW; }
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
@@ -873,6 +1112,8 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
     const int n_cu = n_cu_cached;
     // 1. dX chain
     const int variant = r2l_chain_variant(N);
+    // the bf16x3 trio (r2l_fwd3 wrote the stash): split stash layout, see r2l_common.h
+    const bool split = r2l_stash_split(N, emb != nullptr);
     if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
                                            params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
@@ -881,7 +1122,7 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         const int rc = r2l_coop_backward(rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block, grad_scale, dpre,
                                          gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;
-    } else if (r2l_use_fwd3() && !getenv("R2L_NO_BWD3")) {
+    } else if (split) {
         // one-wave-per-tile dX chain on the bf16 matrix pipe (fp32-accurate products): r2l_bwd3.hip
         const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t,
                                          wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
@@ -908,8 +1149,10 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         wgs = (total + a.units_per_wg - 1) / a.units_per_wg;
         // units_per_wg <= units_per_layer whenever wgs >= 2*n_block (always, for n_block <= 128): a range touches <= 2 layers
         a.slab = (a.units_per_wg <= a.units_per_layer) ? dw_slab : nullptr;
-        // default: both activation operands split into bf16 triples on the fly (R2L_NO_FWD3 / R2L_NO_DW3: fp32 MFMA)
-        if (r2l_use_fwd3() && !getenv("R2L_NO_DW3")) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        // bf16 matrix pipe at fp32 accuracy: operands already split by the chains (split stash), or split on the fly from
+        // the row-major fp32 stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
+        if (split) hipLaunchKernelGGL(r2l_dw_body3s_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        else if (r2l_use_fwd3()) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());
         if (a.slab != nullptr) {
@@ -955,8 +1198,10 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         // partials behind the head's slab region; summed in workgroup order
         float* part = (dw_slab != nullptr && DW_HEAD_SLAB_MAX + wgs * (4 * R2L_W) <= r2l_dw_slab_floats())
                           ? dw_slab + DW_HEAD_SLAB_MAX : nullptr;
-        hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, save_x,
-                           save_x + (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W, grads, part, n_block, N, per);
+        // (split stash: slot n of save_x, at the split slot stride, holds y = x_n + x_0)
+        hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, split ? nullptr : save_x,
+                           save_x + (int64_t)n_block * R2L_PAD_ROWS(N) * (split ? R2L_SPLIT_ROW : R2L_W), grads, part, n_block,
+                           N, per);
         R2L_CHECK(hipGetLastError());
         if (part != nullptr) {
             hipLaunchKernelGGL(r2l_tail_reduce_kernel, dim3(R2L_W / 32, 4), dim3(256), 0, stream, part, wgs, grads, n_block);

@@ -175,6 +175,15 @@ __device__ __forceinline__ void r2l_stash_store(float* p, const f32x4& v) { *rei
 __device__ __forceinline__ void r2l_stash_store_nt(float* p, const f32x4& v) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }
+// ---- split stash layout (the bf16x3 training trio r2l_fwd3 / r2l_bwd3 / r2l_dw_body3s) ----------------------------------
+// The one-wave-per-tile bf16x3 chains stash every layer input as the bf16 (hi, mid, lo) triple they computed for their own
+// MFMAs.  A slot is [tile = ray/32][k-block kb = feature/16][split 3][lane = 32h + ray%32][8 bf16], i.e. 1.5 KiB per ray
+// (slot stride R2L_SPLIT_ROW floats per row); slot s of a lane holds feature 16 kb + 8 (s>>2) + 4h + (s&3).  Each of the
+// three stores of a stage writes one contiguous KiB per wave; the weight-gradient kernel stages the pieces in LDS with DMA
+// loads and builds its ray-major MFMA operands with transposing LDS reads, without any VALU work on the operands.
+#define R2L_SPLIT_ROW 384          // floats per ray and slot
+#define R2L_SPLIT_KB_BYTES 3072    // one (tile, k-block): 3 splits x 1 KiB
+#define R2L_SPLIT_TILE_BYTES 49152 // one tile: 16 k-blocks
 template <bool RELU = false, class Act = IdentityAct>
 struct StoreHookT {
     static constexpr int RD = 0, WR = 1;
@@ -389,6 +398,14 @@ static inline int r2l_chain_variant(int64_t N) {
     const double c16_t = (double)((N + 4095) / 4096) * R2L_C16_ROUND;
     if (c16_t < coop_t && c16_t < main_t) return R2L_VARIANT_COOP16;
     return coop_t < main_t ? R2L_VARIANT_COOP : R2L_VARIANT_MAIN;
+}
+
+// The bf16x3 training trio keeps its stash (save_x[0..n-1], save_t, gx[1..n], gt) in the split layout above (slot stride
+// Np * R2L_SPLIT_ROW floats); slot n of save_x then holds y = x_n + x_0 as row-major fp32 (all the tail gradient needs) and
+// gx[0] stays row-major fp32 (head gradient).  Every other combination (cooperative chains, fp32 chains, the pre-embedded
+// module-boundary path) is row-major fp32 with slot stride Np * 256.  Callers size the buffers with r2l_stash_slot_floats().
+static inline bool r2l_stash_split(int64_t N, bool pre_embedded) {
+    return !pre_embedded && N > 0 && r2l_chain_variant(N) == R2L_VARIANT_MAIN && r2l_use_fwd3();
 }
 
 // error plumbing shared by the C-ABI translation units

@@ -60,11 +60,13 @@ class R2LTrainer:
         dev, nb = self.eng.device, self.eng.n_block
         self.cap = n
         f = dict(dtype=torch.float32, device=dev)
-        npad = int(self.lib.r2l_padded_rows(n))  # rows per slot: N rounded up to a 32-ray tile
-        self.save_x = torch.empty((nb + 1) * npad * W, **f)
-        self.save_t = torch.empty(max(nb, 1) * npad * W, **f)
-        self.gx = torch.empty((nb + 1) * npad * W, **f)
-        self.gt = torch.empty(max(nb, 1) * npad * W, **f)
+        # floats per stash slot: N rounded up to a 32-ray tile x 1.5 KiB (the bf16x3 chains stash bf16 triples; the other
+        # chains use the first Np*256 floats of their slots, row-major fp32)
+        slot = int(self.lib.r2l_stash_slot_floats(n))
+        self.save_x = torch.empty((nb + 1) * slot, **f)
+        self.save_t = torch.empty(max(nb, 1) * slot, **f)
+        self.gx = torch.empty((nb + 1) * slot, **f)
+        self.gt = torch.empty(max(nb, 1) * slot, **f)
         self.dpre = torch.empty(n * 3, **f)
         self.sqerr = torch.empty(int(self.lib.r2l_num_tiles(n)), **f)
         if getattr(self, "dw_slab", None) is None and not os.environ.get("R2L_NO_DW_SLAB"):  # env: A/B diagnostics only
