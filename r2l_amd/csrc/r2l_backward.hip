@@ -601,11 +601,14 @@ __device__ __forceinline__ dw3_bf16x8 dw3s_read(unsigned p0, unsigned p1, unsign
 struct Dw3sRegs {
     Dw3Split gs[4], xs[4];
 };
-// fragment F of a step's 24 (F < 12: activation tile F/3, split F%3; else gradient tile (F-12)/3, split (F-12)%3);
+// fragment F of a step (TERMS == 6: 24 fragments, F < 12: activation tile F/3, split F%3, else gradient tile (F-12)/3, split
+// (F-12)%3;  TERMS == 3: the lo splits are not used: 16 fragments, F < 8: activation tile F/2, split F%2, else gradient);
 // gp / ap [v][t]: lane bases in the G / A image for rotation variant v = split & 1 and ray quad t
+template <int TERMS>
 __device__ __forceinline__ void dw3s_frag(int F, Dw3sRegs& R, const unsigned (&gp)[2][2], const unsigned (&ap)[2][2]) {
-    const bool grad = F >= 12;
-    const int f = grad ? F - 12 : F, e = f / 3, sp = f % 3, v = sp & 1;
+    constexpr int NS = TERMS == 6 ? 3 : 2;
+    const bool grad = F >= 4 * NS;
+    const int f = grad ? F - 4 * NS : F, e = f / NS, sp = f % NS, v = sp & 1;
     const dw3_bf16x8 val = grad ? dw3s_read(gp[v][0], gp[v][1], (unsigned)(e * 3072 + sp * 512))
                                 : dw3s_read(ap[v][0], ap[v][1], (unsigned)(e * 3072 + sp * 512));
     Dw3Split& d = grad ? R.gs[e] : R.xs[e];
@@ -615,10 +618,11 @@ __device__ __forceinline__ void dw3s_frag(int F, Dw3sRegs& R, const unsigned (&g
 }
 // (v_dot2c_f32_bf16 against (1, 1) would be one instruction per pair, but its result is not the fp32 sum: measured 20-40 %
 // off on the bias gradients; unpack and add instead — the VALU is idle beside the MFMAs)
+template <int TERMS>
 __device__ __forceinline__ float dw3s_colsum(const Dw3Split& g, int d, float acc) {  // dword d: two of the lane's 8 rays
     const u32x4 l = __builtin_bit_cast(u32x4, g.l), m = __builtin_bit_cast(u32x4, g.m), h = __builtin_bit_cast(u32x4, g.h);
-    const float v0 = (dw3_lo(l[d]) + dw3_lo(m[d])) + dw3_lo(h[d]);
-    const float v1 = (dw3_hi(l[d]) + dw3_hi(m[d])) + dw3_hi(h[d]);
+    const float v0 = TERMS == 6 ? (dw3_lo(l[d]) + dw3_lo(m[d])) + dw3_lo(h[d]) : dw3_lo(m[d]) + dw3_lo(h[d]);
+    const float v1 = TERMS == 6 ? (dw3_hi(l[d]) + dw3_hi(m[d])) + dw3_hi(h[d]) : dw3_hi(m[d]) + dw3_hi(h[d]);
     acc += v0;
     acc += v1;
     return acc;
@@ -630,6 +634,7 @@ __device__ __forceinline__ void dw3s_dma16(u32x4 rsrc, unsigned voff, unsigned s
                  : "memory");
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char img[DW3S_NBUF][DW3S_BUF_BYTES];
     const int lane = threadIdx.x & 63;
@@ -722,18 +727,33 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a
                     ap[v][t] = ab0[v][t] + bo;
                 }
 #pragma unroll
-            for (int g = 0; g < 24; ++g) {
-                const int eo = g / 6, term = g % 6;
-                // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-                const dw3_bf16x8& ga = (term == 0) ? C.gs[eo].l : (term == 2 || term == 3) ? C.gs[eo].m : C.gs[eo].h;
+            for (int g = 0; g < 4 * TERMS; ++g) {
+                const int eo = g / TERMS, term = g % TERMS;
+                // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h);  TERMS == 3: the last three
+                const int tk = TERMS == 6 ? term : term + 3;
+                const dw3_bf16x8& ga = (tk == 0) ? C.gs[eo].l : (tk == 2 || tk == 3) ? C.gs[eo].m : C.gs[eo].h;
 #pragma unroll
                 for (int ei = 0; ei < 4; ++ei) {
-                    const dw3_bf16x8& xb = (term == 1) ? C.xs[ei].l : (term == 2 || term == 4) ? C.xs[ei].m : C.xs[ei].h;
+                    const dw3_bf16x8& xb = (tk == 1) ? C.xs[ei].l : (tk == 2 || tk == 4) ? C.xs[ei].m : C.xs[ei].h;
                     acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb, acc[eo][ei], 0, 0, 0);
                 }
-                dw3s_frag(g, Nx, gp, ap);
-                if ((g & 1) == 0) piece(s + 3, buf, g >> 1);
-                if (wi == 0 && term < 4) bsum[eo] = dw3s_colsum(C.gs[eo], term, bsum[eo]);  // a quarter per group
+                if (TERMS == 6) {
+                    dw3s_frag<6>(g, Nx, gp, ap);
+                    if ((g & 1) == 0) piece(s + 3, buf, g >> 1);
+                    if (wi == 0 && term < 4) bsum[eo] = dw3s_colsum<6>(C.gs[eo], term, bsum[eo]);  // a quarter per group
+                } else {  // 12 groups: 16 fragments, 12 pieces
+                    if (g < 4) {
+                        dw3s_frag<3>(2 * g, Nx, gp, ap);
+                        dw3s_frag<3>(2 * g + 1, Nx, gp, ap);
+                    } else {
+                        dw3s_frag<3>(g + 4, Nx, gp, ap);
+                    }
+                    piece(s + 3, buf, g);
+                    if (wi == 0) {
+                        bsum[eo] = dw3s_colsum<3>(C.gs[eo], term, bsum[eo]);
+                        if (term == 2) bsum[eo] = dw3s_colsum<3>(C.gs[eo], 3, bsum[eo]);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -748,7 +768,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a
             asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             __syncthreads();
 #pragma unroll
-            for (int F = 0; F < 24; ++F) dw3s_frag(F, RA, gb0, ab0);  // step 0 from buffer 0
+            for (int F = 0; F < (TERMS == 6 ? 24 : 16); ++F) dw3s_frag<TERMS>(F, RA, gb0, ab0);  // step 0 from buffer 0
             int buf = 0;
             for (int s = 0; s < nsteps; s += 2) {
                 step(RA, RB, s, buf);
@@ -1151,7 +1171,8 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         a.slab = (a.units_per_wg <= a.units_per_layer) ? dw_slab : nullptr;
         // bf16 matrix pipe at fp32 accuracy: operands already split by the chains (split stash), or split on the fly from
         // the row-major fp32 stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
-        if (split) hipLaunchKernelGGL(r2l_dw_body3s_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        if (split && r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_dw_body3s_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        else if (split) hipLaunchKernelGGL(r2l_dw_body3s_kernel<6>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else if (r2l_use_fwd3()) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());

@@ -112,6 +112,7 @@ struct B3TakeU {  // u values masked by relu'(t_b)
     }
 };
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[B3_NBUF][F3_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     }
 
     // ---- weight staging (5 buffers: 32 KiB of LDS go to the mask ring) --------------------------------------------------------
-    typedef F3PipeT<B3_NBUF> Pipe;
+    typedef F3PipeT<B3_NBUF, TERMS> Pipe;
     Pipe P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
@@ -308,7 +309,8 @@ int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, 
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    hipLaunchKernelGGL(r2l_bwd3_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    if (r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_bwd3_kernel<3>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(r2l_bwd3_kernel<6>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

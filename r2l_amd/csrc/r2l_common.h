@@ -408,6 +408,14 @@ static inline bool r2l_stash_split(int64_t N, bool pre_embedded) {
     return !pre_embedded && N > 0 && r2l_chain_variant(N) == R2L_VARIANT_MAIN && r2l_use_fwd3();
 }
 
+// bf16 products per fp32 product in the GRADIENT GEMMs of the bf16x3 trio (dX chain, dW body): 6 = fp32-accurate (default);
+// R2L_GRAD_TERMS=3 in the environment keeps the three largest (operands to 16 mantissa bits, product error ~2^-16: between
+// TF32 and fp32) at half the matrix work.  The forward always uses 6.
+static inline int r2l_grad_terms() {
+    const char* e = getenv("R2L_GRAD_TERMS");
+    return (e && e[0] == '3') ? 3 : 6;
+}
+
 // error plumbing shared by the C-ABI translation units
 extern "C" const char* r2l_last_error(void);
 void r2l_set_error(const char* what, hipError_t e);
