@@ -567,76 +567,98 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3_kernel(const R2LDwArgs a)
 }
 
 // =================================================================================================================
-// The same GEMMs fed from the SPLIT stash of the bf16x3 chains (r2l_common.h): the chains stored every operand value as the
-// bf16 (hi, mid, lo) triple they used themselves, so no VALU work is left here.  What is left is a transpose: the stash is
-// feature-contiguous per ray (the chains' k runs over features), the weight gradient's k runs over rays.
-//   * one k-step = 16 rays (half a tile).  Per operand the 48 pieces (k-block kb, split) of the half tile, 512 B each, are
-//     copied to LDS by DMA (buffer_load ... lds, 1 KiB = two pieces per instruction, all four waves share the image; three
-//     step buffers, one barrier per step);
-//   * the MFMA operands (lane = feature, 8 consecutive rays in its 16 bytes) come out of LDS through ds_read_b64_tr_b16:
-//     within a 16-lane group lane L = 4*row + q supplies the address of four consecutive bf16 (ray row, feature quad q) and
-//     lane l receives rows 0..3 of column l — 4 rays of feature l (measured: tools/tr_probe.hip).  A k-block holds 16
-//     features as quads (s>>2, h): q = 2*(s>>2) + h gives output lane l = feature 16 kb + l, the natural order;
-//   * LDS image of a piece (kb, split), pc = 3 kb + split: [h][pos][16 B] with pos = (ray + 8 h + 4 (pc & 1)) & 15 — the
-//     rotation spreads the 32 lanes of a read pass (two k-blocks x two h x four rays) over all banks;
-//   * db: the G operands unpacked and added on the VALU (waves wi == 0).
+// The same GEMMs fed from the CHUNKED fp32 stash of the bf16x3 chains (r2l_common.h), every operand value split ONCE per
+// workgroup.  (r2l_dw_body3_kernel lets each wave load and split its own operands: every value is split by two waves, and
+// the split — ~6 VALU instructions per value — is what bounds it.)
+//   * one k-step = 16 rays (half a tile): per operand 32 chunks x 512 contiguous bytes.  Wave w loads chunks 8w .. 8w+7 of
+//     both operands (8 x 16 B per lane: lane = (chunk parity, ray, half chunk) -> 4 consecutive features of one ray),
+//     splits them into bf16 (hi, mid, lo) (packed v_cvt_pk_bf16_f32, shift / mask, subtract) and writes the three 8-byte
+//     quads into the step image in LDS: [split][chunk][slot S][8 B];
+//   * the MFMA operands (lane = feature, 8 consecutive rays in its 16 bytes) come out of the image through
+//     ds_read_b64_tr_b16: within a 16-lane group lane L = 4*row + q supplies the address of four consecutive bf16 (ray row,
+//     feature quad q) and lane l receives rows 0..3 of column l — 4 rays of feature l (measured: tools/tr_probe.hip);
+//   * slot S of (ray, quad fq = 2 chunk + half) = half*16 + ((ray + 4 (chunk & 3)) & 15): the 32 lanes of a read pass (two
+//     16-feature blocks x four quads x four rays) and of a write pass (16 rays x two halves) hit 32 different 8-byte slots;
+//   * software pipeline per step s (two images, one barrier per step): the 4 x TERMS groups of four MFMAs of step s carry
+//     along the transposing reads of step s+1 (image s+1 -> registers), the split + LDS write of step s+2 (raw registers ->
+//     image s+2, which takes the buffer of image s) and the global loads of step s+3 (in place into the raw registers, one
+//     step of latency cover; inline asm with hand-placed vmcnt(7) waits: hipcc would drain vmcnt to 0 at the loop header);
+//   * db: the loader lanes add up their raw fp32 gradient quads (4 adds per quad); the 16 rays of a quad column are
+//     combined by xor-shuffles at the flush.
 // Work split, accumulators and the slab reduce are those of r2l_dw_body_kernel; tile eo of a wave's 128-feature slice is
-// features 32 eo .. 32 eo + 31 here (row m of the MFMA result = feature 32 eo + m).
+// features 32 eo .. 32 eo + 31 here (row m of the MFMA result = feature 32 eo + m).  TERMS == 3 (R2L_GRAD_TERMS=3): only
+// the (m,h) (h,m) (h,h) products, no lo split.
 // =================================================================================================================
-#define DW3S_OP_BYTES 24576   // one operand, one step: 48 pieces x 512 B
-#define DW3S_BUF_BYTES 49152  // G image, A image
-#define DW3S_NBUF 3
-typedef short dw3s_s16x4 __attribute__((ext_vector_type(4)));
+#define DW3C_OP_BYTES 24576   // one operand, one step: 3 splits x 32 chunks x 256 B
+#define DW3C_BUF_BYTES 49152  // G image, A image
+typedef short dw3c_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dw3c_u32x2 __attribute__((ext_vector_type(2)));
 
 // 8 rays of this lane's feature: two transposing reads (rays 8hh + 0..3 at p0, 8hh + 4..7 at p1), byte offset off (a constant
 // after unrolling: it ends up in the instruction's offset field)
-__device__ __forceinline__ dw3_bf16x8 dw3s_read(unsigned p0, unsigned p1, unsigned off) {
-    typedef __attribute__((address_space(3))) dw3s_s16x4 lds_v;
-    const dw3s_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(size_t)(p0 + off));
-    const dw3s_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(size_t)(p1 + off));
+__device__ __forceinline__ dw3_bf16x8 dw3c_read(unsigned p0, unsigned p1, unsigned off) {
+    typedef __attribute__((address_space(3))) dw3c_s16x4 lds_v;
+    const dw3c_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(size_t)(p0 + off));
+    const dw3c_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(size_t)(p1 + off));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(dw3_bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 // the operand registers of one k-step: gs = tiles of the gradient operand (MFMA A), xs = tiles of the activation operand
-struct Dw3sRegs {
+struct Dw3cRegs {
     Dw3Split gs[4], xs[4];
 };
 // fragment F of a step (TERMS == 6: 24 fragments, F < 12: activation tile F/3, split F%3, else gradient tile (F-12)/3, split
-// (F-12)%3;  TERMS == 3: the lo splits are not used: 16 fragments, F < 8: activation tile F/2, split F%2, else gradient);
-// gp / ap [v][t]: lane bases in the G / A image for rotation variant v = split & 1 and ray quad t
+// (F-12)%3;  TERMS == 3: 16 fragments, F < 8: activation tile F/2, split F%2, else gradient);  gp / ap [t]: lane bases in the
+// G / A image for ray quad t
 template <int TERMS>
-__device__ __forceinline__ void dw3s_frag(int F, Dw3sRegs& R, const unsigned (&gp)[2][2], const unsigned (&ap)[2][2]) {
+__device__ __forceinline__ void dw3c_frag(int F, Dw3cRegs& R, const unsigned (&gp)[2], const unsigned (&ap)[2]) {
     constexpr int NS = TERMS == 6 ? 3 : 2;
     const bool grad = F >= 4 * NS;
-    const int f = grad ? F - 4 * NS : F, e = f / NS, sp = f % NS, v = sp & 1;
-    const dw3_bf16x8 val = grad ? dw3s_read(gp[v][0], gp[v][1], (unsigned)(e * 3072 + sp * 512))
-                                : dw3s_read(ap[v][0], ap[v][1], (unsigned)(e * 3072 + sp * 512));
+    const int f = grad ? F - 4 * NS : F, e = f / NS, sp = f % NS;
+    const dw3_bf16x8 val = grad ? dw3c_read(gp[0], gp[1], (unsigned)(e * 1024 + sp * 8192))
+                                : dw3c_read(ap[0], ap[1], (unsigned)(e * 1024 + sp * 8192));
     Dw3Split& d = grad ? R.gs[e] : R.xs[e];
     if (sp == 0) d.h = val;
     else if (sp == 1) d.m = val;
     else d.l = val;
 }
-// (v_dot2c_f32_bf16 against (1, 1) would be one instruction per pair, but its result is not the fp32 sum: measured 20-40 %
-// off on the bias gradients; unpack and add instead — the VALU is idle beside the MFMAs)
-template <int TERMS>
-__device__ __forceinline__ float dw3s_colsum(const Dw3Split& g, int d, float acc) {  // dword d: two of the lane's 8 rays
-    const u32x4 l = __builtin_bit_cast(u32x4, g.l), m = __builtin_bit_cast(u32x4, g.m), h = __builtin_bit_cast(u32x4, g.h);
-    const float v0 = TERMS == 6 ? (dw3_lo(l[d]) + dw3_lo(m[d])) + dw3_lo(h[d]) : dw3_lo(m[d]) + dw3_lo(h[d]);
-    const float v1 = TERMS == 6 ? (dw3_hi(l[d]) + dw3_hi(m[d])) + dw3_hi(h[d]) : dw3_hi(m[d]) + dw3_hi(h[d]);
-    acc += v0;
-    acc += v1;
-    return acc;
+// 16-byte global load the compiler does not track (so that it does not wait for it at loop headers): the consumer waits
+// with dw3c_wait7 — the loads retire in order and exactly 7 younger ones are in flight at every use
+__device__ __forceinline__ void dw3c_load(f32x4& dst, u32x4 rsrc, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
-__device__ __forceinline__ void dw3s_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
+__device__ __forceinline__ void dw3c_wait7(f32x4& v) { asm volatile("s_waitcnt vmcnt(7)" : "+v"(v)::"memory"); }
+__device__ __forceinline__ void dw3c_wait0(f32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); }
+// split state of one raw quad (4 features of one ray)
+struct Dw3cQuad {
+    float r[4];
+    unsigned uh[2], um[2], ul[2];
+};
+// part 0: hi + first residual; part 1: mid + second residual; part 2: lo  (TERMS == 3: parts 0, 1 only)
+__device__ __forceinline__ void dw3c_split_part(Dw3cQuad& q, const f32x4& x, int part) {
+    if (part == 0) {
+        q.uh[0] = dw3_pk(x[0], x[1]);
+        q.uh[1] = dw3_pk(x[2], x[3]);
+        q.r[0] = x[0] - dw3_lo(q.uh[0]); q.r[1] = x[1] - dw3_hi(q.uh[0]);
+        q.r[2] = x[2] - dw3_lo(q.uh[1]); q.r[3] = x[3] - dw3_hi(q.uh[1]);
+    } else if (part == 1) {
+        q.um[0] = dw3_pk(q.r[0], q.r[1]);
+        q.um[1] = dw3_pk(q.r[2], q.r[3]);
+        q.r[0] -= dw3_lo(q.um[0]); q.r[1] -= dw3_hi(q.um[0]);
+        q.r[2] -= dw3_lo(q.um[1]); q.r[3] -= dw3_hi(q.um[1]);
+    } else {
+        q.ul[0] = dw3_pk(q.r[0], q.r[1]);
+        q.ul[1] = dw3_pk(q.r[2], q.r[3]);
+    }
+}
+__device__ __forceinline__ void dw3c_write(unsigned addr, unsigned d0, unsigned d1) {
+    typedef __attribute__((address_space(3))) dw3c_u32x2 lds_u2;
+    *(lds_u2*)(size_t)addr = dw3c_u32x2{d0, d1};
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char img[DW3S_NBUF][DW3S_BUF_BYTES];
+__global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char img[2][DW3C_BUF_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wo = wave >> 1, wi = wave & 1;
@@ -653,28 +675,36 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a
         for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[eo][ei][c] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bacc[4];  // db partials of this loader lane: gradient chunk pair kk, its 4 features, summed over its ray column
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t Np = R2L_PAD_ROWS(a.N);
-    const int64_t slot = Np * R2L_SPLIT_ROW;
-
-    // DMA source of LDS unit u = lane of an instruction (two pieces): piece parity pp, half h, rotated position pos
-    const unsigned dvoff = [&] {
-        const int pp = lane >> 5, hq = (lane >> 4) & 1, pos = lane & 15;
-        return (unsigned)(pp * 1024 + (hq * 32 + ((pos - 8 * hq - 4 * pp) & 15)) * 16);
-    }();
+    const int64_t slot = Np * R2L_W;
     const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&img[0][0];
-    // read bases: 16-lane group g = (hh, par): k-block parity par inside the tile, rays 8hh..; lane L = 4*row + q in it
-    unsigned gb0[2][2], ab0[2][2];
+
+    // loader lane: chunk parity cc inside the instruction's chunk pair, ray j of the half tile, half chunk hf
+    const int lcc = lane >> 5, lj = (lane >> 1) & 15, lhf = lane & 1;
+    const unsigned lvoff = (unsigned)(lcc * 1024 + lj * 32 + lhf * 16);
+    // its write address in an operand image for instruction kk (chunk 8 wave + 2 kk + cc): [split][chunk][S][8 B];
+    // (chunk & 3) = (2 kk + cc) & 3 -> two rotations, even / odd kk
+    unsigned wbase[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int rot = 4 * ((2 * par + lcc) & 3);
+        wbase[par] = img_lds + (unsigned)(wave * 2048 + lcc * 256 + (lhf * 16 + ((lj + rot) & 15)) * 8);
+    }
+    // read bases: 16-lane group (hh, par): 16-feature block parity par inside the tile, rays 8hh..; lane L = 4*row + q in it
+    unsigned gb0[2], ab0[2];
     {
-        const int g = lane >> 4, L = lane & 15, par = g & 1, hh = g >> 1, hf = L & 1, sh = (L >> 1) & 1, row = L >> 2;
+        const int g = lane >> 4, L = lane & 15, par = g & 1, hh = g >> 1, q = L & 3, row = L >> 2;
+        const int cl = 2 * par + (q >> 1);  // chunk inside the tile's four
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned base = (unsigned)(par * 1536 + hf * 256 + ((8 * hh + 4 * t + row + 8 * hf + 4 * ((par + v) & 1)) & 15) * 16 + sh * 8);
-                gb0[v][t] = img_lds + base + (unsigned)wo * 12288u;
-                ab0[v][t] = img_lds + DW3S_OP_BYTES + base + (unsigned)wi * 12288u;
-            }
+        for (int t = 0; t < 2; ++t) {
+            const int S = (q & 1) * 16 + ((8 * hh + 4 * t + row + 4 * (cl & 3)) & 15);
+            const unsigned base = (unsigned)(cl * 256 + S * 8);
+            gb0[t] = img_lds + base + (unsigned)wo * 4096u;
+            ab0[t] = img_lds + DW3C_OP_BYTES + base + (unsigned)wi * 4096u;
+        }
     }
 
     int64_t u = u0;
@@ -690,91 +720,103 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a
         const int64_t r0 = cu * DW_CHUNK;  // a multiple of 64 rays: two whole tiles
         int64_t r1 = cend * DW_CHUNK;
         if (r1 > Np) r1 = Np;
-        const int nsteps = (int)((r1 - r0) / 16);  // Np is a multiple of 32
-        // descriptors based at the first tile of the segment
-        const unsigned long long ga = (unsigned long long)(reinterpret_cast<const unsigned char*>(G) + (r0 / 32) * R2L_SPLIT_TILE_BYTES);
-        const unsigned long long aa = (unsigned long long)(reinterpret_cast<const unsigned char*>(A) + (r0 / 32) * R2L_SPLIT_TILE_BYTES);
+        const int nsteps = (int)((r1 - r0) / 16);  // Np is a multiple of 32: always even
+        // descriptors based at the first tile of the segment (+ this wave's eight chunks)
+        const unsigned long long ga = (unsigned long long)(G + r0 * R2L_W + wave * 8 * R2L_CHUNK_PIECE);
+        const unsigned long long aa = (unsigned long long)(A + r0 * R2L_W + wave * 8 * R2L_CHUNK_PIECE);
         const u32x4 grs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga),
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         const u32x4 ars = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)aa),
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(aa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
-        // this wave's share of a step image: instructions wave, wave + 4, .. of the 24 of each operand = 12 pieces, piece k:
-        // operand k & 1, instruction wave + 4 (k >> 1).  Steps past the end are clamped to the last one (harmless reloads:
-        // every step issues exactly 12 loads, which keeps the vmcnt arithmetic uniform)
-        auto piece = [&](int s, int buf, int k) {
+        // raw quad k of a step: k < 4 gradient chunk pair k, else activation chunk pair k - 4.  Steps past the end are
+        // clamped to the last one (harmless reloads: every step issues exactly 8 loads, which keeps vmcnt(7) uniform)
+        f32x4 raw[8];
+        auto load = [&](int s, int k) {
             const int sc = s < nsteps ? s : nsteps - 1;
-            const unsigned so = (unsigned)(sc >> 1) * (unsigned)R2L_SPLIT_TILE_BYTES + (unsigned)(sc & 1) * 256u +
-                                (unsigned)wave * 2048u + (unsigned)(k >> 1) * 8192u;
-            const unsigned la = img_lds + (unsigned)buf * DW3S_BUF_BYTES + (unsigned)wave * 1024u + (unsigned)(k >> 1) * 4096u;
-            if (k & 1) dw3s_dma16(ars, dvoff, so, la + DW3S_OP_BYTES);
-            else dw3s_dma16(grs, dvoff, so, la);
+            const unsigned so = (unsigned)(sc >> 1) * (unsigned)(R2L_CHUNK_TILE * 4) + (unsigned)(sc & 1) * 512u + (unsigned)(k & 3) * 2048u;
+            dw3c_load(raw[k], (k < 4) ? grs : ars, lvoff, so);
         };
-        // One k-step: 96 MFMAs on the registers C (read from LDS during the previous step); riding along, one per group of
-        // four MFMAs: a fragment of step s+1 (LDS -> registers Nx), every other group a DMA piece of step s+3 (HBM -> the
-        // LDS buffer step s occupied: every wave finished reading it before this step's barrier).
-        auto step = [&](Dw3sRegs& C, Dw3sRegs& Nx, int s, int buf) {
-            // the own pieces of step s+1 (the 12 of step s+2 may still fly), then everybody's; lgkmcnt(0) is part of the
-            // barrier: nobody's reads of buffer `buf` are pending any more
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        Dw3cQuad qs;
+        // parts of the split of raw quad k into the image in buffer `buf`; the last part writes the quads and reloads raw[k]
+        // with the data of step s_next
+        auto quad_part = [&](int k, int part, int buf, int s_next) {
+            if (part == 0) {
+                dw3c_wait7(raw[k]);
+                // (raw holds step s_next - 1: a clamped reload past the end must not be counted)
+                if (k < 4) bacc[k] += raw[k] * ((s_next - 1 < nsteps) ? 1.f : 0.f);
+            }
+            dw3c_split_part(qs, raw[k], part);
+            if (part == (TERMS == 6 ? 2 : 1)) {
+                const unsigned wa = wbase[k & 1] + (unsigned)buf * DW3C_BUF_BYTES + (unsigned)(k >> 2) * DW3C_OP_BYTES + (unsigned)(k & 3) * 512u;
+                dw3c_write(wa, qs.uh[0], qs.uh[1]);
+                dw3c_write(wa + 8192u, qs.um[0], qs.um[1]);
+                if (TERMS == 6) dw3c_write(wa + 16384u, qs.ul[0], qs.ul[1]);
+                load(s_next, k);
+            }
+        };
+        // One k-step: 16 x TERMS MFMAs on the registers C; riding along, per group of four MFMAs: fragments of step s+1 (LDS
+        // image s+1 -> registers Nx) and a part of the split of step s+2 (raw -> image s+2 in the buffer image s occupied;
+        // raw reloaded with step s+3)
+        auto step = [&](Dw3cRegs& C, Dw3cRegs& Nx, int s, int buf) {
+            // image s+1 is complete (everybody wrote its share during step s-1) and nobody reads image s any more
             __syncthreads();
-            const unsigned bo = (unsigned)(buf == DW3S_NBUF - 1 ? 0 : buf + 1) * DW3S_BUF_BYTES;  // image of step s+1
-            unsigned gp[2][2], ap[2][2];
-#pragma unroll
-            for (int v = 0; v < 2; ++v)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    gp[v][t] = gb0[v][t] + bo;
-                    ap[v][t] = ab0[v][t] + bo;
-                }
+            const unsigned bo = (unsigned)(buf ^ 1) * DW3C_BUF_BYTES;  // image of step s+1
+            const unsigned gp[2] = {gb0[0] + bo, gb0[1] + bo}, ap[2] = {ab0[0] + bo, ab0[1] + bo};
 #pragma unroll
             for (int g = 0; g < 4 * TERMS; ++g) {
                 const int eo = g / TERMS, term = g % TERMS;
                 // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h);  TERMS == 3: the last three
                 const int tk = TERMS == 6 ? term : term + 3;
-                const dw3_bf16x8& ga = (tk == 0) ? C.gs[eo].l : (tk == 2 || tk == 3) ? C.gs[eo].m : C.gs[eo].h;
+                const dw3_bf16x8& ga2 = (tk == 0) ? C.gs[eo].l : (tk == 2 || tk == 3) ? C.gs[eo].m : C.gs[eo].h;
 #pragma unroll
                 for (int ei = 0; ei < 4; ++ei) {
                     const dw3_bf16x8& xb = (tk == 1) ? C.xs[ei].l : (tk == 2 || tk == 4) ? C.xs[ei].m : C.xs[ei].h;
-                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb, acc[eo][ei], 0, 0, 0);
+                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga2, xb, acc[eo][ei], 0, 0, 0);
                 }
-                if (TERMS == 6) {
-                    dw3s_frag<6>(g, Nx, gp, ap);
-                    if ((g & 1) == 0) piece(s + 3, buf, g >> 1);
-                    if (wi == 0 && term < 4) bsum[eo] = dw3s_colsum<6>(C.gs[eo], term, bsum[eo]);  // a quarter per group
-                } else {  // 12 groups: 16 fragments, 12 pieces
+                if (TERMS == 6) {  // 24 groups: 24 fragments, 8 quads x 3 parts
+                    dw3c_frag<6>(g, Nx, gp, ap);
+                    quad_part(g / 3, g % 3, buf, s + 3);
+                } else {  // 12 groups: 16 fragments, 8 quads x 2 parts
                     if (g < 4) {
-                        dw3s_frag<3>(2 * g, Nx, gp, ap);
-                        dw3s_frag<3>(2 * g + 1, Nx, gp, ap);
+                        dw3c_frag<3>(2 * g, Nx, gp, ap);
+                        dw3c_frag<3>(2 * g + 1, Nx, gp, ap);
+                        quad_part(g, 0, buf, s + 3);
+                        quad_part(g, 1, buf, s + 3);
                     } else {
-                        dw3s_frag<3>(g + 4, Nx, gp, ap);
-                    }
-                    piece(s + 3, buf, g);
-                    if (wi == 0) {
-                        bsum[eo] = dw3s_colsum<3>(C.gs[eo], term, bsum[eo]);
-                        if (term == 2) bsum[eo] = dw3s_colsum<3>(C.gs[eo], 3, bsum[eo]);
+                        dw3c_frag<3>(g + 4, Nx, gp, ap);
+                        quad_part(4 + (g - 4) / 2, (g - 4) % 2, buf, s + 3);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (nsteps > 0) {  // (always even: 64-ray units, Np a multiple of 32)
-            Dw3sRegs RA, RB;
+        if (nsteps > 0) {
+            Dw3cRegs RA, RB;
+            // prologue: images 0 and 1, raw = step 2 (latencies exposed once per segment)
 #pragma unroll
-            for (int k = 0; k < 12; ++k) piece(0, 0, k);
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) piece(1, 1, k);
+                for (int k = 0; k < 8; ++k) load(s, k);
 #pragma unroll
-            for (int k = 0; k < 12; ++k) piece(2, 2, k);
-            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                for (int k = 0; k < 8; ++k) {
+                    dw3c_wait0(raw[k]);
+                    if (k < 4) bacc[k] += raw[k];
+#pragma unroll
+                    for (int part = 0; part < (TERMS == 6 ? 3 : 2); ++part) dw3c_split_part(qs, raw[k], part);
+                    const unsigned wa = wbase[k & 1] + (unsigned)s * DW3C_BUF_BYTES + (unsigned)(k >> 2) * DW3C_OP_BYTES + (unsigned)(k & 3) * 512u;
+                    dw3c_write(wa, qs.uh[0], qs.uh[1]);
+                    dw3c_write(wa + 8192u, qs.um[0], qs.um[1]);
+                    if (TERMS == 6) dw3c_write(wa + 16384u, qs.ul[0], qs.ul[1]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) load(2, k);
             __syncthreads();
 #pragma unroll
-            for (int F = 0; F < (TERMS == 6 ? 24 : 16); ++F) dw3s_frag<TERMS>(F, RA, gb0, ab0);  // step 0 from buffer 0
-            int buf = 0;
+            for (int F = 0; F < (TERMS == 6 ? 24 : 16); ++F) dw3c_frag<TERMS>(F, RA, gb0, ab0);  // step 0 from buffer 0
             for (int s = 0; s < nsteps; s += 2) {
-                step(RA, RB, s, buf);
-                buf = (buf == DW3S_NBUF - 1) ? 0 : buf + 1;
-                step(RB, RA, s + 1, buf);
-                buf = (buf == DW3S_NBUF - 1) ? 0 : buf + 1;
+                step(RA, RB, s, 0);
+                step(RB, RA, s + 1, 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // the images are dead (and the clamped reloads landed) before the next segment refills them
@@ -808,16 +850,23 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3s_kernel(const R2LDwArgs a
                             acc[eo][ei][c] = 0.f;
                         }
             }
-            if (wi == 0) {
+            // db: loader lane (cc, j, hf) holds, for kk = 0..3, features 8 (8 wave + 2 kk + cc) + 4 hf .. +3 summed over its ray
+            // column j; the 16 columns sit in lane bits 1..4
 #pragma unroll
-                for (int eo = 0; eo < 4; ++eo) {
-                    const float sv = bsum[eo] + __shfl_xor(bsum[eo], 32);
-                    if (hh == 0) {
-                        if (sl != nullptr) sl[R2L_W * R2L_W + wo * 128 + 32 * eo + n] = sv;
-                        else atomicAdd(gbias + wo * 128 + 32 * eo + n, sv);
-                    }
-                    bsum[eo] = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                f32x4 v = bacc[k];
+#pragma unroll
+                for (int m = 2; m <= 16; m <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], m);
+                if (lj == 0) {
+                    const int f = 8 * (8 * wave + 2 * k + lcc) + 4 * lhf;
+                    if (sl != nullptr) *reinterpret_cast<f32x4*>(sl + R2L_W * R2L_W + f) = v;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(gbias + f + e, v[e]);
                 }
+                bacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         u += cend - cu;
@@ -1110,7 +1159,7 @@ __global__ __launch_bounds__(256) void r2l_tail_reduce_kernel(const float* __res
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS; }
-extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_PAD_ROWS(N) * (int64_t)R2L_SPLIT_ROW; }
+extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_PAD_ROWS(N) * (int64_t)R2L_W; }
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
@@ -1132,8 +1181,8 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
     const int n_cu = n_cu_cached;
     // 1. dX chain
     const int variant = r2l_chain_variant(N);
-    // the bf16x3 trio (r2l_fwd3 wrote the stash): split stash layout, see r2l_common.h
-    const bool split = r2l_stash_split(N, emb != nullptr);
+    // the bf16x3 trio (r2l_fwd3 wrote the stash): chunked stash layout, see r2l_common.h
+    const bool split = r2l_stash_chunked(N, emb != nullptr);
     if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
                                            params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
@@ -1169,10 +1218,10 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         wgs = (total + a.units_per_wg - 1) / a.units_per_wg;
         // units_per_wg <= units_per_layer whenever wgs >= 2*n_block (always, for n_block <= 128): a range touches <= 2 layers
         a.slab = (a.units_per_wg <= a.units_per_layer) ? dw_slab : nullptr;
-        // bf16 matrix pipe at fp32 accuracy: operands already split by the chains (split stash), or split on the fly from
-        // the row-major fp32 stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
-        if (split && r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_dw_body3s_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
-        else if (split) hipLaunchKernelGGL(r2l_dw_body3s_kernel<6>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        // bf16 matrix pipe at fp32 accuracy: operands split once per workgroup from the chunked stash of the bf16x3 chains
+        // (r2l_dw_body3c), or per wave from the row-major stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
+        if (split && r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_dw_body3c_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        else if (split) hipLaunchKernelGGL(r2l_dw_body3c_kernel<6>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else if (r2l_use_fwd3()) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());
@@ -1219,10 +1268,9 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         // partials behind the head's slab region; summed in workgroup order
         float* part = (dw_slab != nullptr && DW_HEAD_SLAB_MAX + wgs * (4 * R2L_W) <= r2l_dw_slab_floats())
                           ? dw_slab + DW_HEAD_SLAB_MAX : nullptr;
-        // (split stash: slot n of save_x, at the split slot stride, holds y = x_n + x_0)
+        // (chunked stash: slot n of save_x holds y = x_n + x_0)
         hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, split ? nullptr : save_x,
-                           save_x + (int64_t)n_block * R2L_PAD_ROWS(N) * (split ? R2L_SPLIT_ROW : R2L_W), grads, part, n_block,
-                           N, per);
+                           save_x + (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W, grads, part, n_block, N, per);
         R2L_CHECK(hipGetLastError());
         if (part != nullptr) {
             hipLaunchKernelGGL(r2l_tail_reduce_kernel, dim3(R2L_W / 32, 4), dim3(256), 0, stream, part, wgs, grads, n_block);

@@ -73,42 +73,43 @@ struct B3Args {
     int64_t N;
 };
 
-// mask piece kb = 2T + r of the block: the hi split of relu(t_b) for the fragment registers 8r .. 8r+7 of tile T (eight bf16
-// per lane, non-negative: relu(t) > 0 <=> its bf16 hi part is not zero) -> bits (T&1)*16 + 8r .. +7 of word T>>1
-__device__ __forceinline__ void b3_fold(unsigned (&mb)[4], const unsigned char* ring_lane, int kb) {
-    const u32x4 p = *reinterpret_cast<const u32x4*>(ring_lane + (kb % B3_RING) * 1024);
-    unsigned bits = 0u;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-        bits |= ((p[d] & 0x7fffu) ? 1u : 0u) << (2 * d) | ((p[d] & 0x7fff0000u) ? 2u : 0u) << (2 * d);
-    const int T = kb >> 1, r = kb & 1;
-    mb[T >> 1] |= bits << ((T & 1) * 16 + 8 * r);
+// mask piece pi = 4T + q of the block (fragment registers 4q .. 4q+3 of tile T) -> bits (T&1)*16 + 4q .. +3 of word T>>1
+__device__ __forceinline__ void b3_fold(unsigned (&mb)[4], const unsigned char* ring_lane, int pi) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(ring_lane + (pi % B3_RING) * 1024);
+    const unsigned bits = (p[0] > 0.f ? 1u : 0u) | (p[1] > 0.f ? 2u : 0u) | (p[2] > 0.f ? 4u : 0u) | (p[3] > 0.f ? 8u : 0u);
+    const int T = pi >> 2, q = pi & 3;
+    mb[T >> 1] |= bits << ((T & 1) * 16 + 4 * q);
 }
-// gatherers: four B values of the next stage (+ the mask piece that is due in this half stage)
-struct B3TakeG {  // g values (identity)
+// gatherers: four B values of the next stage (+ their stash store, + the mask piece that is due in this half stage)
+struct B3TakeG {  // g values (identity), stored to gx[b+1]
     const f32x16& frag;
     int c0;
-    unsigned (&mb)[4];
-    const unsigned char* ring_lane;
-    int fold_kb;  // mask piece to fold here, or -1
-    __device__ __forceinline__ void operator()(float (&v)[4]) const {
-        if (fold_kb >= 0) b3_fold(mb, ring_lane, fold_kb);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = frag[c0 + s];
-    }
-};
-struct B3TakeU {  // u values masked by relu'(t_b)
-    const f32x16& frag;
-    int c0;
+    float* stash;  // lane base (r2l_chunk_lane) in the gx slot: chunked layout
     int T;
     unsigned (&mb)[4];
     const unsigned char* ring_lane;
-    int fold_kb;
+    int fold_pi;  // mask piece to fold here, or -1
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
-        if (fold_kb >= 0) b3_fold(mb, ring_lane, fold_kb);
+        if (fold_pi >= 0) b3_fold(mb, ring_lane, fold_pi);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = frag[c0 + s];
+        r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
+    }
+};
+struct B3TakeU {  // u values masked by relu'(t_b), stored to gt[b]
+    const f32x16& frag;
+    int c0;
+    float* stash;
+    int T;
+    unsigned (&mb)[4];
+    const unsigned char* ring_lane;
+    int fold_pi;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        if (fold_pi >= 0) b3_fold(mb, ring_lane, fold_pi);
         const unsigned w = mb[T >> 1] >> ((T & 1) * 16 + c0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = ((w >> s) & 1u) ? frag[c0 + s] : 0.f;
+        r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
     }
 };
 
@@ -213,10 +214,10 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&mring[0][0][0] +
                               (unsigned)wave * (B3_RING * 1024u);
     const unsigned char* ring_lane = &mring[0][0][0] + wave * (B3_RING * 1024) + lane * 16;
-    // byte offset of this lane's 16 bytes in the first piece of its tile (split layout, r2l_common.h)
-    const int64_t lane_off = tile * R2L_SPLIT_TILE_BYTES + lane * 16;
-    const unsigned mvoff = (unsigned)lane_off;
-    const int64_t slot = Np * R2L_SPLIT_ROW;  // floats
+    // byte offset of this lane's base in a (chunked) slot; mask piece pi lies 1 KiB * pi behind it
+    const int64_t lane_off = r2l_chunk_lane(tile, lane & 31, h);
+    const unsigned mvoff = (unsigned)(lane_off * 4);
+    const int64_t slot = Np * R2L_W;
 
 #pragma unroll 1
     for (int b = a.n_block - 1; b >= 0; --b) {
@@ -226,67 +227,54 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
         const u32x4 trs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta),
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ta >> 32)) & 0xffffu, 0xffffffffu,
                            0x00020000u};
-        unsigned char* gxs = reinterpret_cast<unsigned char*>(a.gx + (int64_t)(b + 1) * slot) + lane_off;
-        unsigned char* gts = reinterpret_cast<unsigned char*>(a.gt + (int64_t)b * slot) + lane_off;
-        // half stage rho of the block (0..67): the sixteen mask pieces (hi split of relu(t_b), one per k-block) are fetched
-        // by DMA in the even half stages 0 .. 30 and folded four stages later (kb >= 12: five — the stage 16 gathers
-        // nothing, its successor is a zero stage);  first use of piece kb: rho = 34 + 2 kb
-#define B3_ISSUE(RHO) (((RHO) < 32 && (RHO) % 2 == 0) ? (RHO) / 2 : -1)
-#define B3_FOLD(RHO)                                                       \
-    (((RHO) >= 8 && (RHO) < 32 && (RHO) % 2 == 0) ? ((RHO) - 8) / 2         \
-                                                  : (((RHO) >= 34 && (RHO) < 42 && (RHO) % 2 == 0) ? ((RHO) - 10) / 2 : -1))
-#define B3_EXTRA(RHO)                                                                                              \
-    F3Dma{B3_ISSUE(RHO) >= 0, trs, mvoff, (unsigned)(B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) * R2L_SPLIT_KB_BYTES,  \
+        float* gxs = a.gx + (int64_t)(b + 1) * slot + lane_off;
+        float* gts = a.gt + (int64_t)b * slot + lane_off;
+        // half stage rho of the block (0..67): DMA of mask piece issue_pi(rho), fold of piece fold_pi(rho)
+        //   issue: piece pi at rho = pi (pi < 24) or pi + 2 (the half stages 24, 25 are skipped: see fold);
+        //   fold:  eight half stages after the issue -> rho = pi + 8 (pi < 24), pi + 10 (pi >= 24): never in the half stages
+        //          32, 33 (stage 16 gathers nothing: its successor is a zero stage);  first use of piece pi: rho = 34 + pi
+#define B3_ISSUE(RHO) ((RHO) < 24 ? (RHO) : (((RHO) >= 26 && (RHO) < 34) ? (RHO) - 2 : -1))
+#define B3_FOLD(RHO) (((RHO) >= 8 && (RHO) < 32) ? (RHO) - 8 : (((RHO) >= 34 && (RHO) < 42) ? (RHO) - 10 : -1))
+#define B3_EXTRA(RHO)                                                                                                   \
+    F3Dma{B3_ISSUE(RHO) >= 0, trs, mvoff, (unsigned)(B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) * (R2L_CHUNK_PIECE * 4u),  \
           ring_lds + (unsigned)((B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) % B3_RING) * 1024u}
-        const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
-        // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1.
-        // The B triple of every stage (g = dL/dx_{b+1}) is the weight-gradient operand: stashed as it stands into gx[b+1]
-        f3_stage<true, true, false>(u, P, B3TakeG{g[0], 0, mb, ring_lane, B3_FOLD(0)}, B3TakeG{g[0], 4, mb, ring_lane, B3_FOLD(1)},
-                                    B3_EXTRA(0), B3_EXTRA(1), F3Stash{gxs});
+        // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
+        f3_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0, mb, ring_lane, B3_FOLD(0)},
+                                    B3TakeG{g[0], 4, gxs, 0, mb, ring_lane, B3_FOLD(1)}, B3_EXTRA(0), B3_EXTRA(1));
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f3_stage<false, false, false>(
-                u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), mb, ring_lane, B3_FOLD(2 * kb + 2)},
-                B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, mb, ring_lane, B3_FOLD(2 * kb + 3)}, B3_EXTRA(2 * kb + 2),
-                B3_EXTRA(2 * kb + 3), F3Stash{gxs + (kb + 1) * R2L_SPLIT_KB_BYTES});
+                u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 2)},
+                B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 3)},
+                B3_EXTRA(2 * kb + 2), B3_EXTRA(2 * kb + 3));
         f3_stage<false, false, true>(u, P, F3None{}, F3None{}, B3_EXTRA(32), B3_EXTRA(33));
-        // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1;
-        // the masked u (dL/d(hidden pre-activation)) goes to gt[b]
-        f3_stage<true, false, false>(g, P, B3TakeU{u[0], 0, 0, mb, ring_lane, B3_FOLD(34)},
-                                     B3TakeU{u[0], 4, 0, mb, ring_lane, B3_FOLD(35)}, no_dma, no_dma, F3Stash{gts});
+        // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
+        f3_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb, ring_lane, B3_FOLD(34)},
+                                     B3TakeU{u[0], 4, gts, 0, mb, ring_lane, B3_FOLD(35)});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f3_stage<false, false, false>(
-                g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), (kb + 1) >> 1, mb, ring_lane, B3_FOLD(36 + 2 * kb)},
-                B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(37 + 2 * kb)}, no_dma,
-                no_dma, F3Stash{gts + (kb + 1) * R2L_SPLIT_KB_BYTES});
+                g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(36 + 2 * kb)},
+                B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(37 + 2 * kb)});
         f3_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
 #undef B3_EXTRA
 #undef B3_FOLD
 #undef B3_ISSUE
     }
 
-    // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] (row-major fp32: the head weight gradient reads rows)
+    // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] ---------------------------------------------------------
     {
-        const unsigned char* r = reinterpret_cast<const unsigned char*>(a.save_x) + lane_off;  // x_0: hi split of slot 0
-        float* o = a.gx + ray * R2L_W + 4 * h;
+        const float* r = a.save_x + lane_off;  // x_0: chunked like every slot the forward chain stashes
+        float* o = a.gx + ray * R2L_W + 4 * h;  // row-major: the head weight gradient reads rows
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const u32x4 xv = *reinterpret_cast<const u32x4*>(r + (2 * T + rr) * R2L_SPLIT_KB_BYTES);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(r + R2L_CHUNK_PIECE * (4 * T + q));
+                f32x4 ov;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    f32x4 ov;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned w = xv[2 * q + (j >> 1)];
-                        const bool on = (j & 1) ? (w & 0x7fff0000u) != 0u : (w & 0x7fffu) != 0u;
-                        const int c = 8 * rr + 4 * q + j;
-                        ov[j] = on ? g[T][c] + dy[T][c] : 0.f;
-                    }
-                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * (2 * rr + q)) = ov;
-                }
+                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? g[T][4 * q + j] + dy[T][4 * q + j] : 0.f;
+                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = ov;
             }
     }
 }

@@ -175,15 +175,21 @@ __device__ __forceinline__ void r2l_stash_store(float* p, const f32x4& v) { *rei
 __device__ __forceinline__ void r2l_stash_store_nt(float* p, const f32x4& v) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }
-// ---- split stash layout (the bf16x3 training trio r2l_fwd3 / r2l_bwd3 / r2l_dw_body3s) ----------------------------------
-// The one-wave-per-tile bf16x3 chains stash every layer input as the bf16 (hi, mid, lo) triple they computed for their own
-// MFMAs.  A slot is [tile = ray/32][k-block kb = feature/16][split 3][lane = 32h + ray%32][8 bf16], i.e. 1.5 KiB per ray
-// (slot stride R2L_SPLIT_ROW floats per row); slot s of a lane holds feature 16 kb + 8 (s>>2) + 4h + (s&3).  Each of the
-// three stores of a stage writes one contiguous KiB per wave; the weight-gradient kernel stages the pieces in LDS with DMA
-// loads and builds its ray-major MFMA operands with transposing LDS reads, without any VALU work on the operands.
-#define R2L_SPLIT_ROW 384          // floats per ray and slot
-#define R2L_SPLIT_KB_BYTES 3072    // one (tile, k-block): 3 splits x 1 KiB
-#define R2L_SPLIT_TILE_BYTES 49152 // one tile: 16 k-blocks
+// ---- chunked stash layout (the bf16x3 training trio r2l_fwd3 / r2l_bwd3 / r2l_dw_body3c) ----------------------------------
+// A [Np,256] fp32 slot is stored as [tile = ray/32][chunk = feature/8][ray%32][feature%8]: float index
+//     tile*8192 + chunk*256 + (ray%32)*8 + feature%8 .
+// The one-wave-per-tile chains hold, per lane (j, h) and fragment piece pi = 4T + c0/4, the features 8*pi + 4h .. +3 of ray j:
+// the 64 lanes of one piece store 64 x 16 B = one contiguous KiB (row-major, the same store scatters 32-byte fragments over
+// 32 rows and every 128-byte line is written by four different instructions).  The weight-gradient kernel loads the half
+// tile of a chunk (16 rays x 32 B) as one 512-byte run.
+#define R2L_CHUNK_PIECE 256   // floats per (tile, chunk) piece
+#define R2L_CHUNK_TILE 8192   // floats per tile
+__device__ __forceinline__ int64_t r2l_chunk_lane(int64_t tile, int j, int h) {
+    return tile * R2L_CHUNK_TILE + j * 8 + 4 * h;
+}
+__device__ __forceinline__ void r2l_chunk_store(float* p, const f32x4& v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
 template <bool RELU = false, class Act = IdentityAct>
 struct StoreHookT {
     static constexpr int RD = 0, WR = 1;
@@ -400,11 +406,10 @@ static inline int r2l_chain_variant(int64_t N) {
     return coop_t < main_t ? R2L_VARIANT_COOP : R2L_VARIANT_MAIN;
 }
 
-// The bf16x3 training trio keeps its stash (save_x[0..n-1], save_t, gx[1..n], gt) in the split layout above (slot stride
-// Np * R2L_SPLIT_ROW floats); slot n of save_x then holds y = x_n + x_0 as row-major fp32 (all the tail gradient needs) and
-// gx[0] stays row-major fp32 (head gradient).  Every other combination (cooperative chains, fp32 chains, the pre-embedded
-// module-boundary path) is row-major fp32 with slot stride Np * 256.  Callers size the buffers with r2l_stash_slot_floats().
-static inline bool r2l_stash_split(int64_t N, bool pre_embedded) {
+// The bf16x3 training trio keeps its stash (save_x[0..n-1], save_t, gx[1..n], gt) in the chunked layout above; slot n of
+// save_x then holds y = x_n + x_0 row-major (all the tail gradient needs) and gx[0] stays row-major (head gradient).
+// Every other combination (cooperative chains, fp32 chains, the pre-embedded module-boundary path) is row-major throughout.
+static inline bool r2l_stash_chunked(int64_t N, bool pre_embedded) {
     return !pre_embedded && N > 0 && r2l_chain_variant(N) == R2L_VARIANT_MAIN && r2l_use_fwd3();
 }
 

@@ -218,25 +218,9 @@ struct F3PipeT {
 // are read from LDS while the second half of stage k still feeds the matrix pipe.
 typedef F3PipeT<F3_NBUF> F3Pipe;
 
-// Training stash: the B triple of a stage IS the layer input of the chain (x_b, relu(t_b), g, masked u) already split the
-// way the weight-gradient GEMMs want it, so it is stored as it stands: three 16-byte stores per stage, each a contiguous
-// KiB per wave (whole 128-byte lines, written once: non-temporal).  Slot layout ("split layout", r2l_common.h):
-// [tile][k-block][split][lane][8 bf16].
-struct F3NoStash {
-    __device__ __forceinline__ void operator()(const F3Split&) const {}
-};
-struct F3Stash {
-    unsigned char* p;  // lane base of the (tile, k-block) triple: + split * 1 KiB
-    __device__ __forceinline__ void operator()(const F3Split& b) const {
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, b.h), reinterpret_cast<u32x4*>(p));
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, b.m), reinterpret_cast<u32x4*>(p + 1024));
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, b.l), reinterpret_cast<u32x4*>(p + 2048));
-    }
-};
-
-template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class Pipe, class GLo, class GHi, class St = F3NoStash>
+template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class Pipe, class GLo, class GHi>
 __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], Pipe& P, GLo glo, GHi ghi, F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
-                                         F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u}, St stash = St{}) {
+                                         F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u}) {
     F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, extra_a};
     f3_mfma_half<BIAS_K, ZERO_K, Pipe::TERMS>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
@@ -250,18 +234,23 @@ __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], Pipe& P, GLo glo
         P.sb.h = __builtin_bit_cast(bf16x8, u32x4{sa.uh[0], sa.uh[1], sb2.uh[0], sb2.uh[1]});
         P.sb.m = __builtin_bit_cast(bf16x8, u32x4{sa.um[0], sa.um[1], sb2.um[0], sb2.um[1]});
         P.sb.l = __builtin_bit_cast(bf16x8, u32x4{sa.ul[0], sa.ul[1], sb2.ul[0], sb2.ul[1]});
-        stash(P.sb);
     }
 }
 
 // gatherers of four B values
-template <bool RELU>
-struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile
+template <bool RELU, bool STASH = false>
+struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile (tile T given for the stash address)
     const f32x16& frag;
     int c0;
+    float* stash;  // training: this lane's base in the chunked stash slot of the layer input (r2l_chunk_lane), or nullptr
+    int T;         // piece (T, c0/4)
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = RELU ? fmaxf(frag[c0 + s], 0.f) : frag[c0 + s];
+        // the B values ARE the layer input (x_b, relu(t_b)): the stash store rides along, one 16-byte piece per half stage
+        // (unconditional when STASH: a data-dependent branch per piece would cut the half stage's schedule in two)
+        // chunked layout: the 64 lanes of a piece write one contiguous KiB (whole 128-byte lines, written once: non-temporal)
+        if (STASH) r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
     }
 };
 struct F3None {

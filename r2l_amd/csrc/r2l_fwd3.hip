@@ -277,43 +277,37 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
         }
 
     // ---- body -----------------------------------------------------------------------------------------------------------
-    // training (SAVE): the B triple of every stage is the layer's input (x_b for the first layer of a block, relu(t_b) for
-    // the second) already split for the matrix pipe: it is stashed as it stands (F3Stash, split layout of r2l_common.h)
+    // training (SAVE): the B values of every stage are the layer's input, so the stash (x_b for the first layer of a block,
+    // relu(t_b) for the second) is stored by the gatherers, two 16-byte pieces per stage (chunked layout: whole lines)
     const int64_t Np = R2L_PAD_ROWS(a.N);
     // (rows of the padding rays of the last tile exist: Np rows per slot)
-    const int64_t slot = Np * R2L_SPLIT_ROW;
-    unsigned char* sx = SAVE ? reinterpret_cast<unsigned char*>(a.save_x) + tile * R2L_SPLIT_TILE_BYTES + lane * 16 : nullptr;
-    unsigned char* st = SAVE ? reinterpret_cast<unsigned char*>(a.save_t) + tile * R2L_SPLIT_TILE_BYTES + lane * 16 : nullptr;
-    auto stash_at = [](unsigned char* base, int kb) {
-        if constexpr (SAVE) return F3Stash{base + kb * R2L_SPLIT_KB_BYTES};
-        else return F3NoStash{};
-    };
-    const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    // chunked stash layout (r2l_common.h): lane base of the tile, pieces 1 KiB apart
+    float* sx = SAVE ? a.save_x + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
+    float* st = SAVE ? a.save_t + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
+    const int64_t slot = Np * R2L_W;
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
-        f3_stage<true, true, false>(t, P, F3Take4<false>{x[0], 0}, F3Take4<false>{x[0], 4}, no_dma, no_dma, stash_at(sx, 0));
+        f3_stage<true, true, false>(t, P, F3Take4<false, SAVE>{x[0], 0, sx, 0}, F3Take4<false, SAVE>{x[0], 4, sx, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(t, P, F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                          F3Take4<false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4}, no_dma, no_dma,
-                                          stash_at(sx, kb + 1));
+            f3_stage<false, false, false>(t, P, F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
+                                          F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
         f3_stage<false, false, true>(t, P, F3None{}, F3None{});
         // x += W2 relu(t) + b2
-        f3_stage<true, false, false>(x, P, F3Take4<true>{t[0], 0}, F3Take4<true>{t[0], 4}, no_dma, no_dma, stash_at(st, 0));
+        f3_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0}, F3Take4<true, SAVE>{t[0], 4, st, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                          F3Take4<true>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4}, no_dma, no_dma,
-                                          stash_at(st, kb + 1));
+            f3_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
+                                          F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1});
         f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
         if (SAVE) {
-            sx += slot * 4;
-            st += slot * 4;
+            sx += slot;
+            st += slot;
         }
     }
     if (SAVE) {  // slot n: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
-        float* sy = a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 4 * h;  // (slot stride of the split layout)
+        float* sy = a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 4 * h;
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll

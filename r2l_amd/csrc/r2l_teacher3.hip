@@ -263,19 +263,19 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
             float pp[3] = {p[0], p[1], p[2]};
             int hh = h;
             asm volatile("" : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(hh));
-            f3_stage<true, true, false>(t, P, T3Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 0}, Relu4{x[0], 0}},
-                                        T3Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 4}, Relu4{x[0], 4}});
+            f3_stage<true, true, false>(t, P, T3Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 0}, Relu4{x[0], 0, nullptr, 0}},
+                                        T3Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 4}, Relu4{x[0], 4, nullptr, 0}});
             if (k == 2) {
                 f3_stage<false, false, false>(t, P, Xyz4{pp, hh, 8}, Xyz4{pp, hh, 12});
                 f3_stage<false, false, false>(t, P, Xyz4{pp, hh, 16}, Xyz4{pp, hh, 20});
                 f3_stage<false, false, false>(t, P, Xyz4{pp, hh, 24}, Xyz4{pp, hh, 28});
-                f3_stage<false, false, false>(t, P, Relu4{x[0], 0}, Relu4{x[0], 4});
+                f3_stage<false, false, false>(t, P, Relu4{x[0], 0, nullptr, 0}, Relu4{x[0], 4, nullptr, 0});
             }
         }
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(t, P, Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                          Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+            f3_stage<false, false, false>(t, P, Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+                                          Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
         f3_stage<false, false, true>(t, P, F3None{}, F3None{});
         if (k == 3) {  // alpha_linear on relu(layer 7)
             float acc = 0.f;
@@ -290,21 +290,21 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
             acc += __shfl_xor(acc, 32);
             alpha = acc + P0[off.alpha_b];
         }
-        f3_stage<true, true, false>(x, P, Relu4{t[0], 0}, Relu4{t[0], 4});
+        f3_stage<true, true, false>(x, P, Relu4{t[0], 0, nullptr, 0}, Relu4{t[0], 4, nullptr, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                          Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+            f3_stage<false, false, false>(x, P, Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+                                          Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
         f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next pair's (or the views layer's) bias stage
     }
 
     // ---- views layer: v[128] = Wv [feature, dir-embedding] + bv in tiles 0-3 of t (ReLU applied by the rgb head) ---------
     typedef F3Take4<false> Id4;
-    f3_stage<true, true, false>(t, P, Id4{x[0], 0}, Id4{x[0], 4});
+    f3_stage<true, true, false>(t, P, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 4, nullptr, 0});
 #pragma unroll
     for (int kb = 0; kb < 15; ++kb)
-        f3_stage<false, false, false>(t, P, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
-                                      Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4});
+        f3_stage<false, false, false>(t, P, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+                                      Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
     f3_stage<false, false, false>(t, P, Dir4{vd, h, 0}, Dir4{vd, h, 4});
     f3_stage<false, false, false>(t, P, Dir4{vd, h, 8}, Dir4{vd, h, 12});
     f3_stage<false, false, true>(t, P, F3None{}, F3None{});  // next: stream padding
