@@ -254,7 +254,8 @@ def main():
                      "peak_note": ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); the default kernel evaluates "
                                    "every fp32 product as 6 bf16 MFMA products (exact bf16 hi/mid/lo splits), so its matrix-pipe "
                                    "peak in algorithmic FLOP/s is the dense bf16 MFMA peak 2500 TF / 6; under that load the chip "
-                                   "runs at ~1.9 GHz instead of the nominal 2.4 GHz the peak assumes (profiles/r01_summary.md)")
+                                   "runs at 1.72-1.77 GHz (power limit) instead of the nominal 2.4 GHz the peak assumes "
+                                   "(profiles/r01_summary.md, r01_clock_probe.txt)")
                      if fwd3 else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                      "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
@@ -298,6 +299,19 @@ def main():
         # 128 of the 1024 wave slots, reported for completeness
         out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
                                             PEAK_FP32_MFMA, n_rays=4096)
+        # opt-in mode, reported beside the default: gradient GEMMs (dX chain, dW body) with the 3 largest of the 6 bf16
+        # products (operands to 16 mantissa bits; forward unchanged) — not the headline training number
+        if "R2L_GRAD_TERMS" not in os.environ and "R2L_NO_FWD3" not in os.environ:
+            os.environ["R2L_GRAD_TERMS"] = "3"
+            try:
+                g3 = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY, PEAK_FP32_MFMA)
+            finally:
+                del os.environ["R2L_GRAD_TERMS"]
+            g3["note"] = ("R2L_GRAD_TERMS=3: products of the gradient GEMMs to ~2^-16 instead of 2^-24; measured gradient "
+                          "difference to the default 2.7e-6 (relative L2, W256D88, 98 304 rays: tools/grad3_err.py)")
+            g3["roofline"]["matrix_path"] = "bf16x3 forward (6 products), dX chain and dW with 3 products"
+            g3["roofline"]["peak_note"] = "peak = dense bf16 MFMA / 6 as for the default path (fewer matrix products per algorithmic FLOP in the backward)"
+            out["train_grad3"] = g3
 
     if not a.no_teacher:
         out["teacher"] = teacher_leg(device, world, rank, distributed)
