@@ -367,6 +367,12 @@ __host__ __device__ static inline int64_t r2l_fwd3_stages(int n_block) { return 
 __host__ __device__ static inline int64_t r2l_fwd3_stream_floats(int n_block) {
     return (r2l_fwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
 }
+// fp16x2 forward (r2l_fwd2.hip): same stages, 16 KiB each, then 64 bytes of status (word 0: range guard)
+#define R2L_F2_RANGE 32768.0f  // |activation| from which on a forward launch is handed over to the bf16x3 kernel
+__host__ __device__ static inline int64_t r2l_fwd2_status_offset(int n_block) {
+    return (r2l_fwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (16384 / 4);
+}
+__host__ __device__ static inline int64_t r2l_fwd2_stream_floats(int n_block) { return r2l_fwd2_status_offset(n_block) + 16; }
 __host__ __device__ static inline int64_t r2l_bwd3_stages(int n_block) { return 34 * (int64_t)n_block; }
 __host__ __device__ static inline int64_t r2l_bwd3_stream_floats(int n_block) {
     return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
@@ -381,10 +387,23 @@ static inline bool r2l_use_fwd3() {
     const char* e = getenv("R2L_NO_FWD3");
     return !(e && e[0] && e[0] != '0');
 }
+// forward-only launches (no training stash): three fp16 products per fp32 product, ~2^-21 relative (r2l_fwd2.hip), with
+// the bf16x3 kernel launched behind it as the range-guard fallback (it returns at once unless the status word is raised).
+// R2L_NO_FWD2=1: bf16x3 only.
+static inline bool r2l_use_fwd2() {
+    const char* e = getenv("R2L_NO_FWD2");
+    return r2l_use_fwd3() && !(e && e[0] && e[0] != '0');
+}
+int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream);
+int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                     const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
+                     int n_block, float* rgb, int64_t N, hipStream_t stream);
 int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
+// run_if: nullptr, or a device word — the launch returns at once while it is 0 (fallback behind r2l_fwd2_forward)
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,
-                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
+                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream,
+                     const unsigned* run_if = nullptr);
 
 // Which chain variant is fastest for N rays.  In units of one main-kernel round (1024 wave slots x 32 rays): main needs
 // ceil(N/32768) rounds; coop (4 waves share a 32-ray tile, 256 workgroups) ceil(N/8192) rounds of ~0.34 (measured: fwd

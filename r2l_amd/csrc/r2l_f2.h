@@ -1,0 +1,173 @@
+// r2l_f2.h — the stage machinery of r2l_f3.h for TWO fp16 splits instead of three bf16 ones (r2l_fwd2.hip).
+//
+// An fp32 value x is written hi + mid with hi = fp16(x), mid = fp16(x - hi): 11 + 11 mantissa bits, i.e. x to ~2^-22
+// relative as long as both parts stay inside fp16's exponent range (|x| < 65504; parts below 2^-14 lose bits but are then
+// below 2^-25 absolutely).  A product a*b is taken as the three fp16 products mid*hi + hi*mid + hi*hi (fp32 accumulate in
+// the MFMA): relative error ~2^-21 instead of the ~2^-24 of the six-product bf16 scheme, for HALF the matrix work and two
+// thirds of the operand bytes.  Forward-only (render / evaluation): 1e-4 on RGB is the parity bar, measured ~1e-6.
+// Range guard: every lane tracks the largest |B value| it converts; a kernel that saw one near the end of fp16's range
+// raises a status word in device memory and the caller reruns the launch on the bf16x3 kernel (r2l_fwd2.hip).
+//
+// Everything else is r2l_f3.h's design: 16 KiB stages [split][tile][lane][8 fp16] DMA'd into LDS by the four waves (a
+// quarter each = 4 pieces), six buffers, the barrier that publishes stage k+1 in the middle of stage k, side work (A-operand
+// LDS reads, DMA pieces, gather + split of the next stage's B values) hand-interleaved with the MFMA groups.
+#pragma once
+#include "r2l_f3.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define F2_STAGE_BYTES 16384  // 2 splits x 8 tiles x 64 lanes x 16 B
+#define F2_NBUF 6
+
+struct F2Split {
+    f16x8 h, m;
+};
+struct F2A4 {  // A operands (fp16 pairs) of four output tiles
+    f16x8 h[4], m[4];
+};
+
+// side work of one half stage in six steps, two per group of four MFMAs:
+//   A operand reads of the NEXT half stage: 8 (2 per step, steps 0..3); DMA pieces: 4 (steps 0..3);
+//   four B values of the next stage: gather (0), hi (1), residual (2), mid (3)
+template <bool BIAS_A, class Gather>
+struct F2Side {
+    F2A4& a;
+    const unsigned char* lb;  // lane base of the stage buffer the A operands come from
+    int half;
+    Gather gather;
+    bool want_b;
+    F3Dma dma;
+    float& amax;  // running max |B value| of this lane (range guard: fp16 ends at 65504)
+    float x[4];
+    unsigned uh[2], um[2];  // packed fp16 pairs: values (0,1) and (2,3)
+    static __device__ __forceinline__ unsigned pk(float a0, float a1) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, h2));
+    }
+    static __device__ __forceinline__ float lo(unsigned u) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return (float)__builtin_bit_cast(h2, u)[0];
+    }
+    static __device__ __forceinline__ float hi(unsigned u) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return (float)__builtin_bit_cast(h2, u)[1];
+    }
+    __device__ __forceinline__ void loads(int i) {
+#pragma unroll
+        for (int k = 2 * i; k < 2 * i + 2; ++k) {
+            if (k >= (BIAS_A ? 4 : 8)) continue;
+            const int tt = BIAS_A ? k : k / 2, sp = BIAS_A ? 0 : k % 2;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(lb + (sp * 8 + 4 * half + tt) * 1024);
+            if (sp == 0) a.h[tt] = v;
+            else a.m[tt] = v;
+        }
+    }
+    __device__ __forceinline__ void step(int i) {
+        loads(i);
+        if (dma.on && i < 4) f3_dma16(dma.rs, dma.voff, dma.so + i * 1024u, dma.la + i * 1024u);
+        if (!want_b) return;
+        if (i == 0) {
+            gather(x);
+            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));  // v_max3_f32
+            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+        } else if (i == 1) {
+            uh[0] = pk(x[0], x[1]);
+            uh[1] = pk(x[2], x[3]);
+        } else if (i == 2) {
+            x[0] -= lo(uh[0]); x[1] -= hi(uh[0]);
+            x[2] -= lo(uh[1]); x[3] -= hi(uh[1]);
+        } else if (i == 3) {
+            um[0] = pk(x[0], x[1]);
+            um[1] = pk(x[2], x[3]);
+        }
+    }
+};
+
+// acc[4 tiles of `half`] (+)= W . b: three fp16 MFMAs per tile, small terms first, term-major; after every group of four
+// MFMAs two steps of `side`.  BIAS stage: one MFMA per tile (hi, mid of the bias in k slots 0, 1 against ones).
+template <bool BIAS, bool ZERO_INIT, class Side>
+__device__ __forceinline__ void f2_mfma_half(f32x16 (&acc)[R2L_NT], int half, const F2A4& a, const F2Split& b, Side& side) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (BIAS) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[t], b.h, ZERO_INIT ? zero : acc[4 * half + t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) side.step(i);
+        return;
+    }
+#define F2_GROUP(AA, BB, I)                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[4 * half + t] =                                                   \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[t], BB, acc[4 * half + t], 0, 0, 0);                                   \
+    side.step(I);                                                                                                       \
+    side.step(I + 1);                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    if (ZERO_INIT) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.m[t], b.h, zero, 0, 0, 0);
+        side.step(0);
+        side.step(1);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        F2_GROUP(a.m, b.h, 0)
+    }
+    F2_GROUP(a.h, b.m, 2)
+    F2_GROUP(a.h, b.h, 4)
+#undef F2_GROUP
+}
+
+// state of the weight-staging pipeline (r2l_f3.h's F3PipeT for 16 KiB stages: 4 pieces per wave and stage)
+struct F2Pipe {
+    u32x4 rs;
+    unsigned lds0;
+    unsigned voff, wq;  // lane * 16 ; this wave's quarter of a stage (4096 * wave)
+    const unsigned char* base;
+    int lane;
+    int gb;
+    int gq, gqb;
+    const unsigned char* lb;
+    F2A4 a1, a2;
+    F2Split sb;
+    F2Split ones;
+    float amax;  // max |B value| seen by this lane
+    __device__ __forceinline__ void issue() {
+        const unsigned so = (unsigned)gq * F2_STAGE_BYTES + wq;
+        const unsigned la = lds0 + (unsigned)gqb * F2_STAGE_BYTES + wq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f3_dma16(rs, voff, so + i * 1024u, la + i * 1024u);
+        ++gq;
+        gqb = (gqb == F2_NBUF - 1) ? 0 : gqb + 1;
+    }
+    // vmcnt retires in order: the own loads of stage k+1 have the 4 x 3 loads of stages k+2..k+4 behind them
+    __device__ __forceinline__ void sync_next() {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        static_assert(F2_NBUF == 6, "wait immediate written for 6 buffers");
+        __syncthreads();
+        gb = (gb == F2_NBUF - 1) ? 0 : gb + 1;
+        lb = base + gb * F2_STAGE_BYTES + lane * 16;
+    }
+    __device__ __forceinline__ F3Dma request() {
+        F3Dma d{true, rs, voff, (unsigned)gq * F2_STAGE_BYTES + wq, lds0 + (unsigned)gqb * F2_STAGE_BYTES + wq};
+        ++gq;
+        gqb = (gqb == F2_NBUF - 1) ? 0 : gqb + 1;
+        return d;
+    }
+};
+
+// One stage (see f3_stage): acc (+)= stage k; glo / ghi fill the B values 0-3 / 4-7 of stage k+1.
+template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
+__device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi) {
+    F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax};
+    f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    P.sync_next();
+    F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax};
+    f2_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (BIAS_NEXT) {
+        P.sb = P.ones;
+    } else {
+        P.sb.h = __builtin_bit_cast(f16x8, u32x4{sa.uh[0], sa.uh[1], sb2.uh[0], sb2.uh[1]});
+        P.sb.m = __builtin_bit_cast(f16x8, u32x4{sa.um[0], sa.um[1], sb2.um[0], sb2.um[1]});
+    }
+}

@@ -257,3 +257,34 @@ struct F3None {
     __device__ __forceinline__ void operator()(float (&v)[4]) const { v[0] = v[1] = v[2] = v[3] = 0.f; }
 };
 
+// gatherers of the head: four values of the positional encoding (shared by r2l_fwd3.hip and r2l_fwd2.hip)
+struct F3Trig2 {  // (sin, cos) of x * 2^f0 and x * 2^(f0+1)
+    float x;
+    int f0;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        r2l_sincos(x * (float)(1 << f0), v[0], v[1]);
+        r2l_sincos(x * (float)(1 << (f0 + 1)), v[2], v[3]);
+    }
+};
+struct F3Ident4 {  // identity features: coordinates e0 .. e0+3 of this half-wave (point = o + d * z)
+    const float (&o)[3];
+    const float (&d)[3];
+    const float (&z)[8];
+    int e0;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = o[(e0 + s) % 3] + d[(e0 + s) % 3] * z[(e0 + s) / 3];
+    }
+};
+struct F3TrigOrIdent {  // last stage of a head trip: first block of the next trip, or the first identity block
+    bool ident;
+    F3Trig2 tr;
+    F3Ident4 id;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        float w[4];
+        tr(v);
+        id(w);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = ident ? w[s] : v[s];
+    }
+};

@@ -1,56 +1,36 @@
-// r2l_fwd3.hip — the R2L student forward at fp32 accuracy on the bf16 matrix pipe (gfx950).
-//
-// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  An fp32 value is the exact sum of three bf16 numbers
-// (hi + mid + lo: 8 + 8 + 8 mantissa bits, same exponent range as fp32), so a product a*b of fp32 operands is
-// reproduced to ~2^-24 relative by the six bf16 products  hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi  (each exact
-// in the MFMA's fp32 accumulator; the three dropped terms are below 2^-24).  Six bf16 MFMAs of K = 16 replace sixteen
-// fp32 MFMAs of K = 2 at the same result quality: 2.67x fewer matrix-pipe cycles for the same 11.79 MFLOP/ray.
-//
-// Structure: the register-resident activation chain of r2l_forward.hip (one wave = 32 rays for the whole network, C/D
-// fragment of layer n = B operand of layer n+1: with the k slots of a K=16 block numbered so that lane-half h supplies the
-// eight features {8q+4h+e}, the eight B values of a block are eight CONSECUTIVE fragment registers) — but
-//   * weights are pre-split into bf16 triples by r2l_pack_fwd3_kernel and streamed in 24 KiB stages (one k-block of 16 x
-//     256 outputs x 3 splits) straight into LDS with `buffer_load_dwordx4 ... lds` (no registers), four buffers deep
-//     (three stages ~1.9 us of latency cover), shared by the four waves of the workgroup: one barrier per stage;
-//   * the eight B values of a block are split into (hi, mid, lo) on the VALU in the shadow of the block's 48 MFMAs;
-//   * the bias of a layer is ONE MFMA per output tile: hi, mid, lo of the bias sit in three k slots against B = 1;
-//   * X_0 stays in registers (the weight ring no longer needs them) for the outer residual.
-// Used for forward-only launches (render / evaluation); training keeps the fp32-MFMA kernels.
-#include "r2l_f3.h"
+// r2l_fwd2.hip — the R2L student forward on the fp16 matrix pipe with two-way operand splits (see r2l_f2.h): every fp32
+// product as three fp16 MFMA products, ~2^-21 relative.  Structure, stage order and gatherers are r2l_fwd3.hip's; stages are
+// 16 KiB ([split 2][tile 8][lane 64][8 fp16]).  Forward-only launches (render / evaluation), opt-in: R2L_FWD2=1.
+#include "r2l_f2.h"
 
-__host__ __device__ static inline int64_t f3_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
-__host__ __device__ static inline int64_t f3_off_body_w(int layer) {
+__host__ __device__ static inline int64_t f2_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
+__host__ __device__ static inline int64_t f2_off_body_w(int layer) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
 }
-__host__ __device__ static inline int64_t f3_off_body_b(int layer) { return f3_off_body_w(layer) + R2L_W * R2L_W; }
-__host__ __device__ static inline int64_t f3_off_tail_w(int n_block) { return f3_off_body_w(2 * n_block); }
-__host__ __device__ static inline int64_t f3_off_tail_b(int n_block) { return f3_off_tail_w(n_block) + 3 * R2L_W; }
+__host__ __device__ static inline int64_t f2_off_body_b(int layer) { return f2_off_body_w(layer) + R2L_W * R2L_W; }
+__host__ __device__ static inline int64_t f2_off_tail_w(int n_block) { return f2_off_body_w(2 * n_block); }
+__host__ __device__ static inline int64_t f2_off_tail_b(int n_block) { return f2_off_tail_w(n_block) + 3 * R2L_W; }
 
 // =================================================================================================================
-// pack: flat fp32 parameters -> stage stream.  Stage g: 0 = head bias, 1..63 = head k-blocks, then per body layer
-// [bias stage, 16 k-block stages].  A stage is [split sp][tile t][lane (i,h)][slot s] bf16: split sp of
-// W[32t + i][feature(stage, h, s)].
-//   head k-block b, half h, slot s:  v = 8b + s indexes the half's 504 encoding values: v < 480: coordinate ci = v/20 of
-//     the half (sample 8h + ci/3, axis ci%3), frequency f = (v%20)/2, sin (even) / cos (odd);  v >= 480: identity of
-//     coordinate v - 480.
-//   body k-block kb = 2T + r: feature 32T + 8(2r + (s>>2)) + 4h + (s&3)  — fragment registers 8r .. 8r+7 of tile T.
-//   bias stage: split region 0 only: slots 0,1,2 of half 0 = hi, mid, lo of bias[32t + i]; everything else 0.
+// pack: flat fp32 parameters -> stage stream, stage order and slot numbering exactly as r2l_pack_fwd2_kernel; a stage is
+// [split sp (2)][tile t][lane (i,h)][slot s] fp16.  bias stage: split region 0 only: slots 0, 1 of half 0 = hi, mid.
 // =================================================================================================================
-__global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
+__device__ __forceinline__ unsigned short f2_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+__global__ void r2l_pack_fwd2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
     const int64_t stages = r2l_fwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
         const int64_t g = idx >> 12;
         const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
-        unsigned short* st = out + g * (F3_STAGE_BYTES / 2);
-        unsigned short v0 = 0, v1 = 0, v2 = 0;
+        unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
+        unsigned short v0 = 0, v1 = 0;
         if (g < stages) {
             bool bias_stage = false;
             float w = 0.f;
             if (g == 0) {
                 bias_stage = true;
-                w = params[f3_off_head_b() + o];
+                w = params[f2_off_head_b() + o];
             } else if (g < 64) {
                 const int v = 8 * (int)(g - 1) + s;
                 int col;
@@ -66,34 +46,35 @@ __global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned 
                 const int layer = (int)((g - 64) / 17), r17 = (int)((g - 64) % 17);
                 if (r17 == 0) {
                     bias_stage = true;
-                    w = params[f3_off_body_b(layer) + o];
+                    w = params[f2_off_body_b(layer) + o];
                 } else {
                     const int kb = r17 - 1, T = kb >> 1, r = kb & 1;
                     const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
-                    w = params[f3_off_body_w(layer) + (int64_t)o * R2L_W + in];
+                    w = params[f2_off_body_w(layer) + (int64_t)o * R2L_W + in];
                 }
             }
-            const unsigned short hi = f3_bf16_rne(w);
-            const float r1 = w - f3_bf16_to_f(hi);
-            const unsigned short mid = f3_bf16_rne(r1);
-            const unsigned short lo = f3_bf16_rne(r1 - f3_bf16_to_f(mid));
+            const _Float16 hi = (_Float16)w;
+            const _Float16 mid = (_Float16)(w - (float)hi);
             if (bias_stage) {
-                v0 = (h == 0) ? (s == 0 ? hi : (s == 1 ? mid : (s == 2 ? lo : (unsigned short)0))) : (unsigned short)0;
+                v0 = (h == 0) ? (s == 0 ? f2_bits(hi) : (s == 1 ? f2_bits(mid) : (unsigned short)0)) : (unsigned short)0;
             } else {
-                v0 = hi; v1 = mid; v2 = lo;
+                v0 = f2_bits(hi); v1 = f2_bits(mid);
             }
         }
         const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
         st[e] = v0;
         st[8 * 64 * 8 + e] = v1;
-        st[2 * 8 * 64 * 8 + e] = v2;
     }
+}
+// status word behind the stages: cleared by every pack (new weights: new chance)
+__global__ void r2l_fwd2_status_clear_kernel(unsigned* status) {
+    if (threadIdx.x < 16) status[threadIdx.x] = 0u;
 }
 
 // =================================================================================================================
 // forward
 // =================================================================================================================
-struct F3Args {
+struct F2Args {
     const float* rays_o;
     const float* rays_d;
     const float* t_rand;
@@ -101,8 +82,8 @@ struct F3Args {
     float c2w[12];
     int H, Wimg;
     float focal;
-    const unsigned char* stream;  // fwd3 stage stream
-    const unsigned* run_if;       // nullptr, or: return at once while this word is 0 (range-guard fallback of r2l_fwd2.hip)
+    const unsigned char* stream;  // fwd2 stage stream
+    unsigned* status;             // range-guard word behind the stream: != 0 -> this launch is left to the bf16x3 kernel
     const float* params;
     int n_block;
     float* rgb;
@@ -112,10 +93,11 @@ struct F3Args {
 };
 
 template <bool POSE, bool SAVE>
-__global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char wbuf[F3_NBUF][F3_STAGE_BYTES];
+__global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
 
-    if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
+    // an earlier launch with these weights left fp16's range: the bf16x3 kernel behind this one does the work
+    if (__builtin_nontemporal_load(a.status) != 0u) return;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // every wave of the workgroup takes part in the weight staging and the barriers: a wave whose tile lies past the end
@@ -162,34 +144,34 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     }
 
     // ---- weight staging: stage g of the stream is DMA'd into LDS buffer g % 6 by the four waves (a quarter each) ----------
-    F3Pipe P;
+    F2Pipe P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
         P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         P.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&wbuf[0][0];
         P.voff = (unsigned)lane * 16u;
-        P.wq = (unsigned)wave * 6144u;
+        P.wq = (unsigned)wave * 4096u;
         P.base = &wbuf[0][0];
         P.lane = lane;
         P.gb = 0;
         P.gq = 0;
         P.gqb = 0;
+        P.amax = 0.f;
     }
     P.issue(); P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..4
 #pragma unroll
-    for (int k = 0; k < 8; ++k) P.ones.h[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
+    for (int k = 0; k < 8; ++k) P.ones.h[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
     P.ones.m = P.ones.h;
-    P.ones.l = P.ones.h;
 
     f32x16 x[R2L_NT], t[R2L_NT], x0[R2L_NT];
     // prologue: stage 0 (head bias) becomes current
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();
     P.lb = P.base + lane * 16;
     {
         F3None none;
-        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}};
+        F2Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax};
 #pragma unroll
         for (int i = 0; i < 6; ++i) s0.step(i);
     }
@@ -209,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 #pragma unroll
         for (int ci = 0; ci < 6; ++ci) xc[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
     }
-    f3_stage<true, true, false>(x, P, F3Trig2{xc[0], 0}, F3Trig2{xc[0], 2});
+    f2_stage<true, true, false>(x, P, F3Trig2{xc[0], 0}, F3Trig2{xc[0], 2});
 #pragma unroll 1
     for (int it2 = 0; it2 < 4; ++it2) {  // two samples = six coordinates = three pairs = 15 k-blocks per trip
         // coordinates of the NEXT trip (the last stage of this trip prepares the first B triple of the next one)
@@ -222,14 +204,14 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const float xa = xc[2 * p], xb = xc[2 * p + 1];
-            f3_stage<false, false, false>(x, P, F3Trig2{xa, 4}, F3Trig2{xa, 6});
-            f3_stage<false, false, false>(x, P, F3Trig2{xa, 8}, F3Trig2{xb, 0});
-            f3_stage<false, false, false>(x, P, F3Trig2{xb, 2}, F3Trig2{xb, 4});
-            f3_stage<false, false, false>(x, P, F3Trig2{xb, 6}, F3Trig2{xb, 8});
+            f2_stage<false, false, false>(x, P, F3Trig2{xa, 4}, F3Trig2{xa, 6});
+            f2_stage<false, false, false>(x, P, F3Trig2{xa, 8}, F3Trig2{xb, 0});
+            f2_stage<false, false, false>(x, P, F3Trig2{xb, 2}, F3Trig2{xb, 4});
+            f2_stage<false, false, false>(x, P, F3Trig2{xb, 6}, F3Trig2{xb, 8});
             if (p < 2) {
-                f3_stage<false, false, false>(x, P, F3Trig2{xc[2 * p + 2], 0}, F3Trig2{xc[2 * p + 2], 2});
+                f2_stage<false, false, false>(x, P, F3Trig2{xc[2 * p + 2], 0}, F3Trig2{xc[2 * p + 2], 2});
             } else {
-                f3_stage<false, false, false>(x, P, F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 0}, F3Ident4{o, d, z, 0}},
+                f2_stage<false, false, false>(x, P, F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 0}, F3Ident4{o, d, z, 0}},
                                               F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 2}, F3Ident4{o, d, z, 4}});
             }
         }
@@ -237,9 +219,9 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
         for (int ci = 0; ci < 6; ++ci) xc[ci] = xn[ci];
     }
     // identity features: coordinates 8j .. 8j+7 of the half
-    f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 8}, F3Ident4{o, d, z, 12});
-    f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 16}, F3Ident4{o, d, z, 20});
-    f3_stage<false, false, true>(x, P, F3None{}, F3None{});
+    f2_stage<false, false, false>(x, P, F3Ident4{o, d, z, 8}, F3Ident4{o, d, z, 12});
+    f2_stage<false, false, false>(x, P, F3Ident4{o, d, z, 16}, F3Ident4{o, d, z, 20});
+    f2_stage<false, false, true>(x, P, F3None{}, F3None{});
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
@@ -260,19 +242,19 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
-        f3_stage<true, true, false>(t, P, F3Take4<false, SAVE>{x[0], 0, sx, 0}, F3Take4<false, SAVE>{x[0], 4, sx, 0});
+        f2_stage<true, true, false>(t, P, F3Take4<false, SAVE>{x[0], 0, sx, 0}, F3Take4<false, SAVE>{x[0], 4, sx, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(t, P, F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
+            f2_stage<false, false, false>(t, P, F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
                                           F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
-        f3_stage<false, false, true>(t, P, F3None{}, F3None{});
+        f2_stage<false, false, true>(t, P, F3None{}, F3None{});
         // x += W2 relu(t) + b2
-        f3_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0}, F3Take4<true, SAVE>{t[0], 4, st, 0});
+        f2_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0}, F3Take4<true, SAVE>{t[0], 4, st, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
+            f2_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
                                           F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1});
-        f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
+        f2_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
         if (SAVE) {
             sx += slot;
             st += slot;
@@ -289,8 +271,11 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
                           x[T][4 * q + 3] + x0[T][4 * q + 3]};
     }
 
+    // range guard: a value that close to 65504 may have become inf in a product's operand -> hand the launch over
+    if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt) on the VALU -------------------------------------------------------------
-    const float* tw = a.params + f3_off_tail_w(a.n_block) + 4 * h;
+    const float* tw = a.params + f2_off_tail_w(a.n_block) + 4 * h;
     float p3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)
@@ -311,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     if (valid && h == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = p3[c] + a.params[f3_off_tail_b(a.n_block) + c];
+            const float v = p3[c] + a.params[f2_off_tail_b(a.n_block) + c];
             a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
         }
     }
@@ -320,28 +305,30 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream) {
-    hipLaunchKernelGGL(r2l_pack_fwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
-                       reinterpret_cast<unsigned short*>(wstream3), n_block);
+int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream) {
+    hipLaunchKernelGGL(r2l_pack_fwd2_kernel, dim3(2048), dim3(256), 0, stream, params,
+                       reinterpret_cast<unsigned short*>(wstream2), n_block);
+    R2L_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(r2l_fwd2_status_clear_kernel, dim3(1), dim3(64), 0, stream,
+                       reinterpret_cast<unsigned*>(wstream2 + r2l_fwd2_status_offset(n_block)));
     R2L_CHECK(hipGetLastError());
     return 0;
 }
 
-int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
-                     const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,
-                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream,
-                     const unsigned* run_if) {
-    F3Args a{};
-    a.run_if = run_if;
+int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                     const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
+                     int n_block, float* rgb, int64_t N, hipStream_t stream) {
+    F2Args a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
-    a.stream = reinterpret_cast<const unsigned char*>(wstream3); a.params = params;
-    a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
+    a.stream = reinterpret_cast<const unsigned char*>(wstream2); a.params = params;
+    // the status word lives in the caller's stream buffer (library-private contents): written through, hence the cast
+    a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + r2l_fwd2_status_offset(n_block));
+    a.n_block = n_block; a.rgb = rgb; a.save_x = nullptr; a.save_t = nullptr; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (c2w_host12) hipLaunchKernelGGL((r2l_fwd3_kernel<true, false>), grid, block, 0, stream, a);
-    else if (save_x) hipLaunchKernelGGL((r2l_fwd3_kernel<false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((r2l_fwd3_kernel<false, false>), grid, block, 0, stream, a);
+    if (c2w_host12) hipLaunchKernelGGL((r2l_fwd2_kernel<true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((r2l_fwd2_kernel<false, false>), grid, block, 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -120,10 +120,11 @@ extern "C" int64_t r2l_param_count(int n_block) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)2 * n_block * (R2L_W * R2L_W + R2L_W) + 3 * R2L_W + 3;
 }
 
-// a stream buffer = [32-ray-tile layout | 16-ray-tile layout | bf16x3 stages (forward only)]; every kernel finds its part
-// by offset
+// a stream buffer = [32-ray-tile layout | 16-ray-tile layout | bf16x3 stages | fp16x2 stages (forward stream only)]; every
+// kernel finds its part by offset
 extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
-    return r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) + r2l_fwd3_stream_floats(n_block);
+    return r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) + r2l_fwd3_stream_floats(n_block) +
+           r2l_fwd2_stream_floats(n_block);
 }
 
 extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
@@ -133,12 +134,13 @@ extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
 // launches use (r2l_variant_for) can skip the other half of the stream: 10 us each, 3 % of a 4096-ray step.
 extern "C" int r2l_variant_for(int64_t N) { return r2l_chain_variant(N); }
-// stream layout a forward launch with N rays reads: 16 / 32 (cooperative variants / fp32-MFMA kernels) or 3 (the bf16x3
-// kernel, r2l_fwd3.hip: every one-wave-per-tile forward, with or without the training stash)
+// stream layout a forward launch with N rays reads: 16 / 32 (cooperative variants / fp32-MFMA kernels), 3 (the bf16x3
+// kernel, r2l_fwd3.hip: every one-wave-per-tile forward, with or without the training stash) or 2 (fp16x2 kernel,
+// r2l_fwd2.hip, with the bf16x3 stream as its fallback: forward-only launches)
 extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
-    (void)with_stash;
+    if (v == R2L_VARIANT_MAIN && !with_stash && r2l_use_fwd2()) return 2;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return 3;
     return 32;
 }
@@ -152,8 +154,15 @@ extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* 
                            wstream + r2l_fwd32_stream_floats(n_block), n_block);
         R2L_CHECK(hipGetLastError());
     }
-    if (layout == 0 || layout == 3) {
+    if (layout == 0 || layout == 3 || layout == 2) {  // (2: the bf16x3 stream is the range-guard fallback of the fp16x2 one)
         const int rc = r2l_fwd3_pack(params, n_block, wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block),
+                                     (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (layout == 0 || layout == 2) {
+        const int rc = r2l_fwd2_pack(params, n_block,
+                                     wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) +
+                                         r2l_fwd3_stream_floats(n_block),
                                      (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -183,7 +192,11 @@ extern "C" int r2l_pack_forward(const float* params, int n_block, float* wstream
     hipLaunchKernelGGL(r2l_pack_fwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
                        wstream + r2l_fwd32_stream_floats(n_block), n_block);
     R2L_CHECK(hipGetLastError());
-    return r2l_fwd3_pack(params, n_block, wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block),
+    const int rc = r2l_fwd3_pack(params, n_block, wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block),
+                                 (hipStream_t)stream);
+    if (rc) return rc;
+    return r2l_fwd2_pack(params, n_block,
+                         wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) + r2l_fwd3_stream_floats(n_block),
                          (hipStream_t)stream);
 }
 

@@ -111,7 +111,7 @@ class R2LEngine:
 
     def layout_for(self, n, with_stash=True):
         """Which part of the packed forward stream a launch with n rays reads: 16 (16-ray cooperative kernels), 32
-        (one-wave-per-tile / 32-ray cooperative kernels, every training launch) or 3 (the bf16x3 forward-only kernel)."""
+        (32-ray cooperative / fp32-MFMA kernels), 3 (the bf16x3 kernels) or 2 (fp16x2 forward-only kernel, R2L_FWD2=1)."""
         return self.lib.r2l_forward_layout_for(int(n), 1 if with_stash else 0)
 
     def pack_now(self):
@@ -119,7 +119,7 @@ class R2LEngine:
         not replay)."""
         _lib.check(self.lib.r2l_pack_forward(_ptr(self.flat), self.n_block, _ptr(self.wstream), _stream()),
                    "r2l_pack_forward")
-        self._packed_version = {16: self.version(), 32: self.version(), 3: self.version()}
+        self._packed_version = {16: self.version(), 32: self.version(), 3: self.version(), 2: self.version()}
 
     def ensure_packed(self, n=None, with_stash=True):
         """Re-pack the weight stream if the parameters changed since it was packed.  With n given only the layout that a
@@ -128,8 +128,8 @@ class R2LEngine:
             self.flatten(self.params[0].device)
         ver = self.version()
         if self._packed_version is None:
-            self._packed_version = {16: None, 32: None, 3: None}
-        for layout in ((16, 32, 3) if n is None else (self.layout_for(n, with_stash),)):
+            self._packed_version = {16: None, 32: None, 3: None, 2: None}
+        for layout in ((16, 32, 3, 2) if n is None else (self.layout_for(n, with_stash),)):
             if self._packed_version[layout] != ver:
                 _lib.check(self.lib.r2l_pack_forward_layout(_ptr(self.flat), self.n_block, _ptr(self.wstream), layout,
                                                             _stream()), "r2l_pack_forward_layout")

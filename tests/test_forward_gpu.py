@@ -10,16 +10,21 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "main-bf16x3", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
-    """Every test runs under each forward kernel family: one wave per tile on the bf16x3 matrix path (r2l_fwd3.hip) and
-    on the fp32 MFMA (r2l_forward.hip, R2L_NO_FWD3=1), and the two cooperative small-batch families."""
+    """Every test runs under each forward kernel family: one wave per tile on the fp16x2 matrix path (r2l_fwd2.hip, the
+    default of forward-only launches), on the bf16x3 path (r2l_fwd3.hip, R2L_NO_FWD2=1) and on the fp32 MFMA
+    (r2l_forward.hip, R2L_NO_FWD3=1), and the two cooperative small-batch families."""
     name = request.param
     monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
     if name == "main-f32mfma":
         monkeypatch.setenv("R2L_NO_FWD3", "1")
     else:
         monkeypatch.delenv("R2L_NO_FWD3", raising=False)
+    if name == "main-bf16x3":
+        monkeypatch.setenv("R2L_NO_FWD2", "1")
+    else:
+        monkeypatch.delenv("R2L_NO_FWD2", raising=False)
     return name
 T = torch.from_numpy
 TOL = 1e-4  # north_star: RGB within 1e-4 abs of the reference PyTorch path
@@ -126,3 +131,32 @@ def test_small_depth_and_gain(golden_dir):
     with torch.no_grad():
         out = m.forward_rays(o.cuda(), d.cuda(), ps)
     assert (out.cpu() - ref).abs().max().item() < TOL
+
+
+def test_fp16_range_guard_falls_back(chain_variant):
+    """Activations beyond fp16's range: the fp16x2 forward raises its status word and the bf16x3 kernel behind it redoes the
+    launch, so the result still matches the oracle (3-block net with a head scaled up until |x_0| reaches ~1e5)."""
+    from model.nerf_raybased import PointSampler
+    sd = O.make_state_dict(n_block=3, seed=4)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["head.0.weight"] *= 3.0e4
+    sd["head.0.bias"] *= 3.0e4
+    for k in sd:  # keep the output in the sigmoid's active range
+        if k.startswith("tail."):
+            sd[k] = sd[k] * 1.0e-5
+    m = build_model(sd, 3)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    g = torch.Generator().manual_seed(11)
+    n = 70000  # enough rays for the one-wave-per-tile kernels to be the natural choice as well
+    o = torch.randn(n, 3, generator=g) * 1.5
+    d = torch.randn(n, 3, generator=g)
+    emb = O.positional_embed(O.sample_train(o[:2048], d[:2048], O.z_vals(16, 2., 6.), 0.), 10)
+    ref, xs, ts = O.r2l_forward(sd, emb, return_acts=True)
+    assert max(x.abs().max().item() for x in xs) > 4.0e4  # the case really leaves the guarded range
+    with torch.no_grad():
+        rgb = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
+        rgb2 = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)  # second launch: status word already raised
+    assert torch.isfinite(rgb).all()
+    # relative bar: with activations of 1e5 the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 tail
+    assert (rgb[:2048].cpu() - ref).abs().max().item() < TOL
+    assert torch.equal(rgb, rgb2)
