@@ -231,17 +231,31 @@ def main():
     rays = H * W * a.steps * world
     value = rays / dt
     achieved = H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
-    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # default path: fp32-accurate products on the bf16 MFMA
-    traffic, traffic_src = pmc_traffic("void r2l_fwd3_kernel<true>" if fwd3 else "void r2l_fwd_kernel<1, false>")
-    # every fp32 product costs six bf16 MFMA products on that path: its matrix-pipe peak in algorithmic FLOP/s is the
-    # dense bf16 peak / 6; the exact-fp32 MFMA peak is kept beside it for reference
-    peak = PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA
+    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # matrix-pipe paths built from low-precision MFMA products
+    fwd2 = fwd3 and not os.environ.get("R2L_NO_FWD2", "0").strip("0")  # default of forward-only launches: 3 fp16 products
+    traffic, traffic_src = pmc_traffic("void r2l_fwd2_kernel<true" if fwd2 else
+                                       ("void r2l_fwd3_kernel<true" if fwd3 else "void r2l_fwd_kernel<1, false>"))
+    # matrix-pipe peak in ALGORITHMIC FLOP/s: every fp32 product costs three fp16 MFMA products on the default path (six
+    # bf16 products on the bf16x3 path), so it is the dense fp16/bf16 MFMA peak / 3 (/ 6); the exact-fp32 MFMA peak is kept
+    # beside it for reference
+    peak = PEAK_BF16_MFMA / 3. if fwd2 else (PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA)
+    dtype = ("f32 (every product as 3 fp16 MFMA products of two-way fp16 operand splits hi + mid, ~2^-21 relative, fp32 "
+             "accumulate; range-guarded, bf16x3 fallback)" if fwd2 else
+             ("f32 (products as 6 bf16 MFMA terms of exact bf16 hi/mid/lo splits, fp32 accumulate)" if fwd3 else "f32"))
+    peak_note = ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); the default forward-only kernel (r2l_fwd2.hip) "
+                 "evaluates every fp32 product as 3 fp16 MFMA products (operands as fp16 hi + mid: 22 mantissa bits; measured "
+                 "max |dRGB| 1.3e-6 against the fp32 oracle, bar 1e-4), so its matrix-pipe peak in algorithmic FLOP/s is the "
+                 "dense 16-bit MFMA peak 2500 TF / 3; the chip is power-limited under such a stream (1.5-1.8 GHz instead of "
+                 "the nominal 2.4 GHz the peak assumes: profiles/r01_summary.md, r01_clock_probe.txt)" if fwd2 else
+                 ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); this kernel evaluates every fp32 product as 6 "
+                  "bf16 MFMA products (exact bf16 hi/mid/lo splits): peak = dense bf16 MFMA peak 2500 TF / 6; the chip runs at "
+                  "1.72-1.77 GHz (power limit) under that load" if fwd3 else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"))
 
     out = {
         "metric": "rays/sec (train+render) W256D88 lego@400x400", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (products as 6 bf16 MFMA terms of exact bf16 hi/mid/lo splits, fp32 accumulate)" if fwd3 else "f32",
+        "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": "R2L W256D88 render_test 400x400 testskip=1: 1 frame (160000 rays, 16 samples/ray, "
                                "L=10) per GPU per step, fused sample+encode+ResMLP forward; seeded weights, "
@@ -251,20 +265,30 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_fp32_mfma": PEAK_FP32_MFMA,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
-                     "peak_note": ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); the default kernel evaluates "
-                                   "every fp32 product as 6 bf16 MFMA products (exact bf16 hi/mid/lo splits), so its matrix-pipe "
-                                   "peak in algorithmic FLOP/s is the dense bf16 MFMA peak 2500 TF / 6; under that load the chip "
-                                   "runs at 1.72-1.77 GHz (power limit) instead of the nominal 2.4 GHz the peak assumes "
-                                   "(profiles/r01_summary.md, r01_clock_probe.txt)")
-                     if fwd3 else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                     "peak_note": peak_note,
                      "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
-                                     "bytes per launch = 160000 rays x 12 B out + the packed weight stream (37.6 MB of "
-                                     "bf16 triples / 24.3 MB fp32)" % traffic_src,
-                     "kernel": "r2l_fwd3_kernel<POSE>" if fwd3 else "r2l_fwd_kernel<MODE_POSE>", "kernel_ms": kernel_ms,
+                                     "bytes per launch = 160000 rays x 12 B out + the packed weight stream (25.1 MB of "
+                                     "fp16 pairs / 37.6 MB of bf16 triples / 24.3 MB fp32)" % traffic_src,
+                     "kernel": ("r2l_fwd2_kernel<POSE> (+ the idle range-guard launch of r2l_fwd3_kernel)" if fwd2 else
+                                ("r2l_fwd3_kernel<POSE>" if fwd3 else "r2l_fwd_kernel<MODE_POSE>")),
+                     "kernel_ms": kernel_ms,
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }
 
+    if fwd2 and rank == 0 and world == 1:
+        # the same frame on the bf16x3 kernel (six bf16 products per fp32 product: fp32-exact products), for reference
+        os.environ["R2L_NO_FWD2"] = "1"
+        try:
+            dt3, k3 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
+        finally:
+            del os.environ["R2L_NO_FWD2"]
+        n3 = max(3, a.steps // 4)
+        a3 = H * W * FWD_FLOP_PER_RAY / (k3 * 1e-3) / 1e12
+        out["render_bf16x3"] = {"value": H * W * n3 / dt3, "unit": "rays/s", "ms_per_step": dt3 / n3 * 1e3,
+                                "roofline": {"bound": "mfma", "achieved": a3, "peak": PEAK_BF16_MFMA / 6., "unit": "TFLOP/s",
+                                             "frac": a3 / (PEAK_BF16_MFMA / 6.), "kernel": "r2l_fwd3_kernel<POSE>",
+                                             "kernel_ms": k3}}
     if fwd3 and rank == 0 and world == 1:
         # the same frame on the exact-fp32 MFMA kernel (r2l_forward.hip), for reference: the C side reads the switch per call
         os.environ["R2L_NO_FWD3"] = "1"

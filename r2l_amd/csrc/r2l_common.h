@@ -387,7 +387,7 @@ static inline bool r2l_use_fwd3() {
     const char* e = getenv("R2L_NO_FWD3");
     return !(e && e[0] && e[0] != '0');
 }
-// forward-only launches (no training stash): three fp16 products per fp32 product, ~2^-21 relative (r2l_fwd2.hip), with
+// one-wave-per-tile forward launches: three fp16 products per fp32 product, ~2^-21 relative (r2l_fwd2.hip), with
 // the bf16x3 kernel launched behind it as the range-guard fallback (it returns at once unless the status word is raised).
 // R2L_NO_FWD2=1: bf16x3 only.
 static inline bool r2l_use_fwd2() {
@@ -397,7 +397,7 @@ static inline bool r2l_use_fwd2() {
 int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream);
 int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
-                     int n_block, float* rgb, int64_t N, hipStream_t stream);
+                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
 int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
 // run_if: nullptr, or a device word — the launch returns at once while it is 0 (fallback behind r2l_fwd2_forward)
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,

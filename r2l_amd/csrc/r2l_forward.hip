@@ -265,14 +265,14 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
     if (variant == R2L_VARIANT_COOP)
         return r2l_coop_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream, params, n_block, rgb, save_x,
                                 save_t, N, (hipStream_t)stream);
-    if (N > 0 && save_x == nullptr && r2l_use_fwd2()) {
+    if (N > 0 && r2l_use_fwd2()) {
         const float* w3 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
         const float* w2 = w3 + r2l_fwd3_stream_floats(n_block);
-        const int rc = r2l_fwd2_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w2, params, n_block, rgb, N,
-                                        (hipStream_t)stream);
+        const int rc = r2l_fwd2_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w2, params, n_block, rgb, save_x,
+                                        save_t, N, (hipStream_t)stream);
         if (rc) return rc;
         // range-guard fallback: returns at once unless the fp16x2 launch raised its status word
-        return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w3, params, n_block, rgb, nullptr, nullptr, N,
+        return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w3, params, n_block, rgb, save_x, save_t, N,
                                 (hipStream_t)stream, reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block)));
     }
     if (N > 0 && r2l_use_fwd3())
@@ -301,7 +301,7 @@ extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float foc
         const float* w3 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
         const float* w2 = w3 + r2l_fwd3_stream_floats(n_block);
         const int rc = r2l_fwd2_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, w2, params, n_block, rgb,
-                                        a.N, (hipStream_t)stream);
+                                        nullptr, nullptr, a.N, (hipStream_t)stream);
         if (rc) return rc;
         return r2l_fwd3_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, w3, params, n_block, rgb, nullptr,
                                 nullptr, a.N, (hipStream_t)stream,

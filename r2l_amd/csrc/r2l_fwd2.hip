@@ -1,6 +1,7 @@
 // r2l_fwd2.hip — the R2L student forward on the fp16 matrix pipe with two-way operand splits (see r2l_f2.h): every fp32
 // product as three fp16 MFMA products, ~2^-21 relative.  Structure, stage order and gatherers are r2l_fwd3.hip's; stages are
-// 16 KiB ([split 2][tile 8][lane 64][8 fp16]).  Forward-only launches (render / evaluation), opt-in: R2L_FWD2=1.
+// 16 KiB ([split 2][tile 8][lane 64][8 fp16]).  Default of every one-wave-per-tile forward launch (render / evaluation and the training forward with its stash);
+// R2L_NO_FWD2=1: bf16x3 only.
 #include "r2l_f2.h"
 
 __host__ __device__ static inline int64_t f2_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
@@ -317,17 +318,18 @@ int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t
 
 int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
-                     int n_block, float* rgb, int64_t N, hipStream_t stream) {
+                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream) {
     F2Args a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.stream = reinterpret_cast<const unsigned char*>(wstream2); a.params = params;
     // the status word lives in the caller's stream buffer (library-private contents): written through, hence the cast
     a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + r2l_fwd2_status_offset(n_block));
-    a.n_block = n_block; a.rgb = rgb; a.save_x = nullptr; a.save_t = nullptr; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
+    a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     if (c2w_host12) hipLaunchKernelGGL((r2l_fwd2_kernel<true, false>), grid, block, 0, stream, a);
+    else if (save_x) hipLaunchKernelGGL((r2l_fwd2_kernel<false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((r2l_fwd2_kernel<false, false>), grid, block, 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;

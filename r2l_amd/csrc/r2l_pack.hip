@@ -140,7 +140,8 @@ extern "C" int r2l_variant_for(int64_t N) { return r2l_chain_variant(N); }
 extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
-    if (v == R2L_VARIANT_MAIN && !with_stash && r2l_use_fwd2()) return 2;
+    (void)with_stash;
+    if (v == R2L_VARIANT_MAIN && r2l_use_fwd2()) return 2;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return 3;
     return 32;
 }

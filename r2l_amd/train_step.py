@@ -76,6 +76,8 @@ class R2LTrainer:
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
         ver, layout = eng.version(), eng.layout_for(n)  # 16 / 32 / 3: same choice as the forward (r2l_backward dispatches alike)
+        if layout == 2:  # fp16x2 forward: the gradient kernels behind it read the bf16x3 transposed stream
+            layout = 3
         if self._bwd_packed is None:
             self._bwd_packed = {16: None, 32: None, 3: None}
         if self._bwd_packed[layout] != ver:

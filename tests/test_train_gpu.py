@@ -12,11 +12,12 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "main-grad3", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "main-bf16x3", "main-grad3", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
-    """Every test runs under each chain kernel family: one wave per tile on the bf16x3 matrix path (r2l_fwd3.hip /
-    r2l_bwd3.hip; also with the opt-in 3-product gradient GEMMs, R2L_GRAD_TERMS=3) and on the fp32 MFMA (R2L_NO_FWD3=1),
-    and the two cooperative small-batch families."""
+    """Every test runs under each chain kernel family: one wave per tile with the fp16x2 forward (r2l_fwd2.hip, default)
+    or the bf16x3 forward (R2L_NO_FWD2=1) in front of the bf16x3 gradient kernels (r2l_bwd3.hip, r2l_dw_body3c; also with the
+    opt-in 3-product gradient GEMMs, R2L_GRAD_TERMS=3), everything on the fp32 MFMA (R2L_NO_FWD3=1), and the two cooperative
+    small-batch families."""
     name = request.param
     monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
     if name == "main-f32mfma":
@@ -27,6 +28,10 @@ def chain_variant(request, monkeypatch):
         monkeypatch.setenv("R2L_GRAD_TERMS", "3")
     else:
         monkeypatch.delenv("R2L_GRAD_TERMS", raising=False)
+    if name == "main-bf16x3":
+        monkeypatch.setenv("R2L_NO_FWD2", "1")
+    else:
+        monkeypatch.delenv("R2L_NO_FWD2", raising=False)
     return name
 T = torch.from_numpy
 
