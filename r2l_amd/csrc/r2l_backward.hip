@@ -227,6 +227,11 @@ struct R2LDwArgs {
     int64_t units_per_wg;
     float* slab;  // [wgs][2][DW_SLAB_FLOATS] per-workgroup partial (dW, db) of the <= 2 layers its range touches, or
                   // nullptr -> fp32 atomics straight into grads
+    float unscale = 1.0f;  // the gradient operands carry a power-of-two scale (r2l_bwd3): dW, db are multiplied by its inverse
+    // range guard of the fp16 variant (r2l_dw_body3c_kernel<3, true>): it raises *status when an operand value leaves fp16's
+    // safe range; the bf16 variant launched behind it with run_if = status then redoes the launch (else returns at once)
+    unsigned* status = nullptr;
+    const unsigned* run_if = nullptr;
 };
 
 #define DW_SLAB_FLOATS (R2L_W * R2L_W + R2L_W)  // one layer: dW[256][256] then db[256], as in the flat gradient
@@ -634,8 +639,35 @@ struct Dw3cQuad {
     float r[4];
     unsigned uh[2], um[2], ul[2];
 };
-// part 0: hi + first residual; part 1: mid + second residual; part 2: lo  (TERMS == 3: parts 0, 1 only)
+__device__ __forceinline__ unsigned dw3c_pk16(float a0, float a1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, h2));
+}
+__device__ __forceinline__ float dw3c_lo16(unsigned u) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(h2, u)[0];
+}
+__device__ __forceinline__ float dw3c_hi16(unsigned u) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(h2, u)[1];
+}
+// part 0: hi + first residual; part 1: mid + second residual; part 2: lo  (TERMS == 3: parts 0, 1 only).
+// F16: two-way fp16 split (hi = fp16(x), mid = fp16(x - hi): x to ~2^-22) instead of bf16 parts
+template <bool F16>
 __device__ __forceinline__ void dw3c_split_part(Dw3cQuad& q, const f32x4& x, int part) {
+    if (F16) {
+        if (part == 0) {
+            q.uh[0] = dw3c_pk16(x[0], x[1]);
+            q.uh[1] = dw3c_pk16(x[2], x[3]);
+            q.r[0] = x[0] - dw3c_lo16(q.uh[0]); q.r[1] = x[1] - dw3c_hi16(q.uh[0]);
+            q.r[2] = x[2] - dw3c_lo16(q.uh[1]); q.r[3] = x[3] - dw3c_hi16(q.uh[1]);
+        } else {
+            q.um[0] = dw3c_pk16(q.r[0], q.r[1]);
+            q.um[1] = dw3c_pk16(q.r[2], q.r[3]);
+        }
+        return;
+    }
     if (part == 0) {
         q.uh[0] = dw3_pk(x[0], x[1]);
         q.uh[1] = dw3_pk(x[2], x[3]);
@@ -656,9 +688,12 @@ __device__ __forceinline__ void dw3c_write(unsigned addr, unsigned d0, unsigned 
     *(lds_u2*)(size_t)addr = dw3c_u32x2{d0, d1};
 }
 
-template <int TERMS>
+template <int TERMS, bool F16>
 __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char img[2][DW3C_BUF_BYTES];
+    static_assert(!F16 || TERMS == 3, "the fp16 variant is the 3-product scheme");
+    if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
+    float amax = 0.f;  // F16: largest |operand value| this lane converted
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wo = wave >> 1, wi = wave & 1;
@@ -744,8 +779,12 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                 dw3c_wait7(raw[k]);
                 // (raw holds step s_next - 1: a clamped reload past the end must not be counted)
                 if (k < 4) bacc[k] += raw[k] * ((s_next - 1 < nsteps) ? 1.f : 0.f);
+                if (F16) {
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][0])), __builtin_fabsf(raw[k][1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][2])), __builtin_fabsf(raw[k][3]));
+                }
             }
-            dw3c_split_part(qs, raw[k], part);
+            dw3c_split_part<F16>(qs, raw[k], part);
             if (part == (TERMS == 6 ? 2 : 1)) {
                 const unsigned wa = wbase[k & 1] + (unsigned)buf * DW3C_BUF_BYTES + (unsigned)(k >> 2) * DW3C_OP_BYTES + (unsigned)(k & 3) * 512u;
                 dw3c_write(wa, qs.uh[0], qs.uh[1]);
@@ -771,7 +810,13 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
 #pragma unroll
                 for (int ei = 0; ei < 4; ++ei) {
                     const dw3_bf16x8& xb = (tk == 1) ? C.xs[ei].l : (tk == 2 || tk == 4) ? C.xs[ei].m : C.xs[ei].h;
-                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga2, xb, acc[eo][ei], 0, 0, 0);
+                    if (F16) {
+                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga2), __builtin_bit_cast(f16x8, xb),
+                                                                             acc[eo][ei], 0, 0, 0);
+                    } else {
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga2, xb, acc[eo][ei], 0, 0, 0);
+                    }
                 }
                 if (TERMS == 6) {  // 24 groups: 24 fragments, 8 quads x 3 parts
                     dw3c_frag<6>(g, Nx, gp, ap);
@@ -802,7 +847,11 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                     dw3c_wait0(raw[k]);
                     if (k < 4) bacc[k] += raw[k];
 #pragma unroll
-                    for (int part = 0; part < (TERMS == 6 ? 3 : 2); ++part) dw3c_split_part(qs, raw[k], part);
+                    for (int part = 0; part < (TERMS == 6 ? 3 : 2); ++part) dw3c_split_part<F16>(qs, raw[k], part);
+                    if (F16) {
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][0])), __builtin_fabsf(raw[k][1]));
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][2])), __builtin_fabsf(raw[k][3]));
+                    }
                     const unsigned wa = wbase[k & 1] + (unsigned)s * DW3C_BUF_BYTES + (unsigned)(k >> 2) * DW3C_OP_BYTES + (unsigned)(k & 3) * 512u;
                     dw3c_write(wa, qs.uh[0], qs.uh[1]);
                     dw3c_write(wa + 8192u, qs.um[0], qs.um[1]);
@@ -836,7 +885,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c];
+                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * a.unscale;
                             acc[eo][ei][c] = 0.f;
                         }
             } else {
@@ -846,7 +895,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c]);
+                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * a.unscale);
                             acc[eo][ei][c] = 0.f;
                         }
             }
@@ -859,6 +908,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                 for (int m = 2; m <= 16; m <<= 1)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], m);
+                v *= a.unscale;
                 if (lj == 0) {
                     const int f = 8 * (8 * wave + 2 * k + lcc) + 4 * lhf;
                     if (sl != nullptr) *reinterpret_cast<f32x4*>(sl + R2L_W * R2L_W + f) = v;
@@ -871,6 +921,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
         }
         u += cend - cu;
     }
+    if (F16 && a.status != nullptr && !(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
 }
 
 // =================================================================================================================
@@ -1158,7 +1209,8 @@ __global__ __launch_bounds__(256) void r2l_tail_reduce_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
-extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS; }
+// (+ 16 floats of status words behind the partials)
+extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS + 16; }
 extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_PAD_ROWS(N) * (int64_t)R2L_W; }
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
@@ -1183,6 +1235,15 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
     const int variant = r2l_chain_variant(N);
     // the bf16x3 trio (r2l_fwd3 wrote the stash): chunked stash layout, see r2l_common.h
     const bool split = r2l_stash_chunked(N, emb != nullptr);
+    // MSE mode of the trio: the dX chain runs on gscale * g, gscale = 2^(8 - e) for grad_scale = m * 2^e (m in [0.5, 1)): the
+    // seed gscale * dL/dpre is then <= 64 |rgb - target|, which puts the chain's values into fp16's range for the fp16
+    // gradient kernels; powers of two commute with fp32 rounding, so the scaled chain is bit-identical after unscaling
+    float gscale = 1.0f;
+    if (split && target != nullptr && grad_scale > 0.f) {
+        int e = 0;
+        (void)frexpf(grad_scale, &e);
+        gscale = ldexpf(1.0f, 8 - e);
+    }
     if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
                                            params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
@@ -1195,7 +1256,7 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         // one-wave-per-tile dX chain on the bf16 matrix pipe (fp32-accurate products): r2l_bwd3.hip
         const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t,
                                          wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
-                                         params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
+                                         params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream, gscale);
         if (rc) return rc;
     } else {
         R2LBwdArgs a{};
@@ -1220,8 +1281,25 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         a.slab = (a.units_per_wg <= a.units_per_layer) ? dw_slab : nullptr;
         // bf16 matrix pipe at fp32 accuracy: operands split once per workgroup from the chunked stash of the bf16x3 chains
         // (r2l_dw_body3c), or per wave from the row-major stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
-        if (split && r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_dw_body3c_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
-        else if (split) hipLaunchKernelGGL(r2l_dw_body3c_kernel<6>, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        // chunked stash: the gradient operands carry the chain's power-of-two scale
+        if (split) a.unscale = 1.0f / gscale;
+        // default in MSE mode (operand range known up to the guard): two-way fp16 splits, 3 fp16 products per fp32 product,
+        // with the bf16 6-product kernel behind it as range-guard fallback (status word at the end of dw_slab)
+        const bool dw16 = split && target != nullptr && a.slab != nullptr && r2l_grad_terms() == 6 && !getenv("R2L_NO_DW2");
+        if (dw16) {
+            unsigned* status = reinterpret_cast<unsigned*>(dw_slab + (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS);
+            R2L_CHECK(hipMemsetAsync(status, 0, 64, stream));
+            a.status = status;
+            hipLaunchKernelGGL((r2l_dw_body3c_kernel<3, true>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
+            R2L_CHECK(hipGetLastError());
+            a.status = nullptr;
+            a.run_if = status;
+            hipLaunchKernelGGL((r2l_dw_body3c_kernel<6, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        } else if (split && r2l_grad_terms() == 3) {
+            hipLaunchKernelGGL((r2l_dw_body3c_kernel<3, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        } else if (split) {
+            hipLaunchKernelGGL((r2l_dw_body3c_kernel<6, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
+        }
         else if (r2l_use_fwd3()) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());

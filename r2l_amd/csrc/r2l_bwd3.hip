@@ -66,6 +66,7 @@ struct B3Args {
     const float* params;
     int n_block;
     float grad_scale;
+    float gscale, ginv;  // the chain runs on gscale * g (a power of two; what it stashes is scaled), gx[0] is scaled back
     float* dpre;
     float* gx;
     float* gt;
@@ -169,9 +170,9 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
                 for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = wv[0][j] * dp[0];
-                    v = __builtin_fmaf(wv[1][j], dp[1], v);
-                    v = __builtin_fmaf(wv[2][j], dp[2], v);
+                    float v = wv[0][j] * (dp[0] * a.gscale);
+                    v = __builtin_fmaf(wv[1][j], dp[1] * a.gscale, v);
+                    v = __builtin_fmaf(wv[2][j], dp[2] * a.gscale, v);
                     g[T][4 * q + j] = v;
                     dy[T][4 * q + j] = v;
                 }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(r + R2L_CHUNK_PIECE * (4 * T + q));
                 f32x4 ov;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? g[T][4 * q + j] + dy[T][4 * q + j] : 0.f;
+                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? (g[T][4 * q + j] + dy[T][4 * q + j]) * a.ginv : 0.f;
                 *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = ov;
             }
     }
@@ -291,8 +292,9 @@ int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t
 
 int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream) {
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale) {
     B3Args a{};
+    a.gscale = gscale; a.ginv = 1.0f / gscale;
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;

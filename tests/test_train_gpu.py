@@ -234,3 +234,32 @@ def test_graph_replayed_steps_equal_eager_steps(monkeypatch):
         assert torch.equal(a, b)
     assert out["eager"][4] == out["graph"][4] == 6
     assert out["eager"][3][-1, 0] < out["eager"][3][0, 0]  # and the loss went down
+
+
+def test_fp16_range_guards_in_training():
+    """Activations beyond fp16's range (head scaled up until |x| ~ 1e5): the fp16 forward and the fp16 dW kernel raise
+    their status words and the bf16x3 kernels behind them redo the launches: gradients still match the oracle."""
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    sd = {k: v.clone() for k, v in O.make_state_dict(n_block=3, seed=4).items()}
+    sd["head.0.weight"] *= 3.0e4
+    sd["head.0.bias"] *= 3.0e4
+    for k in sd:
+        if k.startswith("tail."):
+            sd[k] = sd[k] * 1.0e-5
+    m = build_model(sd, 3)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    gen = torch.Generator().manual_seed(21)
+    n = 600
+    o = torch.randn(n, 3, generator=gen) * 1.5
+    d = torch.randn(n, 3, generator=gen)
+    tgt = torch.rand(n, 3, generator=gen)
+    emb = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
+    loss, rgb_ref, gref = O.r2l_loss_and_grads(sd, emb, tgt)
+    tr = R2LTrainer(m, ps)
+    rgb = tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda())
+    assert (rgb.cpu() - rgb_ref).abs().max().item() < 1e-4
+    grads = split_flat(tr.grads.cpu(), sd)
+    for k in sd:
+        assert torch.isfinite(grads[k]).all(), k
+        assert rel_err(grads[k], gref[k]) < 2e-3, (k, rel_err(grads[k], gref[k]))
