@@ -27,12 +27,16 @@ int64_t r2l_bwd_stream_floats(int n_block);  /* size of the packed transposed (d
 /* Re-pack params into the MFMA A-operand weight streams the chain kernels read (call after every weight update). */
 int r2l_pack_forward(const float* params, int n_block, float* wstream, void* stream);
 int r2l_pack_backward(const float* params, int n_block, float* wstream_bwd, void* stream);
-/* Per-layout form: layout = 32 (one-wave-per-tile and 32-ray cooperative kernels), 16 (16-ray cooperative kernels), 3
- * (forward stream only: bf16 (hi, mid, lo) stages of the forward-only kernel r2l_fwd3.hip) or 0 (all parts, =
+/* Per-layout form: layout = 32 (fp32-MFMA one-wave-per-tile and 32-ray cooperative kernels), 16 (16-ray cooperative
+ * kernels), 3 (bf16 (hi, mid, lo) stages: r2l_fwd3.hip / r2l_bwd3.hip), 2 (fp16 (hi, mid) stages: r2l_fwd2.hip /
+ * r2l_bwd2.hip; fills layout 3 as well, their fallback) or 0 (all parts, =
  * r2l_pack_forward/backward).  r2l_variant_for(N) tells which chain variant a call with N rays will take
  * (0 main, 1 coop: layout 32; 2 coop16: layout 16), honouring R2L_FORCE_VARIANT. */
 int r2l_variant_for(int64_t N);
-int r2l_forward_layout_for(int64_t N, int with_stash); /* 16, 32, or 3 = the bf16x3 forward-only kernel's stage stream */
+int r2l_forward_layout_for(int64_t N, int with_stash); /* 16, 32, 3 = bf16x3 stage stream, 2 = fp16x2 stage stream (+ the
+                                                         * bf16x3 one behind it as range-guard fallback) */
+/* Same for the transposed stream r2l_backward reads for N rays (r2l_pack_backward_layout takes the value). */
+int r2l_backward_layout_for(int64_t N);
 int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream);
 int r2l_pack_backward_layout(const float* params, int n_block, float* wstream, int layout, void* stream);
 

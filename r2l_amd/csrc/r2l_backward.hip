@@ -1253,10 +1253,21 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
                                          gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;
     } else if (split) {
-        // one-wave-per-tile dX chain on the bf16 matrix pipe (fp32-accurate products): r2l_bwd3.hip
-        const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t,
-                                         wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
-                                         params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream, gscale);
+        // one-wave-per-tile dX chain.  MSE mode (scaled chain, values in fp16's range up to the guard): two-way fp16 splits,
+        // 3 fp16 products per fp32 product (r2l_bwd2.hip), with the bf16x3 chain behind it as range-guard fallback (returns at
+        // once unless the status word behind the bwd2 stream was raised); otherwise the bf16x3 chain (r2l_bwd3.hip)
+        const float* w3 = wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
+        const float* w2 = w3 + r2l_bwd3_stream_floats(n_block);
+        const bool bwd16 = target != nullptr && r2l_use_bwd2();
+        unsigned* status = reinterpret_cast<unsigned*>(const_cast<float*>(w2) + r2l_bwd2_status_offset(n_block));
+        if (bwd16) {
+            R2L_CHECK(hipMemsetAsync(status, 0, 64, stream));
+            const int rc = r2l_bwd2_backward(rgb, target, drgb, save_x, save_t, w2, params, n_block, grad_scale, dpre, gx, gt,
+                                             sqerr_partial, N, stream, gscale, status);
+            if (rc) return rc;
+        }
+        const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t, w3, params, n_block, grad_scale, dpre, gx, gt,
+                                         sqerr_partial, N, stream, gscale, bwd16 ? status : nullptr);
         if (rc) return rc;
     } else {
         R2LBwdArgs a{};

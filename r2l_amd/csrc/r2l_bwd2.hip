@@ -1,62 +1,52 @@
-// r2l_bwd3.hip — the dX chain of the R2L student backward at fp32 accuracy on the bf16 matrix pipe (same scheme as
-// r2l_fwd3.hip, machinery in r2l_f3.h): one wave = 32 rays, per block  u = (W2^T g) * [t_b > 0],  g += W1^T u,  writing
-// g (-> gx[b+1]) and the masked u (-> gt[b]) for the weight-gradient GEMMs.
-//   * stage stream: per block (last block first) [zero stage, 16 k-blocks of W2^T, zero stage, 16 k-blocks of W1^T].  The
-//     all-zero "bias" stages cost 8 MFMAs each and buy what the bias stages give the forward: u is zero-initialised by the
-//     matrix pipe, and the B values of a GEMM's first k-block are gathered AFTER the previous GEMM has finished;
-//   * the B values of every stage are exactly what has to be stashed (g, masked u): the stores ride along the gathers;
-//   * the ReLU mask of the block is read from the forward stash save_t[b] without any register load: one 1 KiB tile piece
-//     per half stage is DMA'd into a per-wave LDS ring during the first GEMM, folded into 128 mask bits per lane eight half
-//     stages later (by then the staging pipeline's own `vmcnt` waits have guaranteed its arrival), and applied when u is
-//     gathered as the B operand of the second GEMM;
-//   * dy (the outer-residual branch) waits in scratch for the head.
-#include "r2l_f3.h"
+// r2l_bwd2.hip — the dX chain of r2l_bwd3.hip on the fp16 matrix pipe with two-way operand splits (machinery: r2l_f2.h):
+// three fp16 products per fp32 product, ~2^-21 relative.  The chain runs on gscale * g (a power of two chosen from the MSE
+// gradient scale, r2l_backward), which puts its values into fp16's range; a range guard raises a status word and the bf16x3
+// kernel launched behind it redoes the launch.  Stage order, mask ring and stash stores are r2l_bwd3.hip's; six 16 KiB
+// weight buffers fit beside the 32 KiB mask ring.
+#include "r2l_f2.h"
 
-#define B3_NBUF 5
 #define B3_RING 8  // mask pieces in flight per wave
 
-__host__ __device__ static inline int64_t b3_off_body_w(int layer) {
+__host__ __device__ static inline int64_t b2_off_body_w(int layer) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
 }
-__host__ __device__ static inline int64_t b3_off_tail_w(int n_block) { return b3_off_body_w(2 * n_block); }
+__host__ __device__ static inline int64_t b2_off_tail_w(int n_block) { return b2_off_body_w(2 * n_block); }
 
 // =================================================================================================================
-// pack: stage g = 34 * slot + r, slot = n_block-1-b;  r = 0 / 17: zero stages;  r = 1..16: k-block r-1 of W2^T (layer 2b+1);
-// r = 18..33: k-block r-18 of W1^T (layer 2b).  Element (split, tile t, lane (i,h), slot s): (W^T)[32t+i][feature(kb,h,s)]
+// pack: stage order and element numbering of r2l_pack_bwd2_kernel, two fp16 splits per value, 16 KiB stages
 // =================================================================================================================
-__global__ void r2l_pack_bwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
+__global__ void r2l_pack_bwd2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
     const int64_t stages = r2l_bwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
         const int64_t g = idx >> 12;
         const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
-        unsigned short* st = out + g * (F3_STAGE_BYTES / 2);
-        unsigned short v0 = 0, v1 = 0, v2 = 0;
+        unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
+        unsigned short v0 = 0, v1 = 0;
         if (g < stages) {
             const int slot = (int)(g / 34), r = (int)(g % 34), b = n_block - 1 - slot;
             if (r != 0 && r != 17) {
                 const int layer = r < 17 ? 2 * b + 1 : 2 * b, kb = r < 17 ? r - 1 : r - 18;
                 const int T = kb >> 1, rr = kb & 1;
                 const int in = 32 * T + 8 * (2 * rr + (s >> 2)) + 4 * h + (s & 3);
-                const float w = params[b3_off_body_w(layer) + (int64_t)in * R2L_W + o];  // (W^T)[o][in] = W[in][o]
-                v0 = f3_bf16_rne(w);
-                const float r1 = w - f3_bf16_to_f(v0);
-                v1 = f3_bf16_rne(r1);
-                v2 = f3_bf16_rne(r1 - f3_bf16_to_f(v1));
+                const float w = params[b2_off_body_w(layer) + (int64_t)in * R2L_W + o];  // (W^T)[o][in] = W[in][o]
+                const _Float16 hi = (_Float16)w;
+                const _Float16 mid = (_Float16)(w - (float)hi);
+                v0 = __builtin_bit_cast(unsigned short, hi);
+                v1 = __builtin_bit_cast(unsigned short, mid);
             }
         }
         const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
         st[e] = v0;
         st[8 * 64 * 8 + e] = v1;
-        st[2 * 8 * 64 * 8 + e] = v2;
     }
 }
 
 // =================================================================================================================
 // kernel
 // =================================================================================================================
-struct B3Args {
+struct B2Args {
     const float* rgb;
     const float* target;
     const float* drgb;
@@ -67,7 +57,7 @@ struct B3Args {
     int n_block;
     float grad_scale;
     float gscale, ginv;  // the chain runs on gscale * g (a power of two; what it stashes is scaled), gx[0] is scaled back
-    const unsigned* run_if;  // nullptr, or: return at once while this word is 0 (range-guard fallback of r2l_bwd2.hip)
+    unsigned* status;    // range guard: raised when a chain value leaves fp16's safe range (the bf16x3 kernel then redoes it)
     float* dpre;
     float* gx;
     float* gt;
@@ -115,11 +105,9 @@ struct B3TakeU {  // u values masked by relu'(t_b), stored to gt[b]
     }
 };
 
-template <int TERMS>
-__global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char wbuf[B3_NBUF][F3_STAGE_BYTES];
+__global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
-    if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
 
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -162,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     // g = dy = Wt^T dpre   (tail Linear(256,3))
     f32x16 g[R2L_NT], u[R2L_NT], dy[R2L_NT];
     {
-        const float* tw = a.params + b3_off_tail_w(a.n_block);
+        const float* tw = a.params + b2_off_tail_w(a.n_block);
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
@@ -181,33 +169,32 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
             }
     }
 
-    // ---- weight staging (5 buffers: 32 KiB of LDS go to the mask ring) --------------------------------------------------------
-    typedef F3PipeT<B3_NBUF, TERMS> Pipe;
-    Pipe P;
+    // ---- weight staging (6 buffers of 16 KiB beside the 32 KiB mask ring) ------------------------------------------------------
+    F2Pipe P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
         P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         P.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&wbuf[0][0];
         P.voff = (unsigned)lane * 16u;
-        P.wq = (unsigned)wave * 6144u;
+        P.wq = (unsigned)wave * 4096u;
         P.base = &wbuf[0][0];
         P.lane = lane;
         P.gb = 0;
         P.gq = 0;
         P.gqb = 0;
+        P.amax = 0.f;
     }
-    P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..3
+    P.issue(); P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..4
 #pragma unroll
-    for (int k = 0; k < 8; ++k) P.ones.h[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
+    for (int k = 0; k < 8; ++k) P.ones.h[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
     P.ones.m = P.ones.h;
-    P.ones.l = P.ones.h;
-    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();
     P.lb = P.base + lane * 16;
     {
         F3None none;
-        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}};
+        F2Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax};
 #pragma unroll
         for (int i = 0; i < 6; ++i) s0.step(i);
     }
@@ -242,28 +229,30 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     F3Dma{B3_ISSUE(RHO) >= 0, trs, mvoff, (unsigned)(B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) * (R2L_CHUNK_PIECE * 4u),  \
           ring_lds + (unsigned)((B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) % B3_RING) * 1024u}
         // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
-        f3_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0, mb, ring_lane, B3_FOLD(0)},
+        f2_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0, mb, ring_lane, B3_FOLD(0)},
                                     B3TakeG{g[0], 4, gxs, 0, mb, ring_lane, B3_FOLD(1)}, B3_EXTRA(0), B3_EXTRA(1));
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(
+            f2_stage<false, false, false>(
                 u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 2)},
                 B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 3)},
                 B3_EXTRA(2 * kb + 2), B3_EXTRA(2 * kb + 3));
-        f3_stage<false, false, true>(u, P, F3None{}, F3None{}, B3_EXTRA(32), B3_EXTRA(33));
+        f2_stage<false, false, true>(u, P, F3None{}, F3None{}, B3_EXTRA(32), B3_EXTRA(33));
         // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
-        f3_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb, ring_lane, B3_FOLD(34)},
+        f2_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb, ring_lane, B3_FOLD(34)},
                                      B3TakeU{u[0], 4, gts, 0, mb, ring_lane, B3_FOLD(35)});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(
+            f2_stage<false, false, false>(
                 g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(36 + 2 * kb)},
                 B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(37 + 2 * kb)});
-        f3_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
+        f2_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
 #undef B3_EXTRA
 #undef B3_FOLD
 #undef B3_ISSUE
     }
+
+    if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
 
     // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] ---------------------------------------------------------
     {
@@ -285,25 +274,24 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream) {
-    hipLaunchKernelGGL(r2l_pack_bwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
-                       reinterpret_cast<unsigned short*>(wstream3), n_block);
+int r2l_bwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream) {
+    hipLaunchKernelGGL(r2l_pack_bwd2_kernel, dim3(2048), dim3(256), 0, stream, params,
+                       reinterpret_cast<unsigned short*>(wstream2), n_block);
     R2L_CHECK(hipGetLastError());
     return 0;
 }
 
-int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
-                      const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, const unsigned* run_if) {
-    B3Args a{};
-    a.run_if = run_if;
+int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                      const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status) {
+    B2Args a{};
+    a.status = status;
     a.gscale = gscale; a.ginv = 1.0f / gscale;
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
-    a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
+    a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    if (r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_bwd3_kernel<3>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(r2l_bwd3_kernel<6>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(r2l_bwd2_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -377,10 +377,21 @@ __host__ __device__ static inline int64_t r2l_bwd3_stages(int n_block) { return 
 __host__ __device__ static inline int64_t r2l_bwd3_stream_floats(int n_block) {
     return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
 }
+// fp16x2 dX chain (r2l_bwd2.hip): same stages, 16 KiB each, then 64 bytes of status (word 0: range guard)
+__host__ __device__ static inline int64_t r2l_bwd2_status_offset(int n_block) {
+    return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (16384 / 4);
+}
+__host__ __device__ static inline int64_t r2l_bwd2_stream_floats(int n_block) { return r2l_bwd2_status_offset(n_block) + 16; }
 int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
 int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale = 1.0f);
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale = 1.0f,
+                      const unsigned* run_if = nullptr);
+// the same chain on two-way fp16 splits (r2l_bwd2.hip); status: range-guard word (behind the bwd2 stream region)
+int r2l_bwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream);
+int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                      const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status);
 // forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
 // kernel (R2L_NO_FWD3=1: fp32 MFMA)
 static inline bool r2l_use_fwd3() {
@@ -439,6 +450,9 @@ static inline int r2l_grad_terms() {
     const char* e = getenv("R2L_GRAD_TERMS");
     return (e && e[0] == '3') ? 3 : 6;
 }
+
+// dX chain of the trio on two-way fp16 splits (MSE mode; R2L_NO_BWD2=1 or R2L_GRAD_TERMS=3: bf16 kernels only)
+static inline bool r2l_use_bwd2() { return r2l_grad_terms() == 6 && !getenv("R2L_NO_BWD2"); }
 
 // error plumbing shared by the C-ABI translation units
 extern "C" const char* r2l_last_error(void);

@@ -37,6 +37,7 @@ struct F2Side {
     bool want_b;
     F3Dma dma;
     float& amax;  // running max |B value| of this lane (range guard: fp16 ends at 65504)
+    F3Dma extra = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};  // one more 1 KiB piece, issued with step 5 (backward: mask tile)
     float x[4];
     unsigned uh[2], um[2];  // packed fp16 pairs: values (0,1) and (2,3)
     static __device__ __forceinline__ unsigned pk(float a0, float a1) {
@@ -65,6 +66,7 @@ struct F2Side {
     __device__ __forceinline__ void step(int i) {
         loads(i);
         if (dma.on && i < 4) f3_dma16(dma.rs, dma.voff, dma.so + i * 1024u, dma.la + i * 1024u);
+        if (i == 5 && extra.on) f3_dma16(extra.rs, extra.voff, extra.so, extra.la);
         if (!want_b) return;
         if (i == 0) {
             gather(x);
@@ -156,12 +158,14 @@ struct F2Pipe {
 
 // One stage (see f3_stage): acc (+)= stage k; glo / ghi fill the B values 0-3 / 4-7 of stage k+1.
 template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
-__device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi) {
-    F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax};
+__device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi,
+                                         F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
+                                         F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u}) {
+    F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax, extra_a};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
     P.sync_next();
-    F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax};
+    F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax, extra_b};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {

@@ -128,7 +128,8 @@ extern "C" int64_t r2l_fwd_stream_floats(int n_block) {
 }
 
 extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
-    return r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block) + r2l_bwd3_stream_floats(n_block);
+    return r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block) + r2l_bwd3_stream_floats(n_block) +
+           r2l_bwd2_stream_floats(n_block);
 }
 
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
@@ -143,6 +144,14 @@ extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
     (void)with_stash;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd2()) return 2;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return 3;
+    return 32;
+}
+// transposed-stream layout the backward of an N-ray launch reads: 16 / 32 as the forward, 3 (bf16x3 dX chain) or 2 (fp16x2 dX
+// chain with the bf16x3 stream behind it as range-guard fallback: r2l_pack_backward_layout(2) fills both)
+extern "C" int r2l_backward_layout_for(int64_t N) {
+    const int v = r2l_chain_variant(N);
+    if (v == R2L_VARIANT_COOP16) return 16;
+    if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return r2l_use_bwd2() ? 2 : 3;
     return 32;
 }
 extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream) {
@@ -179,8 +188,15 @@ extern "C" int r2l_pack_backward_layout(const float* params, int n_block, float*
                            wstream + r2l_bwd32_stream_floats(n_block), n_block);
         R2L_CHECK(hipGetLastError());
     }
-    if (layout == 0 || layout == 3) {
+    if (layout == 0 || layout == 3 || layout == 2) {  // (2: the bf16x3 stream is the range-guard fallback of the fp16x2 one)
         const int rc = r2l_bwd3_pack(params, n_block, wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
+                                     (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (layout == 0 || layout == 2) {
+        const int rc = r2l_bwd2_pack(params, n_block,
+                                     wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block) +
+                                         r2l_bwd3_stream_floats(n_block),
                                      (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -207,6 +223,10 @@ extern "C" int r2l_pack_backward(const float* params, int n_block, float* wstrea
     hipLaunchKernelGGL(r2l_pack_bwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
                        wstream + r2l_bwd32_stream_floats(n_block), n_block);
     R2L_CHECK(hipGetLastError());
-    return r2l_bwd3_pack(params, n_block, wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
+    const int rc = r2l_bwd3_pack(params, n_block, wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
+                                 (hipStream_t)stream);
+    if (rc) return rc;
+    return r2l_bwd2_pack(params, n_block,
+                         wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block) + r2l_bwd3_stream_floats(n_block),
                          (hipStream_t)stream);
 }

@@ -75,11 +75,9 @@ class R2LTrainer:
     def _pack_bwd(self, n):
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
-        ver, layout = eng.version(), eng.layout_for(n)  # 16 / 32 / 3: same choice as the forward (r2l_backward dispatches alike)
-        if layout == 2:  # fp16x2 forward: the gradient kernels behind it read the bf16x3 transposed stream
-            layout = 3
-        if self._bwd_packed is None:
-            self._bwd_packed = {16: None, 32: None, 3: None}
+        ver, layout = eng.version(), self.lib.r2l_backward_layout_for(int(n))  # 16 / 32 / 3 / 2: what r2l_backward will read
+        if self._bwd_packed is None:  # (layout 2 = the fp16x2 stream plus the bf16x3 one behind it)
+            self._bwd_packed = {16: None, 32: None, 3: None, 2: None}
         if self._bwd_packed[layout] != ver:
             _lib.check(self.lib.r2l_pack_backward_layout(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), layout,
                                                          _stream()), "r2l_pack_backward_layout")
@@ -200,7 +198,7 @@ class R2LTrainer:
             eng.pack_now()
             _lib.check(self.lib.r2l_pack_backward(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), _stream()),
                        "r2l_pack_backward")
-            self._bwd_packed = {16: eng.version(), 32: eng.version(), 3: eng.version()}  # (pack_now did the forward stream)
+            self._bwd_packed = {16: eng.version(), 32: eng.version(), 3: eng.version(), 2: eng.version()}  # (pack_now did the forward stream)
             gs["rgb"] = self.forward_backward(gs["o"], gs["d"], gs["t"], perturb)
             _lib.check(
                 self.lib.r2l_adam_step_dev(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
