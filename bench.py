@@ -174,13 +174,14 @@ def teacher_leg(device, world, rank, distributed, frames=2):
     dt, step_ms = timed(step, frames, 1, distributed, device)
     flop_per_ray = 2 * 593408 * 256  # 303.82 MFLOP/ray
     achieved = H * W * flop_per_ray / (step_ms * 1e-3) / 1e12
-    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # point network on the bf16 matrix pipe (6 products per fp32 one)
-    peak = PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA
+    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # point network on the 16-bit matrix pipe
+    fwd2 = fwd3 and not os.environ.get("R2L_NO_FWD2", "0").strip("0")  # default: 3 fp16 products per fp32 product (else 6 bf16)
+    peak = PEAK_BF16_MFMA / 3. if fwd2 else (PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA)
     return {"value": H * W * frames * world / dt, "unit": "rays/s", "ms_per_frame": dt / frames * 1e3,
             "workload": "NeRF teacher render 400x400, 64+128 samples/ray, perturb=1, chunk 32768 (create_data rand)",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "peak_fp32_mfma": PEAK_FP32_MFMA, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
-                         "kernel": "r2l_teacher3_kernel" if fwd3 else "r2l_teacher_mlp_kernel",
+                         "kernel": "r2l_teacher2_kernel" if fwd2 else ("r2l_teacher3_kernel" if fwd3 else "r2l_teacher_mlp_kernel"),
                          "flop_per_ray": flop_per_ray}}
 
 
@@ -323,19 +324,16 @@ def main():
         # 128 of the 1024 wave slots, reported for completeness
         out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
                                             PEAK_FP32_MFMA, n_rays=4096)
-        # opt-in mode, reported beside the default: gradient GEMMs (dX chain, dW body) with the 3 largest of the 6 bf16
-        # products (operands to 16 mantissa bits; forward unchanged) — not the headline training number
-        if "R2L_GRAD_TERMS" not in os.environ and "R2L_NO_FWD3" not in os.environ:
-            os.environ["R2L_GRAD_TERMS"] = "3"
+        # reference leg: the same step with every GEMM on six bf16 products per fp32 product (fp32-exact products)
+        if rank == 0 and world == 1 and not any(k in os.environ for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2")):
+            for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
+                os.environ[k] = "1"
             try:
-                g3 = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY, PEAK_FP32_MFMA)
+                out["train_bf16x3"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                                      PEAK_FP32_MFMA)
             finally:
-                del os.environ["R2L_GRAD_TERMS"]
-            g3["note"] = ("R2L_GRAD_TERMS=3: products of the gradient GEMMs to ~2^-16 instead of 2^-24; measured gradient "
-                          "difference to the default 2.7e-6 (relative L2, W256D88, 98 304 rays: tools/grad3_err.py)")
-            g3["roofline"]["matrix_path"] = "bf16x3 forward (6 products), dX chain and dW with 3 products"
-            g3["roofline"]["peak_note"] = "peak = dense bf16 MFMA / 6 as for the default path (fewer matrix products per algorithmic FLOP in the backward)"
-            out["train_grad3"] = g3
+                for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
+                    del os.environ[k]
 
     if not a.no_teacher:
         out["teacher"] = teacher_leg(device, world, rank, distributed)

@@ -1,39 +1,30 @@
-// r2l_teacher3.hip — the fused NeRF-teacher point network (run_network + NeRF.forward, see r2l_teacher_mlp.hip) at fp32
-// accuracy on the bf16 matrix pipe: same scheme as r2l_fwd3.hip (bf16 hi/mid/lo triples, six MFMAs per product, LDS-DMA
-// staged weight stream, machinery in r2l_f3.h), one wavefront = 32 consecutive sample points.
-//
-// Stage stream (24 KiB stages: 16 input features x 256 outputs x 3 splits; "bias" = one-MFMA-per-tile bias stage):
-//   L0:   bias, 4 xyz-embedding blocks
-//   4 x : t-layer (L1, L3, L5, L7): bias, [L5: 4 xyz-embedding blocks], 16 blocks of relu(x)
-//         x-layer (L2, L4, L6, feature): bias, 16 blocks of relu(t)
-//   views: bias, 16 blocks of the feature (no ReLU), 2 direction-embedding blocks; its 128 outputs occupy tiles 0-3 of the
-//          stage, tiles 4-7 are zero padding (9 of 164 stages cost twice what they could; kept for one uniform stage routine)
-// alpha (on relu(L7)) and rgb (on relu(views)) stay on the VALU as in the fp32 kernel.
-// Embedding k order per half-wave h: xyz: 15 (sin, cos) pairs (frequency 5h + q/3, axis q%3), then the identity (h = 0: x,
-// y; h = 1: z, pad);  direction: 6 pairs (frequency 2h + q/3), identity (x, y | z, pad), 2 pads.
-#include "r2l_f3.h"
+// r2l_teacher2.hip — the NeRF teacher's point network of r2l_teacher3.hip on the fp16 matrix pipe with two-way operand splits
+// (machinery: r2l_f2.h): three fp16 products per fp32 product, ~2^-21 relative.  Stage order, gatherers and epilogue are
+// r2l_teacher3.hip's; stages are 16 KiB.  A range guard raises a status word behind the stream and the bf16x3 kernel launched
+// behind this one redoes the launch (sticky until the next pack: the teacher's weights do not change).
+#include "r2l_f2.h"
 
-#define T3_W 256
-#define T3_XYZ 63
-#define T3_DIR 27
-#define T3_STAGES 164
+#define T2_W 256
+#define T2_XYZ 63
+#define T2_DIR 27
+#define T2_STAGES 164
 
-struct T3Off {
+struct T2Off {
     int64_t w[8], b[8], views_w, views_b, feat_w, feat_b, alpha_w, alpha_b, rgb_w, rgb_b, total;
 };
-__host__ __device__ static inline T3Off t3_offsets() {  // state_dict order of NeRF(D=8, W=256, 63, 27, use_viewdirs)
-    T3Off o;
+__host__ __device__ static inline T2Off t2_offsets() {  // state_dict order of NeRF(D=8, W=256, 63, 27, use_viewdirs)
+    T2Off o;
     int64_t p = 0;
     for (int i = 0; i < 8; ++i) {
-        const int fin = i == 0 ? T3_XYZ : (i == 5 ? T3_W + T3_XYZ : T3_W);
-        o.w[i] = p; p += (int64_t)T3_W * fin;
-        o.b[i] = p; p += T3_W;
+        const int fin = i == 0 ? T2_XYZ : (i == 5 ? T2_W + T2_XYZ : T2_W);
+        o.w[i] = p; p += (int64_t)T2_W * fin;
+        o.b[i] = p; p += T2_W;
     }
-    o.views_w = p; p += (int64_t)128 * (T3_W + T3_DIR);
+    o.views_w = p; p += (int64_t)128 * (T2_W + T2_DIR);
     o.views_b = p; p += 128;
-    o.feat_w = p; p += (int64_t)T3_W * T3_W;
-    o.feat_b = p; p += T3_W;
-    o.alpha_w = p; p += T3_W;
+    o.feat_w = p; p += (int64_t)T2_W * T2_W;
+    o.feat_b = p; p += T2_W;
+    o.alpha_w = p; p += T2_W;
     o.alpha_b = p; p += 1;
     o.rgb_w = p; p += 3 * 128;
     o.rgb_b = p; p += 3;
@@ -42,7 +33,7 @@ __host__ __device__ static inline T3Off t3_offsets() {  // state_dict order of N
 }
 
 // embedding column of value v of half h (or -1 = zero padding); `nfreq_half` frequencies per half (5 xyz / 2 direction)
-__host__ __device__ static inline int t3_emb_col(int v, int h, int nfreq_half) {
+__host__ __device__ static inline int t2_emb_col(int v, int h, int nfreq_half) {
     const int ntrig = 6 * nfreq_half;
     if (v < ntrig) {
         const int q = v >> 1, fl = q / 3, ax = q % 3;
@@ -56,14 +47,14 @@ __host__ __device__ static inline int t3_emb_col(int v, int h, int nfreq_half) {
 // =================================================================================================================
 // pack
 // =================================================================================================================
-__global__ void r2l_pack_teacher3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out) {
-    const T3Off off = t3_offsets();
-    const int64_t total = (int64_t)(T3_STAGES + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
+__global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out) {
+    const T2Off off = t2_offsets();
+    const int64_t total = (int64_t)(T2_STAGES + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
         const int g = (int)(idx >> 12);
         const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
-        unsigned short* st = out + (int64_t)g * (F3_STAGE_BYTES / 2);
+        unsigned short* st = out + (int64_t)g * (F2_STAGE_BYTES / 2);
         // decode the stage: kind 0 bias (offset boff), 1 xyz block (layer 0 or 5), 2 256->256 block, 3 views feature block,
         // 4 views direction block
         int kind = -1, layer = 0, kb = 0;
@@ -88,7 +79,7 @@ __global__ void r2l_pack_teacher3_kernel(const float* __restrict__ params, unsig
                 if (r == 0) { kind = 0; boff = lx == 8 ? off.feat_b : off.b[lx]; }
                 else { kind = 2; kb = r - 1; }
             }
-        } else if (g < T3_STAGES) {
+        } else if (g < T2_STAGES) {
             const int r = g - 145;
             views = true;
             if (r == 0) { kind = 0; boff = off.views_b; }
@@ -100,52 +91,53 @@ __global__ void r2l_pack_teacher3_kernel(const float* __restrict__ params, unsig
         if (kind == 0) {
             if (!views || tile < 4) { w = params[boff + o]; have = true; }
         } else if (kind == 1) {
-            const int col = t3_emb_col(8 * kb + s, h, 5);
-            if (col >= 0) { w = layer == 5 ? params[off.w[5] + (int64_t)o * (T3_W + T3_XYZ) + col] : params[off.w[0] + (int64_t)o * T3_XYZ + col]; have = true; }
+            const int col = t2_emb_col(8 * kb + s, h, 5);
+            if (col >= 0) { w = layer == 5 ? params[off.w[5] + (int64_t)o * (T2_W + T2_XYZ) + col] : params[off.w[0] + (int64_t)o * T2_XYZ + col]; have = true; }
         } else if (kind == 2) {
             const int T = kb >> 1, r = kb & 1;
             const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
-            if (layer == 8) w = params[off.feat_w + (int64_t)o * T3_W + in];
-            else if (layer == 5) w = params[off.w[5] + (int64_t)o * (T3_W + T3_XYZ) + T3_XYZ + in];
-            else w = params[off.w[layer] + (int64_t)o * T3_W + in];
+            if (layer == 8) w = params[off.feat_w + (int64_t)o * T2_W + in];
+            else if (layer == 5) w = params[off.w[5] + (int64_t)o * (T2_W + T2_XYZ) + T2_XYZ + in];
+            else w = params[off.w[layer] + (int64_t)o * T2_W + in];
             have = true;
         } else if (kind == 3) {
             const int T = kb >> 1, r = kb & 1;
             const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
-            if (tile < 4) { w = params[off.views_w + (int64_t)o * (T3_W + T3_DIR) + in]; have = true; }
+            if (tile < 4) { w = params[off.views_w + (int64_t)o * (T2_W + T2_DIR) + in]; have = true; }
         } else if (kind == 4) {
-            const int col = t3_emb_col(8 * kb + s, h, 2);
-            if (tile < 4 && col >= 0) { w = params[off.views_w + (int64_t)o * (T3_W + T3_DIR) + T3_W + col]; have = true; }
+            const int col = t2_emb_col(8 * kb + s, h, 2);
+            if (tile < 4 && col >= 0) { w = params[off.views_w + (int64_t)o * (T2_W + T2_DIR) + T2_W + col]; have = true; }
         }
-        unsigned short v0 = 0, v1 = 0, v2 = 0;
+        unsigned short v0 = 0, v1 = 0;
         if (have) {
-            const unsigned short hi = f3_bf16_rne(w);
-            const float r1 = w - f3_bf16_to_f(hi);
-            const unsigned short mid = f3_bf16_rne(r1);
-            const unsigned short lo = f3_bf16_rne(r1 - f3_bf16_to_f(mid));
+            const _Float16 hi = (_Float16)w;
+            const _Float16 mid = (_Float16)(w - (float)hi);
+            const unsigned short hb = __builtin_bit_cast(unsigned short, hi), mb = __builtin_bit_cast(unsigned short, mid);
             if (kind == 0) {
-                v0 = (h == 0) ? (s == 0 ? hi : (s == 1 ? mid : (s == 2 ? lo : (unsigned short)0))) : (unsigned short)0;
+                v0 = (h == 0) ? (s == 0 ? hb : (s == 1 ? mb : (unsigned short)0)) : (unsigned short)0;
             } else {
-                v0 = hi; v1 = mid; v2 = lo;
+                v0 = hb; v1 = mb;
             }
         }
         const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
         st[e] = v0;
         st[8 * 64 * 8 + e] = v1;
-        st[2 * 8 * 64 * 8 + e] = v2;
     }
+}
+__global__ void r2l_teacher2_status_clear_kernel(unsigned* status) {
+    if (threadIdx.x < 16) status[threadIdx.x] = 0u;
 }
 
 // =================================================================================================================
 // kernel
 // =================================================================================================================
-struct T3Args {
+struct T2Args {
     const float* rays_o;
     const float* rays_d;
     const float* viewdirs;
     const float* z;
     const unsigned char* stream;
-    const unsigned* run_if;  // nullptr, or: return at once while this word is 0 (range-guard fallback of r2l_teacher2.hip)
+    unsigned* status;  // range-guard word behind the stream: != 0 -> this launch is left to the bf16x3 kernel
     const float* params;
     float* raw;
     int64_t n_pts;
@@ -154,7 +146,7 @@ struct T3Args {
 
 // four embedding values v0 .. v0+3 of this half-wave: (sin, cos) pairs of c[axis] * 2^(nf*h + fl), then the identity
 template <int NF>
-struct T3Emb4 {
+struct T2Emb4 {
     const float (&c)[3];
     int h;
     int v0;
@@ -178,7 +170,7 @@ struct T3Emb4 {
 };
 // either of two gatherers, chosen at run time (the stage in front of a conditionally inserted group of stages)
 template <class GA, class GB>
-struct T3Select {
+struct T2Select {
     bool first;
     GA ga;
     GB gb;
@@ -191,10 +183,10 @@ struct T3Select {
     }
 };
 
-__global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char wbuf[F3_NBUF][F3_STAGE_BYTES];
-    if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
-    const T3Off off = t3_offsets();
+__global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
+    if (__builtin_nontemporal_load(a.status) != 0u) return;
+    const T2Off off = t2_offsets();
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -214,47 +206,47 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
     }
     const float* P0 = a.params;
 
-    F3Pipe P;
+    F2Pipe P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
         P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         P.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&wbuf[0][0];
         P.voff = (unsigned)lane * 16u;
-        P.wq = (unsigned)wave * 6144u;
+        P.wq = (unsigned)wave * 4096u;
         P.base = &wbuf[0][0];
         P.lane = lane;
         P.gb = 0;
         P.gq = 0;
         P.gqb = 0;
+        P.amax = 0.f;
     }
     P.issue(); P.issue(); P.issue(); P.issue(); P.issue();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) P.ones.h[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
+    for (int k = 0; k < 8; ++k) P.ones.h[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
     P.ones.m = P.ones.h;
-    P.ones.l = P.ones.h;
 
     f32x16 x[R2L_NT], t[R2L_NT];
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();
     P.lb = P.base + lane * 16;
     {
         F3None none;
-        F3Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}};
+        F2Side<true, F3None> s0{P.a1, P.lb, 0, none, false, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax};
 #pragma unroll
         for (int i = 0; i < 6; ++i) s0.step(i);
     }
     P.sb = P.ones;
 
-    typedef T3Emb4<5> Xyz4;
-    typedef T3Emb4<2> Dir4;
+    typedef T2Emb4<5> Xyz4;
+    typedef T2Emb4<2> Dir4;
     typedef F3Take4<true> Relu4;
     // ---- layer 0: x = W0 pe + b0 (pre-activation; every consumer applies the ReLU to its B values) ---------------------
-    f3_stage<true, true, false>(x, P, Xyz4{p, h, 0}, Xyz4{p, h, 4});
-    f3_stage<false, false, false>(x, P, Xyz4{p, h, 8}, Xyz4{p, h, 12});
-    f3_stage<false, false, false>(x, P, Xyz4{p, h, 16}, Xyz4{p, h, 20});
-    f3_stage<false, false, false>(x, P, Xyz4{p, h, 24}, Xyz4{p, h, 28});
-    f3_stage<false, false, true>(x, P, F3None{}, F3None{});
+    f2_stage<true, true, false>(x, P, Xyz4{p, h, 0}, Xyz4{p, h, 4});
+    f2_stage<false, false, false>(x, P, Xyz4{p, h, 8}, Xyz4{p, h, 12});
+    f2_stage<false, false, false>(x, P, Xyz4{p, h, 16}, Xyz4{p, h, 20});
+    f2_stage<false, false, false>(x, P, Xyz4{p, h, 24}, Xyz4{p, h, 28});
+    f2_stage<false, false, true>(x, P, F3None{}, F3None{});
 
     // ---- (L1,L2) (L3,L4) (L5,L6) (L7,feature): t = W_odd relu(x) [+ W5pe pe] + b ; x = W_even relu(t) + b -----------------
     float alpha = 0.f;
@@ -265,20 +257,20 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
             float pp[3] = {p[0], p[1], p[2]};
             int hh = h;
             asm volatile("" : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(hh));
-            f3_stage<true, true, false>(t, P, T3Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 0}, Relu4{x[0], 0, nullptr, 0}},
-                                        T3Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 4}, Relu4{x[0], 4, nullptr, 0}});
+            f2_stage<true, true, false>(t, P, T2Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 0}, Relu4{x[0], 0, nullptr, 0}},
+                                        T2Select<Xyz4, Relu4>{k == 2, Xyz4{pp, hh, 4}, Relu4{x[0], 4, nullptr, 0}});
             if (k == 2) {
-                f3_stage<false, false, false>(t, P, Xyz4{pp, hh, 8}, Xyz4{pp, hh, 12});
-                f3_stage<false, false, false>(t, P, Xyz4{pp, hh, 16}, Xyz4{pp, hh, 20});
-                f3_stage<false, false, false>(t, P, Xyz4{pp, hh, 24}, Xyz4{pp, hh, 28});
-                f3_stage<false, false, false>(t, P, Relu4{x[0], 0, nullptr, 0}, Relu4{x[0], 4, nullptr, 0});
+                f2_stage<false, false, false>(t, P, Xyz4{pp, hh, 8}, Xyz4{pp, hh, 12});
+                f2_stage<false, false, false>(t, P, Xyz4{pp, hh, 16}, Xyz4{pp, hh, 20});
+                f2_stage<false, false, false>(t, P, Xyz4{pp, hh, 24}, Xyz4{pp, hh, 28});
+                f2_stage<false, false, false>(t, P, Relu4{x[0], 0, nullptr, 0}, Relu4{x[0], 4, nullptr, 0});
             }
         }
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(t, P, Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+            f2_stage<false, false, false>(t, P, Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
                                           Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
-        f3_stage<false, false, true>(t, P, F3None{}, F3None{});
+        f2_stage<false, false, true>(t, P, F3None{}, F3None{});
         if (k == 3) {  // alpha_linear on relu(layer 7)
             float acc = 0.f;
 #pragma unroll
@@ -292,24 +284,24 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
             acc += __shfl_xor(acc, 32);
             alpha = acc + P0[off.alpha_b];
         }
-        f3_stage<true, true, false>(x, P, Relu4{t[0], 0, nullptr, 0}, Relu4{t[0], 4, nullptr, 0});
+        f2_stage<true, true, false>(x, P, Relu4{t[0], 0, nullptr, 0}, Relu4{t[0], 4, nullptr, 0});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+            f2_stage<false, false, false>(x, P, Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
                                           Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
-        f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next pair's (or the views layer's) bias stage
+        f2_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next pair's (or the views layer's) bias stage
     }
 
     // ---- views layer: v[128] = Wv [feature, dir-embedding] + bv in tiles 0-3 of t (ReLU applied by the rgb head) ---------
     typedef F3Take4<false> Id4;
-    f3_stage<true, true, false>(t, P, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 4, nullptr, 0});
+    f2_stage<true, true, false>(t, P, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 4, nullptr, 0});
 #pragma unroll
     for (int kb = 0; kb < 15; ++kb)
-        f3_stage<false, false, false>(t, P, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+        f2_stage<false, false, false>(t, P, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
                                       Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
-    f3_stage<false, false, false>(t, P, Dir4{vd, h, 0}, Dir4{vd, h, 4});
-    f3_stage<false, false, false>(t, P, Dir4{vd, h, 8}, Dir4{vd, h, 12});
-    f3_stage<false, false, true>(t, P, F3None{}, F3None{});  // next: stream padding
+    f2_stage<false, false, false>(t, P, Dir4{vd, h, 0}, Dir4{vd, h, 4});
+    f2_stage<false, false, false>(t, P, Dir4{vd, h, 8}, Dir4{vd, h, 12});
+    f2_stage<false, false, true>(t, P, F3None{}, F3None{});  // next: stream padding
 
     // rgb = Wrgb relu(v) + b
     float acc3[3] = {0.f, 0.f, 0.f};
@@ -329,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
         }
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc3[c] = acc3[c] + __shfl_xor(acc3[c], 32) + P0[off.rgb_b + c];
+    if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
     if (valid && h == 0) {
         const f32x4 o4 = {acc3[0], acc3[1], acc3[2], alpha};
         *reinterpret_cast<f32x4*>(a.raw + pt * 4) = o4;
@@ -338,24 +331,29 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher3_kernel(const T3Args a) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side (called from r2l_teacher_mlp.hip's C ABI entry points)
 // ------------------------------------------------------------------------------------------------------------------
-int64_t r2l_teacher3_stream_floats(void) { return (int64_t)(T3_STAGES + R2L_F3_PAD_STAGES) * (F3_STAGE_BYTES / 4); }
+static inline int64_t t2_status_offset() { return (int64_t)(T2_STAGES + R2L_F3_PAD_STAGES) * (F2_STAGE_BYTES / 4); }
+int64_t r2l_teacher2_stream_floats(void) { return t2_status_offset() + 16; }
+const unsigned* r2l_teacher2_status(const float* wstream2) { return reinterpret_cast<const unsigned*>(wstream2 + t2_status_offset()); }
 
-int r2l_teacher3_pack(const float* tparams, float* wstream3, hipStream_t stream) {
-    hipLaunchKernelGGL(r2l_pack_teacher3_kernel, dim3(512), dim3(256), 0, stream, tparams,
-                       reinterpret_cast<unsigned short*>(wstream3));
+int r2l_teacher2_pack(const float* tparams, float* wstream2, hipStream_t stream) {
+    hipLaunchKernelGGL(r2l_pack_teacher2_kernel, dim3(512), dim3(256), 0, stream, tparams,
+                       reinterpret_cast<unsigned short*>(wstream2));
+    R2L_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(r2l_teacher2_status_clear_kernel, dim3(1), dim3(64), 0, stream,
+                       reinterpret_cast<unsigned*>(wstream2 + t2_status_offset()));
     R2L_CHECK(hipGetLastError());
     return 0;
 }
 
-int r2l_teacher3_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
-                     const float* wstream3, const float* tparams, float* raw, int64_t n_pts, int S, hipStream_t stream,
-                     const unsigned* run_if) {
-    T3Args a{};
-    a.run_if = run_if;
+int r2l_teacher2_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
+                     const float* wstream2, const float* tparams, float* raw, int64_t n_pts, int S, hipStream_t stream) {
+    T2Args a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.z = z;
-    a.stream = reinterpret_cast<const unsigned char*>(wstream3); a.params = tparams; a.raw = raw; a.n_pts = n_pts; a.S = S;
+    a.stream = reinterpret_cast<const unsigned char*>(wstream2); a.params = tparams; a.raw = raw; a.n_pts = n_pts; a.S = S;
+    // the status word lives in the caller's stream buffer (library-private contents): written through, hence the cast
+    a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + t2_status_offset());
     const int64_t tiles = (n_pts + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    hipLaunchKernelGGL(r2l_teacher3_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(r2l_teacher2_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -322,15 +322,26 @@ extern "C" int64_t r2l_teacher_param_count(void) { return t_offsets().total; }
 int64_t r2l_teacher3_stream_floats(void);
 int r2l_teacher3_pack(const float* tparams, float* wstream3, hipStream_t stream);
 int r2l_teacher3_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
-                     const float* wstream3, const float* tparams, float* raw, int64_t n_pts, int S, hipStream_t stream);
+                     const float* wstream3, const float* tparams, float* raw, int64_t n_pts, int S, hipStream_t stream,
+                     const unsigned* run_if);
+// r2l_teacher2.hip: three fp16 products per fp32 product (default), range-guarded; its stream follows the bf16x3 one
+int64_t r2l_teacher2_stream_floats(void);
+const unsigned* r2l_teacher2_status(const float* wstream2);
+int r2l_teacher2_pack(const float* tparams, float* wstream2, hipStream_t stream);
+int r2l_teacher2_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
+                     const float* wstream2, const float* tparams, float* raw, int64_t n_pts, int S, hipStream_t stream);
 static inline int64_t t_stream32_floats() { return (int64_t)TG_TOTAL * R2L_GROUP_FLOATS + R2L_STREAM_PAD; }
 
-extern "C" int64_t r2l_teacher_stream_floats(void) { return t_stream32_floats() + r2l_teacher3_stream_floats(); }
+extern "C" int64_t r2l_teacher_stream_floats(void) {
+    return t_stream32_floats() + r2l_teacher3_stream_floats() + r2l_teacher2_stream_floats();
+}
 
 extern "C" int r2l_pack_teacher(const float* params, float* wstream, void* stream) {
     hipLaunchKernelGGL(r2l_pack_teacher_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, params, wstream);
     R2L_CHECK(hipGetLastError());
-    return r2l_teacher3_pack(params, wstream + t_stream32_floats(), (hipStream_t)stream);
+    const int rc = r2l_teacher3_pack(params, wstream + t_stream32_floats(), (hipStream_t)stream);
+    if (rc) return rc;
+    return r2l_teacher2_pack(params, wstream + t_stream32_floats() + r2l_teacher3_stream_floats(), (hipStream_t)stream);
 }
 
 extern "C" int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
@@ -339,9 +350,17 @@ extern "C" int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const f
     a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.z = z; a.wstream = wstream; a.params = params;
     a.raw = raw; a.n_pts = R * (int64_t)S; a.S = S;
     if (a.n_pts <= 0) return 0;
-    if (r2l_use_fwd3())  // default: fp32-accurate products on the bf16 matrix pipe (R2L_NO_FWD3=1: fp32 MFMA)
+    if (r2l_use_fwd2()) {  // default: 3 fp16 products per fp32 product, the bf16x3 kernel behind it as range-guard fallback
+        const float* w3 = wstream + t_stream32_floats();
+        const float* w2 = w3 + r2l_teacher3_stream_floats();
+        const int rc = r2l_teacher2_mlp(rays_o, rays_d, viewdirs, z, w2, params, raw, a.n_pts, S, (hipStream_t)stream);
+        if (rc) return rc;
+        return r2l_teacher3_mlp(rays_o, rays_d, viewdirs, z, w3, params, raw, a.n_pts, S, (hipStream_t)stream,
+                                r2l_teacher2_status(w2));
+    }
+    if (r2l_use_fwd3())  // R2L_NO_FWD2=1: fp32-exact products on the bf16 matrix pipe (R2L_NO_FWD3=1: fp32 MFMA)
         return r2l_teacher3_mlp(rays_o, rays_d, viewdirs, z, wstream + t_stream32_floats(), params, raw, a.n_pts, S,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, nullptr);
     const int64_t tiles = (a.n_pts + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     hipLaunchKernelGGL(r2l_teacher_mlp_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     R2L_CHECK(hipGetLastError());

@@ -290,9 +290,22 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
     # small-batch chains stay on the fp32 MFMA (only their dW GEMMs use the bf16 path)
     fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")
     big = tr.lib.r2l_variant_for(int(n)) == 0
+    f16 = [not os.environ.get(k, "0").strip("0") for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2")]
+    terms3 = os.environ.get("R2L_GRAD_TERMS", "6").startswith("3")
     peak_fp32 = peak
+    path = "fp32 MFMA"
     if fwd3 and big:
-        peak = 2500.0 / 6.
+        if all(f16) and not terms3:
+            # every GEMM of the step as 3 fp16 MFMA products per fp32 product (two-way fp16 operand splits, ~2^-21)
+            peak = 2500.0 / 3.
+            path = "fp16x2: forward, dX chain and dW body with 3 fp16 products per fp32 product (range-guarded, bf16x3 fallback)"
+        else:
+            peak = 2500.0 / 6.
+            path = ("bf16x3 (6 bf16 products per fp32 product) for: %s; fp16x2 (3 products) for the rest"
+                    % ", ".join(nm for nm, on in zip(("forward", "dX chain", "dW body"), f16) if not on or terms3)) \
+                if any(f16) else "bf16x3: forward, dX chain and dW body with 6 bf16 products per fp32 product"
+    elif fwd3:
+        path = "fp32 MFMA chains + bf16x3 dW"
     return {"value": n * steps * world / dt, "unit": "rays/s", "steps": steps, "warmup": warm,
             "ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": n,
             "workload": "distillation step (fwd + bwd + Adam + weight re-pack), %d rays/GPU/step, perturb=1; "
@@ -300,7 +313,6 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "peak_fp32_mfma": peak_fp32,
                          "frac_of_fp32_mfma_peak": achieved / peak_fp32,
-                         "matrix_path": ("bf16x3 (fwd, dX chain, dW)" if (fwd3 and big) else
-                                         ("fp32 MFMA chains + bf16x3 dW" if fwd3 else "fp32 MFMA")),
+                         "matrix_path": path,
                          "flop_per_ray": flop_per_ray, "step_ms_device": step_ms},
             "final_loss": tr.loss_out[0].item()}

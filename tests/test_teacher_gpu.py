@@ -11,14 +11,19 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "f32mfma"])
+@pytest.fixture(autouse=True, params=["fp16x2", "bf16x3", "f32mfma"])
 def mlp_path(request, monkeypatch):
-    """Every test runs on both point-network kernels: r2l_teacher3.hip (fp32-accurate products on the bf16 matrix pipe,
-    the default) and r2l_teacher_mlp.hip (exact-fp32 MFMA, R2L_NO_FWD3=1)."""
+    """Every test runs on the three point-network kernels: r2l_teacher2.hip (3 fp16 products per fp32 product, the
+    default), r2l_teacher3.hip (6 bf16 products: fp32-exact products, R2L_NO_FWD2=1) and r2l_teacher_mlp.hip (exact-fp32
+    MFMA, R2L_NO_FWD3=1)."""
     if request.param == "f32mfma":
         monkeypatch.setenv("R2L_NO_FWD3", "1")
     else:
         monkeypatch.delenv("R2L_NO_FWD3", raising=False)
+    if request.param == "bf16x3":
+        monkeypatch.setenv("R2L_NO_FWD2", "1")
+    else:
+        monkeypatch.delenv("R2L_NO_FWD2", raising=False)
     return request.param
 T = torch.from_numpy
 
