@@ -2,7 +2,7 @@
 # effective shader clock per kernel: GRBM_GUI_ACTIVE / kernel wall time of the same (profiled) pass
 export TMPDIR=/tmp
 REPO=$(pwd); OUT=$REPO/gpurun_out/clk; rm -rf $OUT; mkdir -p $OUT; cd /tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/a -o a --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-teacher > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/a -o a --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 cd $REPO
 python - <<'PY'
 import csv, glob, collections
@@ -14,9 +14,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/clk/a/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         d = dur.get(r['Dispatch_Id'])
-        if d: agg[d[0]][r['Counter_Name']].append((float(r['Counter_Value']), d[1]))
+        if d and d[1] > 100000: agg[d[0]][r['Counter_Name']].append((float(r['Counter_Value']), d[1]))  # (idle guard launches: few us)
 for n, d in agg.items():
-    if not any(k in n for k in ('fwd3', 'bwd3', 'dw_body', 'fwd_kernel', 'c16')): continue
+    if not any(k in n for k in ('fwd2', 'bwd2', 'fwd3', 'bwd3', 'dw_body', 'fwd_kernel', 'c16', 'teacher')): continue
     g = d.get('GRBM_GUI_ACTIVE', [])
     if not g: continue
     # GRBM_GUI_ACTIVE is summed over the XCDs (8): cycles per XCD = value / 8

@@ -36,6 +36,9 @@ def main(n_files=240, it_a=130, it_b=330):
               "--N_rand", "20", "--hard_ratio", "0.2", "--hard_mul", "20", "--warmup_lr", "0.0001,200",
               "--i_print", "100", "--i_testset", "100000", "--i_weights", "100000", "--num_workers", "8"]
     out = {}
+    # (an untimed first run: one-off costs of the process — library load, first-touch of the big buffers — would otherwise
+    # sit in the first timed run only and not cancel in the subtraction)
+    driver.main(common + ["--N_iters", "30", "--experiment_name", "e2e_w"])
     for tag, iters in (("a", it_a), ("b", it_b)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -12,7 +12,7 @@ for f in sorted(glob.glob('gpurun_out/pmct/*/*counter_collection.csv')):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name'].split('(')[0].replace('void ', '')
-        if n.startswith('r2l_') and ('fwd' in n or 'bwd' in n or 'dw_body' in n):
+        if n.startswith('r2l_') and ('fwd' in n or 'bwd' in n or 'dw_body' in n) and 'pack' not in n:
             agg[n][r['Counter_Name']].append(float(r['Counter_Value']))
     for n, d in agg.items():
         for c, v in d.items():
