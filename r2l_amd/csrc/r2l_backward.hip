@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
 #pragma unroll
     for (int k = 0; k < 4; ++k) bacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t Np = R2L_PAD_ROWS(a.N);
-    const int64_t slot = Np * R2L_W;
+    const int64_t slot = R2L_TRIO_SLOT(Np);
     const unsigned img_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&img[0][0];
 
     // loader lane: chunk parity cc inside the instruction's chunk pair, ray j of the half tile, half chunk hf
@@ -1211,7 +1211,7 @@ extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 // (+ 16 floats of status words behind the partials)
 extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS + 16; }
-extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_PAD_ROWS(N) * (int64_t)R2L_W; }
+extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_TRIO_SLOT(R2L_PAD_ROWS(N)); }
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
@@ -1359,7 +1359,8 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
                           ? dw_slab + DW_HEAD_SLAB_MAX : nullptr;
         // (chunked stash: slot n of save_x holds y = x_n + x_0)
         hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, split ? nullptr : save_x,
-                           save_x + (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W, grads, part, n_block, N, per);
+                           save_x + (int64_t)n_block * (split ? R2L_TRIO_SLOT(R2L_PAD_ROWS(N)) : R2L_PAD_ROWS(N) * (int64_t)R2L_W),
+                           grads, part, n_block, N, per);
         R2L_CHECK(hipGetLastError());
         if (part != nullptr) {
             hipLaunchKernelGGL(r2l_tail_reduce_kernel, dim3(R2L_W / 32, 4), dim3(256), 0, stream, part, wgs, grads, n_block);

@@ -5,15 +5,15 @@
 //     all-zero "bias" stages cost 8 MFMAs each and buy what the bias stages give the forward: u is zero-initialised by the
 //     matrix pipe, and the B values of a GEMM's first k-block are gathered AFTER the previous GEMM has finished;
 //   * the B values of every stage are exactly what has to be stashed (g, masked u): the stores ride along the gathers;
-//   * the ReLU mask of the block is read from the forward stash save_t[b] without any register load: one 1 KiB tile piece
-//     per half stage is DMA'd into a per-wave LDS ring during the first GEMM, folded into 128 mask bits per lane eight half
-//     stages later (by then the staging pipeline's own `vmcnt` waits have guaranteed its arrival), and applied when u is
-//     gathered as the B operand of the second GEMM;
+//   * the ReLU mask of the block comes as 128 bits per lane that the forward chain wrote beside its stash (one 1 KiB piece
+//     per tile and block): DMA'd into a two-slot per-wave LDS ring at the start of the block, read when the second GEMM
+//     starts (by then the staging pipeline's own `vmcnt` waits have guaranteed its arrival) and applied when u is gathered as
+//     the B operand of the second GEMM;
 //   * dy (the outer-residual branch) waits in scratch for the head.
 #include "r2l_f3.h"
 
-#define B3_NBUF 5
-#define B3_RING 8  // mask pieces in flight per wave
+#define B3_NBUF 6
+#define B3_RING 2  // mask pieces (one per block) per wave
 
 __host__ __device__ static inline int64_t b3_off_body_w(int layer) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
@@ -75,39 +75,25 @@ struct B3Args {
     int64_t N;
 };
 
-// mask piece pi = 4T + q of the block (fragment registers 4q .. 4q+3 of tile T) -> bits (T&1)*16 + 4q .. +3 of word T>>1
-__device__ __forceinline__ void b3_fold(unsigned (&mb)[4], const unsigned char* ring_lane, int pi) {
-    const f32x4 p = *reinterpret_cast<const f32x4*>(ring_lane + (pi % B3_RING) * 1024);
-    const unsigned bits = (p[0] > 0.f ? 1u : 0u) | (p[1] > 0.f ? 2u : 0u) | (p[2] > 0.f ? 4u : 0u) | (p[3] > 0.f ? 8u : 0u);
-    const int T = pi >> 2, q = pi & 3;
-    mb[T >> 1] |= bits << ((T & 1) * 16 + 4 * q);
-}
-// gatherers: four B values of the next stage (+ their stash store, + the mask piece that is due in this half stage)
+// gatherers: four B values of the next stage (+ their stash store)
 struct B3TakeG {  // g values (identity), stored to gx[b+1]
     const f32x16& frag;
     int c0;
     float* stash;  // lane base (r2l_chunk_lane) in the gx slot: chunked layout
     int T;
-    unsigned (&mb)[4];
-    const unsigned char* ring_lane;
-    int fold_pi;  // mask piece to fold here, or -1
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
-        if (fold_pi >= 0) b3_fold(mb, ring_lane, fold_pi);
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = frag[c0 + s];
         r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
     }
 };
-struct B3TakeU {  // u values masked by relu'(t_b), stored to gt[b]
+struct B3TakeU {  // u values masked by relu'(t_b) (mask words of the forward: bit (T&1)*16 + c of word T>>1), stored to gt[b]
     const f32x16& frag;
     int c0;
     float* stash;
     int T;
-    unsigned (&mb)[4];
-    const unsigned char* ring_lane;
-    int fold_pi;
+    const u32x4& mb;
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
-        if (fold_pi >= 0) b3_fold(mb, ring_lane, fold_pi);
         const unsigned w = mb[T >> 1] >> ((T & 1) * 16 + c0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = ((w >> s) & 1u) ? frag[c0 + s] : 0.f;
@@ -181,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
             }
     }
 
-    // ---- weight staging (5 buffers: 32 KiB of LDS go to the mask ring) --------------------------------------------------------
+    // ---- weight staging (6 buffers beside the 8 KiB mask ring) ----------------------------------------------------------------
     typedef F3PipeT<B3_NBUF, TERMS> Pipe;
     Pipe P;
     {
@@ -197,12 +183,12 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
         P.gq = 0;
         P.gqb = 0;
     }
-    P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..3
+    P.issue(); P.issue(); P.issue(); P.issue(); P.issue();  // stages 0..4
 #pragma unroll
     for (int k = 0; k < 8; ++k) P.ones.h[k] = (__bf16)((h == 0 && k < 3) ? 1.0f : 0.0f);
     P.ones.m = P.ones.h;
     P.ones.l = P.ones.h;
-    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     __syncthreads();
     P.lb = P.base + lane * 16;
     {
@@ -213,18 +199,17 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     }
     P.sb = P.ones;
 
-    // mask ring of this wave: LDS address for the DMA, generic pointer (+16*lane) for the reads
+    // mask words of this wave's tile: one 1 KiB piece per block (64 lanes x 16 B), fetched by DMA into a two-slot LDS ring at
+    // the start of the block and read when its second GEMM starts, 17 stages later
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&mring[0][0][0] +
                               (unsigned)wave * (B3_RING * 1024u);
     const unsigned char* ring_lane = &mring[0][0][0] + wave * (B3_RING * 1024) + lane * 16;
-    // byte offset of this lane's base in a (chunked) slot; mask piece pi lies 1 KiB * pi behind it
-    const int64_t lane_off = r2l_chunk_lane(tile, lane & 31, h);
-    const unsigned mvoff = (unsigned)(lane_off * 4);
-    const int64_t slot = Np * R2L_W;
+    const int64_t lane_off = r2l_chunk_lane(tile, lane & 31, h);  // this lane's base in a (chunked) slot
+    const int64_t slot = R2L_TRIO_SLOT(Np);
+    const unsigned mvoff = (unsigned)((R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) * 4);  // byte offset of the lane's mask words
 
 #pragma unroll 1
     for (int b = a.n_block - 1; b >= 0; --b) {
-        unsigned mb[4] = {0u, 0u, 0u, 0u};
         // descriptor of save_t[b] (per block: 32-bit offsets inside the slot)
         const unsigned long long ta = (unsigned long long)(a.save_t + (int64_t)b * slot);
         const u32x4 trs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta),
@@ -232,37 +217,24 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
                            0x00020000u};
         float* gxs = a.gx + (int64_t)(b + 1) * slot + lane_off;
         float* gts = a.gt + (int64_t)b * slot + lane_off;
-        // half stage rho of the block (0..67): DMA of mask piece issue_pi(rho), fold of piece fold_pi(rho)
-        //   issue: piece pi at rho = pi (pi < 24) or pi + 2 (the half stages 24, 25 are skipped: see fold);
-        //   fold:  eight half stages after the issue -> rho = pi + 8 (pi < 24), pi + 10 (pi >= 24): never in the half stages
-        //          32, 33 (stage 16 gathers nothing: its successor is a zero stage);  first use of piece pi: rho = 34 + pi
-#define B3_ISSUE(RHO) ((RHO) < 24 ? (RHO) : (((RHO) >= 26 && (RHO) < 34) ? (RHO) - 2 : -1))
-#define B3_FOLD(RHO) (((RHO) >= 8 && (RHO) < 32) ? (RHO) - 8 : (((RHO) >= 34 && (RHO) < 42) ? (RHO) - 10 : -1))
-#define B3_EXTRA(RHO)                                                                                                   \
-    F3Dma{B3_ISSUE(RHO) >= 0, trs, mvoff, (unsigned)(B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) * (R2L_CHUNK_PIECE * 4u),  \
-          ring_lds + (unsigned)((B3_ISSUE(RHO) >= 0 ? B3_ISSUE(RHO) : 0) % B3_RING) * 1024u}
+        const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+        const F3Dma mask_dma{true, trs, mvoff, 0u, ring_lds + (unsigned)(b & 1) * 1024u};
         // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
-        f3_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0, mb, ring_lane, B3_FOLD(0)},
-                                    B3TakeG{g[0], 4, gxs, 0, mb, ring_lane, B3_FOLD(1)}, B3_EXTRA(0), B3_EXTRA(1));
+        f3_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0}, B3TakeG{g[0], 4, gxs, 0}, mask_dma, no_dma);
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(
-                u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 2)},
-                B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gxs, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(2 * kb + 3)},
-                B3_EXTRA(2 * kb + 2), B3_EXTRA(2 * kb + 3));
-        f3_stage<false, false, true>(u, P, F3None{}, F3None{}, B3_EXTRA(32), B3_EXTRA(33));
+            f3_stage<false, false, false>(u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gxs, (kb + 1) >> 1},
+                                          B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gxs, (kb + 1) >> 1});
+        // (the mask piece was requested 16 stages ago: every stage wait since has retired all but the newest loads)
+        const u32x4 mb = *reinterpret_cast<const u32x4*>(ring_lane + (b & 1) * 1024);
+        f3_stage<false, false, true>(u, P, F3None{}, F3None{});
         // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
-        f3_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb, ring_lane, B3_FOLD(34)},
-                                     B3TakeU{u[0], 4, gts, 0, mb, ring_lane, B3_FOLD(35)});
+        f3_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb}, B3TakeU{u[0], 4, gts, 0, mb});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(
-                g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(36 + 2 * kb)},
-                B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gts, (kb + 1) >> 1, mb, ring_lane, B3_FOLD(37 + 2 * kb)});
+            f3_stage<false, false, false>(g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gts, (kb + 1) >> 1, mb},
+                                          B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gts, (kb + 1) >> 1, mb});
         f3_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
-#undef B3_EXTRA
-#undef B3_FOLD
-#undef B3_ISSUE
     }
 
     // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] ---------------------------------------------------------

@@ -184,6 +184,11 @@ __device__ __forceinline__ void r2l_stash_store_nt(float* p, const f32x4& v) {
 // tile of a chunk (16 rays x 32 B) as one 512-byte run.
 #define R2L_CHUNK_PIECE 256   // floats per (tile, chunk) piece
 #define R2L_CHUNK_TILE 8192   // floats per tile
+// A slot of the trio's buffers is Np*256 floats of chunked data followed by Np*8 floats of ReLU mask words (save_t slots:
+// per tile 64 lanes x 4 words; bit (T&1)*16 + c of word T>>1 of lane (j, h) = [t > 0] for the lane's fragment register (T, c),
+// written by the forward chain, read back by the dX chain with ONE 1 KiB LDS-DMA piece per block)
+#define R2L_TRIO_SLOT(Np) ((int64_t)(Np) * (R2L_W + 8))
+#define R2L_MASK_OFFSET(Np) ((int64_t)(Np) * R2L_W)
 __device__ __forceinline__ int64_t r2l_chunk_lane(int64_t tile, int j, int h) {
     return tile * R2L_CHUNK_TILE + j * 8 + 4 * h;
 }

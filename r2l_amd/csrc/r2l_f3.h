@@ -244,6 +244,7 @@ struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile 
     int c0;
     float* stash;  // training: this lane's base in the chunked stash slot of the layer input (r2l_chunk_lane), or nullptr
     int T;         // piece (T, c0/4)
+    unsigned* mword = nullptr;  // training, RELU: the block's mask word T>>1 of this lane (bits shifted in MSB-first)
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = RELU ? fmaxf(frag[c0 + s], 0.f) : frag[c0 + s];
@@ -251,6 +252,12 @@ struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile 
         // (unconditional when STASH: a data-dependent branch per piece would cut the half stage's schedule in two)
         // chunked layout: the 64 lanes of a piece write one contiguous KiB (whole 128-byte lines, written once: non-temporal)
         if (STASH) r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
+        if (STASH && RELU) {  // relu'(t) for the backward: word = 2*word + [t > 0]  (v_cmp + v_addc per value)
+            unsigned w = *mword;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w = w + w + (frag[c0 + s] > 0.f ? 1u : 0u);
+            *mword = w;
+        }
     }
 };
 struct F3None {

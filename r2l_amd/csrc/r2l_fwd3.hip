@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     // chunked stash layout (r2l_common.h): lane base of the tile, pieces 1 KiB apart
     float* sx = SAVE ? a.save_x + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
     float* st = SAVE ? a.save_t + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
-    const int64_t slot = Np * R2L_W;
+    const int64_t slot = R2L_TRIO_SLOT(Np);
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
@@ -266,13 +266,20 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
             f3_stage<false, false, false>(t, P, F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
                                           F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
         f3_stage<false, false, true>(t, P, F3None{}, F3None{});
-        // x += W2 relu(t) + b2
-        f3_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0}, F3Take4<true, SAVE>{t[0], 4, st, 0});
+        // x += W2 relu(t) + b2   (training: the gatherers also shift [t > 0] into the block's four mask words)
+        unsigned mw[4] = {0u, 0u, 0u, 0u};
+        f3_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0, &mw[0]}, F3Take4<true, SAVE>{t[0], 4, st, 0, &mw[0]});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f3_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1},
-                                          F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1});
+            f3_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
+                                          F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1, &mw[(kb + 1) >> 2]});
         f3_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
+        if (SAVE) {  // values were shifted in MSB-first: bit (T&1)*16 + c after the reversal
+            u32x4 mv;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) mv[w] = __builtin_bitreverse32(mw[w]);
+            *reinterpret_cast<u32x4*>(a.save_t + (int64_t)b * slot + R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) = mv;
+        }
         if (SAVE) {
             sx += slot;
             st += slot;
