@@ -434,7 +434,10 @@ static inline int r2l_chain_variant(int64_t N) {
     const char* e = getenv("R2L_FORCE_VARIANT");  // read per call (~100 ns) so tests can flip it
     if (e && e[0] == 'm') return R2L_VARIANT_MAIN;
     if (e && e[0] == 'c') return (e[1] && e[2] && e[3] && e[4] == '1') ? R2L_VARIANT_COOP16 : R2L_VARIANT_COOP;
-    const double main_t = (double)((N + 32767) / 32768);
+    // (one main round on the fp16x2 kernels costs 0.30 of a round of the fp32-MFMA kernel the unit was defined on; measured,
+    // tools/variant_sweep.py: 98 304-ray-style steps of 6144 rays 1.99 ms on the one-wave-per-tile kernels vs 2.11 ms on the
+    // 16-ray cooperative ones, 20 480 rays 2.9 vs 5.9 ms; 4096 rays 1.94 vs 1.34 ms)
+    const double main_t = (double)((N + 32767) / 32768) * (r2l_use_fwd3() ? 0.30 : 1.0);
     const double coop_t = (double)((N + 8191) / 8192) * 0.34;
     const double c16_t = (double)((N + 4095) / 4096) * R2L_C16_ROUND;
     if (c16_t < coop_t && c16_t < main_t) return R2L_VARIANT_COOP16;
