@@ -367,7 +367,7 @@ int r2l_coop16_backward(const float* rgb, const float* target, const float* drgb
                         hipStream_t stream);
 
 // ---- fp32-accurate forward on the bf16 matrix pipe (r2l_fwd3.hip): stage stream of bf16 (hi, mid, lo) weight triples ------
-#define R2L_F3_PAD_STAGES 6   // the staging pipeline requests up to 5 stages past the one being consumed
+#define R2L_F3_PAD_STAGES 8   // the staging pipelines request up to 7 stages past the one being consumed
 __host__ __device__ static inline int64_t r2l_fwd3_stages(int n_block) { return 64 + 34 * (int64_t)n_block; }
 __host__ __device__ static inline int64_t r2l_fwd3_stream_floats(int n_block) {
     return (r2l_fwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);

@@ -16,7 +16,9 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define F2_STAGE_BYTES 16384  // 2 splits x 8 tiles x 64 lanes x 16 B
+#ifndef F2_NBUF
 #define F2_NBUF 6
+#endif
 
 struct F2Split {
     f16x8 h, m;
@@ -70,8 +72,10 @@ struct F2Side {
         if (!want_b) return;
         if (i == 0) {
             gather(x);
+#ifndef F2_NO_AMAX
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));  // v_max3_f32
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+#endif
         } else if (i == 1) {
             uh[0] = pk(x[0], x[1]);
             uh[1] = pk(x[2], x[3]);
@@ -142,8 +146,10 @@ struct F2Pipe {
     }
     // vmcnt retires in order: the own loads of stage k+1 have the 4 x 3 loads of stages k+2..k+4 behind them
     __device__ __forceinline__ void sync_next() {
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        static_assert(F2_NBUF == 6, "wait immediate written for 6 buffers");
+        // F2_NBUF buffers: stages k+2 .. k+F2_NBUF-2 (4 loads each) may still fly behind the loads of stage k+1
+        if (F2_NBUF == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        static_assert(F2_NBUF == 6 || F2_NBUF == 8, "wait immediates written for 6 or 8 buffers");
         __syncthreads();
         gb = (gb == F2_NBUF - 1) ? 0 : gb + 1;
         lb = base + gb * F2_STAGE_BYTES + lane * 16;

@@ -221,13 +221,15 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
         P.gqb = 0;
         P.amax = 0.f;
     }
-    P.issue(); P.issue(); P.issue(); P.issue(); P.issue();
+#pragma unroll
+    for (int k = 0; k < F2_NBUF - 1; ++k) P.issue();  // stages 0 .. F2_NBUF-2
 #pragma unroll
     for (int k = 0; k < 8; ++k) P.ones.h[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
     P.ones.m = P.ones.h;
 
     f32x16 x[R2L_NT], t[R2L_NT];
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (F2_NBUF == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 landed
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     __syncthreads();
     P.lb = P.base + lane * 16;
     {
