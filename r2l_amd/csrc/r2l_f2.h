@@ -150,7 +150,9 @@ struct F2Pipe {
         if (F2_NBUF == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         static_assert(F2_NBUF == 6 || F2_NBUF == 8, "wait immediates written for 6 or 8 buffers");
+#ifndef F2_TIMING_NO_BARRIER  // (timing experiment only: results are wrong without the barrier)
         __syncthreads();
+#endif
         gb = (gb == F2_NBUF - 1) ? 0 : gb + 1;
         lb = base + gb * F2_STAGE_BYTES + lane * 16;
     }
