@@ -246,28 +246,8 @@ def lr_schedule(step, lrate, lrate_decay, warmup_lr=""):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# hooks used by __graft_entry__.smoke() and bench.py
+# hook used by bench.py
 # ---------------------------------------------------------------------------------------------------------------
-def smoke_check(net, ps, sd, O):
-    """One tiny fused training step on cuda:0 checked against the oracle's autograd + Adam."""
-    g = torch.Generator().manual_seed(1)
-    n = 300
-    o = torch.randn(n, 3, generator=g) * 1.5
-    d = torch.randn(n, 3, generator=g)
-    tgt = torch.rand(n, 3, generator=g)
-    tr = R2LTrainer(net, ps)
-    emb = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
-    loss_ref, _, grads_ref = O.r2l_loss_and_grads(sd, emb, tgt)
-    tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda())
-    flat_ref = torch.cat([grads_ref[k].reshape(-1) for k in sd])
-    gerr = (tr.grads.cpu() - flat_ref).abs().max().item() / flat_ref.abs().max().item()
-    lerr = abs(tr.loss_out[0].item() - loss_ref.item())
-    print("[smoke] train step %d rays: |loss-oracle| = %.2e, max|grad-oracle|/max|grad| = %.2e" % (n, lerr, gerr))
-    # fp32 re-association flips the ReLU mask of the few activations within ~1e-6 of zero (3.3 M per 300 rays), which
-    # moves individual gradient entries by O(1e-3) of the largest one; anything structural would be O(1)
-    assert lerr < 1e-6 and gerr < 5e-3, (lerr, gerr)
-
-
 def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak, n_rays=None):
     """Training leg of bench.py: K fused steps of `a.train_rays` rays per GPU (synthetic [o,d,rgb] rows as in the
     `.npy` shards, main.py:1305-1311), RCCL all-reduce when world > 1."""
