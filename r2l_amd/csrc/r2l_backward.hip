@@ -660,8 +660,11 @@ __device__ __forceinline__ void dw3c_split_part(Dw3cQuad& q, const f32x4& x, int
         if (part == 0) {
             q.uh[0] = dw3c_pk16(x[0], x[1]);
             q.uh[1] = dw3c_pk16(x[2], x[3]);
-            q.r[0] = x[0] - dw3c_lo16(q.uh[0]); q.r[1] = x[1] - dw3c_hi16(q.uh[0]);
-            q.r[2] = x[2] - dw3c_lo16(q.uh[1]); q.r[3] = x[3] - dw3c_hi16(q.uh[1]);
+            // x - half in one v_fma_mix_f32 each (r2l_f2.h)
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q.r[0]) : "v"(q.uh[0]), "v"(x[0]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q.r[1]) : "v"(q.uh[0]), "v"(x[1]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q.r[2]) : "v"(q.uh[1]), "v"(x[2]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q.r[3]) : "v"(q.uh[1]), "v"(x[3]));
         } else {
             q.um[0] = dw3c_pk16(q.r[0], q.r[1]);
             q.um[1] = dw3c_pk16(q.r[2], q.r[3]);

@@ -20,6 +20,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define F2_NBUF 6
 #endif
 
+// x - fp16 half of a packed pair in ONE instruction: v_fma_mix_f32 (the half as a mixed-precision operand times -1.0 plus
+// x; exact).  The compiler's own form is v_cvt_f32_f16 + v_sub_f32 (checked bit-identical on the device: tools/_bin/mix_probe)
+__device__ __forceinline__ float f2_res_lo(unsigned h, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+__device__ __forceinline__ float f2_res_hi(unsigned h, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+
 struct F2Split {
     f16x8 h, m;
 };
@@ -80,8 +93,8 @@ struct F2Side {
             uh[0] = pk(x[0], x[1]);
             uh[1] = pk(x[2], x[3]);
         } else if (i == 2) {
-            x[0] -= lo(uh[0]); x[1] -= hi(uh[0]);
-            x[2] -= lo(uh[1]); x[3] -= hi(uh[1]);
+            x[0] = f2_res_lo(uh[0], x[0]); x[1] = f2_res_hi(uh[0], x[1]);
+            x[2] = f2_res_lo(uh[1], x[2]); x[3] = f2_res_hi(uh[1], x[3]);
         } else if (i == 3) {
             um[0] = pk(x[0], x[1]);
             um[1] = pk(x[2], x[3]);
