@@ -33,6 +33,23 @@ __device__ __forceinline__ float f2_res_hi(unsigned h, float x) {
     return r;
 }
 
+// LDS-DMA pieces of one request share ONE M0 write: the instruction's immediate offset moves the memory address AND the LDS
+// address (measured: tools/dma_probe.hip), and consecutive pieces advance both by 1 KiB.  Nothing else in these kernels
+// writes M0 between the pieces of a request (LDS instructions do not use it on gfx9+; no dynamic register indexing).
+__device__ __forceinline__ void f2_dma_base(unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_addr) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void f2_dma_piece(u32x4 rsrc, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" : : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void f2_dma_piece_i(int i, u32x4 rsrc, unsigned voff, unsigned soff) {
+    if (i == 0) f2_dma_piece<0>(rsrc, voff, soff);
+    else if (i == 1) f2_dma_piece<1024>(rsrc, voff, soff);
+    else if (i == 2) f2_dma_piece<2048>(rsrc, voff, soff);
+    else f2_dma_piece<3072>(rsrc, voff, soff);
+}
+
 struct F2Split {
     f16x8 h, m;
 };
@@ -80,7 +97,10 @@ struct F2Side {
     }
     __device__ __forceinline__ void step(int i) {
         loads(i);
-        if (dma.on && i < 4) f3_dma16(dma.rs, dma.voff, dma.so + i * 1024u, dma.la + i * 1024u);
+        if (dma.on && i < 4) {
+            if (i == 0) f2_dma_base(dma.la);
+            f2_dma_piece_i(i, dma.rs, dma.voff, dma.so);
+        }
         if (i == 5 && extra.on) f3_dma16(extra.rs, extra.voff, extra.so, extra.la);
         if (!want_b) return;
         if (i == 0) {
@@ -152,8 +172,9 @@ struct F2Pipe {
     __device__ __forceinline__ void issue() {
         const unsigned so = (unsigned)gq * F2_STAGE_BYTES + wq;
         const unsigned la = lds0 + (unsigned)gqb * F2_STAGE_BYTES + wq;
+        f2_dma_base(la);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f3_dma16(rs, voff, so + i * 1024u, la + i * 1024u);
+        for (int i = 0; i < 4; ++i) f2_dma_piece_i(i, rs, voff, so);
         ++gq;
         gqb = (gqb == F2_NBUF - 1) ? 0 : gqb + 1;
     }
