@@ -26,6 +26,39 @@ def test_library_exports_every_declared_symbol():
     assert lib.r2l_num_tiles(33) == 2
 
 
+def test_dispatch_and_buffer_size_helpers(monkeypatch):
+    """Host-side decisions of the library (no device work): which kernel family / stream layout an N-ray launch takes under
+    the environment switches, and the caller-side buffer sizes that go with them."""
+    from r2l_amd import _lib
+    lib = _lib.load()
+    for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_GRAD_TERMS"):
+        monkeypatch.delenv(k, raising=False)
+    # defaults: 16-ray cooperative kernels up to 4096 rays, one wave per tile (fp16x2, with the bf16x3 stream behind it) above
+    assert lib.r2l_variant_for(4096) == 2 and lib.r2l_variant_for(4097) == 0 and lib.r2l_variant_for(160000) == 0
+    assert lib.r2l_forward_layout_for(4096, 1) == 16
+    assert lib.r2l_forward_layout_for(98304, 1) == 2 and lib.r2l_forward_layout_for(160000, 0) == 2
+    assert lib.r2l_backward_layout_for(98304) == 2 and lib.r2l_backward_layout_for(4096) == 16
+    monkeypatch.setenv("R2L_NO_FWD2", "1")
+    assert lib.r2l_forward_layout_for(98304, 1) == 3 and lib.r2l_backward_layout_for(98304) == 2
+    monkeypatch.setenv("R2L_NO_BWD2", "1")
+    assert lib.r2l_backward_layout_for(98304) == 3
+    monkeypatch.delenv("R2L_NO_BWD2")
+    monkeypatch.setenv("R2L_GRAD_TERMS", "3")
+    assert lib.r2l_backward_layout_for(98304) == 3
+    monkeypatch.setenv("R2L_NO_FWD3", "1")  # everything on the fp32 MFMA: the small-batch kernels win up to 20 480 rays again
+    assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_backward_layout_for(98304) == 32
+    assert lib.r2l_variant_for(20480) == 2 and lib.r2l_variant_for(24576) == 0
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "coop")
+    assert lib.r2l_variant_for(98304) == 1 and lib.r2l_forward_layout_for(98304, 1) == 32
+    # buffer sizes: a stash slot holds 1 KiB + 32 B of mask words per (padded) ray; the streams hold every layout + status words
+    assert lib.r2l_padded_rows(33) == 64 and lib.r2l_stash_slot_floats(33) == 64 * 264
+    nb = 43
+    stages_f, stages_b, pad = 64 + 34 * nb, 34 * nb, 8
+    assert lib.r2l_fwd_stream_floats(nb) >= (stages_f + pad) * (24576 + 16384) // 4 + 16
+    assert lib.r2l_bwd_stream_floats(nb) >= (stages_b + pad) * (24576 + 16384) // 4 + 16
+    assert lib.r2l_dw_slab_floats() == 256 * 2 * (256 * 256 + 256) + 16
+
+
 def test_options_readme_command(tmp_path):
     from r2l_amd.options import parse_args
     cfg = os.path.join(ROOT, "configs", "lego_noview.txt")
