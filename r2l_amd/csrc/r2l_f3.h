@@ -1,6 +1,7 @@
 // r2l_f3.h — machinery shared by the kernels that run fp32-accurate GEMM chains on the bf16 matrix pipe (r2l_fwd3.hip,
-// r2l_teacher3.hip): bf16 (hi, mid, lo) triples, the LDS-DMA weight staging pipeline and the stage routine with its
-// hand-interleaved side work.  See the header comment of r2l_fwd3.hip for the scheme.
+// r2l_bwd3.hip, r2l_teacher3.hip): bf16 (hi, mid, lo) triples, the LDS-DMA weight staging pipeline and the stage routine
+// with its hand-interleaved side work.  See the header comment of r2l_fwd3.hip for the scheme.  The gatherers at the end
+// (layer inputs with their ride-along stash stores, positional-encoding values) are shared with the fp16x2 kernels (r2l_f2.h).
 #pragma once
 #include "r2l_common.h"
 

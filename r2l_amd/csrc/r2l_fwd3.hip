@@ -15,7 +15,9 @@
 //   * the eight B values of a block are split into (hi, mid, lo) on the VALU in the shadow of the block's 48 MFMAs;
 //   * the bias of a layer is ONE MFMA per output tile: hi, mid, lo of the bias sit in three k slots against B = 1;
 //   * X_0 stays in registers (the weight ring no longer needs them) for the outer residual.
-// Used for forward-only launches (render / evaluation); training keeps the fp32-MFMA kernels.
+// Since r2l_fwd2.hip (three fp16 products per fp32 product) became the default this kernel is its range-guard fallback
+// (launched behind it, returns at once unless the fp16 kernel raised its status word) and the R2L_NO_FWD2=1 path; with SAVE
+// it also writes the training stash (chunked layout + ReLU mask words, r2l_common.h).
 #include "r2l_f3.h"
 
 __host__ __device__ static inline int64_t f3_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
