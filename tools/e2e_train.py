@@ -15,7 +15,7 @@ from r2l_amd import data, driver  # noqa: E402
 from tests.test_driver_cpu import make_scene  # noqa: E402
 
 
-def main(n_files=240, it_a=130, it_b=330):
+def main(n_files=240, it_a=230, it_b=530):
     tmp = tempfile.mkdtemp(prefix="r2l_e2e_")
     os.chdir(tmp)
     scene = os.path.join(tmp, "scene")
@@ -38,7 +38,7 @@ def main(n_files=240, it_a=130, it_b=330):
     out = {}
     # (an untimed first run: one-off costs of the process — library load, first-touch of the big buffers — would otherwise
     # sit in the first timed run only and not cancel in the subtraction)
-    driver.main(common + ["--N_iters", "30", "--experiment_name", "e2e_w"])
+    driver.main(common + ["--N_iters", "130", "--experiment_name", "e2e_w"])
     for tag, iters in (("a", it_a), ("b", it_b)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
