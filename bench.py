@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py — rays/sec of the R2L W256D88 hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (the driver's form) this process is a rank;
+started bare it launches the N ranks itself (plan_launch) — and exits non-zero rather than run on fewer GPUs than
+--gpus says.  The printed line carries n_gpus and rccl_ranks (the latter measured by an all-reduce).
 
 Workload (config.workload): BASELINE.json configs[1] — render 400x400 frames (160 000 rays each, 16 samples/ray,
 L=10, W256 D88, seeded weights, synthetic pose_spherical poses).  One "step" = one frame per GPU through the fused
@@ -185,6 +189,38 @@ def teacher_leg(device, world, rank, distributed, frames=2):
                          "flop_per_ray": flop_per_ray}}
 
 
+def plan_launch(gpus, env, n_visible, argv=None, free_port=None):
+    """What `python bench.py --gpus N` has to do in this process (reference: the DataParallel branch main.py:472-479 is
+    replaced by one process per GPU).  Returns ("run", world, rank, local_rank) when this process is a rank (or the
+    single-GPU job), or ("spawn", cmd) when it was started bare with N > 1 and must launch N ranks under
+    torch.distributed.run itself.  Raises SystemExit (non-zero) instead of ever running fewer GPUs than asked for."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    world_env = env.get("WORLD_SIZE")
+    if world_env is None:
+        if n_visible < gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible; refusing to report a smaller job "
+                             "under that label" % (gpus, n_visible))
+        if gpus == 1:
+            return ("run", 1, 0, 0)
+        if free_port is None:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                free_port = sk.getsockname()[1]
+        argv = list(sys.argv[1:]) if argv is None else list(argv)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port), os.path.abspath(__file__)] + argv
+        return ("spawn", cmd)
+    world = int(world_env)
+    if world != gpus:
+        raise SystemExit("bench.py: --gpus %d but launched with WORLD_SIZE=%d" % (gpus, world))
+    local_world = int(env.get("LOCAL_WORLD_SIZE", world))
+    if n_visible < local_world:
+        raise SystemExit("bench.py: %d local rank(s) but only %d GPU(s) are visible" % (local_world, n_visible))
+    return ("run", world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,17 +233,25 @@ def main():
     ap.add_argument("--no-teacher", action="store_true")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    plan = plan_launch(a.gpus, os.environ, torch.cuda.device_count())
+    if plan[0] == "spawn":  # `python bench.py --gpus N` run bare: become the launcher of N ranks (one per GPU)
+        import subprocess
+        raise SystemExit(subprocess.call(plan[1]))
+    _, world, rank, local_rank = plan
     distributed = world > 1
-    if a.gpus != world and distributed:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        # the rank count is MEASURED: a SUM all-reduce of ones over RCCL must return --gpus on every rank
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != a.gpus or dist.get_world_size() != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but the RCCL all-reduce saw %d rank(s) (world_size %d)"
+                             % (a.gpus, rccl_ranks, dist.get_world_size()))
 
     from r2l_amd import build as r2l_build
     if not os.path.exists(r2l_build.LIB):  # normally prebuilt in-tree by __graft_entry__.build(); never a CPU fallback
@@ -254,6 +298,7 @@ def main():
 
     out = {
         "metric": "rays/sec (train+render) W256D88 lego@400x400", "value": value, "unit": "rays/s", "n_gpus": world,
+        "rccl_ranks": rccl_ranks,  # measured: SUM all-reduce of ones over the nccl (= RCCL) process group
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": dtype,
@@ -320,8 +365,15 @@ def main():
     if train_mod is not None:
         out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
                                        PEAK_FP32_MFMA)
-        # BASELINE configs[2] read literally ("N_rand=4096" as 4096 rays per step): one 32-ray tile per wave fills only
-        # 128 of the 1024 wave slots, reported for completeness
+        if distributed:
+            # strong-scaling leg: the single-GPU batch (98 304 rays) split over the ranks, same global batch and the same
+            # optimisation schedule as N = 1; the bucketed all-reduce has to hide under 1/N of the dW kernels here
+            per = max(32, (a.train_rays // world + 31) // 32 * 32)
+            out["train_strong"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                                  PEAK_FP32_MFMA, n_rays=per)
+            out["train_strong"]["scaling"] = "strong"
+            out["train_strong"]["global_rays_per_step"] = per * world
+        # BASELINE configs[2] read literally ("N_rand=4096" as 4096 rays per step; at N GPUs configs[3]: 4096 rays per GPU)
         out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
                                             PEAK_FP32_MFMA, n_rays=4096)
         # reference leg: the same step with every GEMM on six bf16 products per fp32 product (fp32-exact products)

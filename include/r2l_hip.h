@@ -90,6 +90,23 @@ int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, 
                  const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                  float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N, void* stream);
 
+/* The same backward cut into stages for data-parallel hosts (replaces nn.DataParallel's ReduceAddCoalesced after
+ * loss.backward(), main.py:37-42,472-479,1404): `parts` = OR of the R2L_BWD_* bits; R2L_BWD_BODY computes the weight and
+ * bias gradients of the body layers [layer_lo, layer_hi) of the 2*n_block (layer 2b = body.b.body.0, 2b+1 = body.b.body.2),
+ * which are complete in `grads` once the call's kernels have run — the host can all-reduce that contiguous range of the
+ * flat buffer while later stages still execute.  R2L_BWD_CHAIN must come first in a step; all stages of a step go to
+ * one stream (they share dw_slab).  r2l_backward(...) == r2l_backward_part(..., R2L_BWD_ALL, 0, 2*n_block). */
+#define R2L_BWD_CHAIN 1
+#define R2L_BWD_BODY 2
+#define R2L_BWD_HEAD 4
+#define R2L_BWD_TAIL 8
+#define R2L_BWD_ALL 15
+int r2l_backward_part(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* emb,
+                      const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                      const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                      float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N, void* stream, int parts,
+                      int layer_lo, int layer_hi);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay 0) on flat buffers (main.py:465-467, 1406); `step` counts from 1;
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "r2l_stash_slot_floats": (_l, [_l]),
     "r2l_dw_slab_floats": (_l, []),
     "r2l_backward": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p]),
+    "r2l_backward_part": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p, _i, _i, _i]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
     "r2l_adam_hyper": (_i, [_p, _f, _f, _f, _i, _p]),
     "r2l_adam_step_dev": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _p]),
@@ -55,6 +56,9 @@ SIGNATURES = {
     "r2l_reader_release": (_i, [_p, _i]),
     "r2l_reader_close": (_i, [_p]),
 }
+
+# stage bits of r2l_backward_part (include/r2l_hip.h)
+BWD_CHAIN, BWD_BODY, BWD_HEAD, BWD_TAIL, BWD_ALL = 1, 2, 4, 8, 15
 
 _lib = None
 

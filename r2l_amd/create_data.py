@@ -60,6 +60,17 @@ def render_pose_rows(pose, H, W, focal, near, far, chunk, render_kwargs):
     return torch.cat([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), rgb.reshape(-1, 3)], dim=-1)
 
 
+def shard_index_base(rank, world, n_pose, chunk_poses, files_per_flush, n_existing=0):
+    """First data_<k>.npy index of a rank.  Every rank gets the same-sized index range, wide enough for the LARGEST
+    per-rank flush count (ranks own i % world == rank of 1..n_pose, so their pose counts differ by one and with them,
+    sometimes, their flush counts: n_pose=301, world=3, chunk=100 -> 1, 2, 1 flushes), and numbering continues after the
+    files a kept directory already holds, as the reference's does (create_data.py:789-792: `split = len(npys)`)."""
+    chunk_poses = max(int(chunk_poses), 1)
+    most_poses = (n_pose + world - 1) // world
+    most_flushes = (most_poses + chunk_poses - 1) // chunk_poses
+    return n_existing + rank * most_flushes * files_per_flush
+
+
 def main(argv=None):
     args = parse_args(argv)
     validate_accelerated(args)
@@ -85,13 +96,16 @@ def main(argv=None):
         os.makedirs(datadir_new, exist_ok=True)
     if world > 1:
         torch.distributed.barrier()
+    n_existing = len([x for x in os.listdir(datadir_new) if x.endswith(".npy")])  # kept directory: numbering continues
+    if world > 1:
+        torch.distributed.barrier()  # every rank has counted before any rank writes
     n_pose = args.n_pose_kd if isinstance(args.n_pose_kd, int) else int(args.n_pose_kd[0])
     mine = [i for i in range(1, n_pose + 1) if i % world == rank]
     rays_per_file = 4096
     # rank-disjoint shard index ranges: each flush of `create_data_chunk` poses yields at most this many files
     files_per_flush = (args.create_data_chunk * H * W) // rays_per_file
-    flushes = (len(mine) + args.create_data_chunk - 1) // max(args.create_data_chunk, 1)
-    next_index = rank * (flushes * files_per_flush)
+    next_index = shard_index_base(rank, world, n_pose, args.create_data_chunk, files_per_flush,
+                                  n_existing)
     # Rows of a flush are copied pose by pose (non-blocking) into one of two pinned staging buffers; a writer thread
     # shuffles and saves a full buffer while the GPU renders into the other one.  The only host syncs are one per flush.
     chunk_poses = max(args.create_data_chunk, 1)

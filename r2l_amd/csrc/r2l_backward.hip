@@ -9,6 +9,7 @@
 //   3. r2l_dw_head_kernel   : dW_head = G_head^T PE(rays) with the 1008-d positional encoding recomputed on the fly.
 //   4. r2l_dw_tail_kernel   : tail weight/bias gradients (3x256) by plain reduction.
 #include "r2l_common.h"
+#include "r2l_hip.h"
 
 // ---- flat parameter offsets (same as r2l_forward.hip) ---------------------------------------------------------
 __host__ __device__ static inline int64_t b_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
@@ -222,6 +223,8 @@ struct R2LDwArgs {
     const float* gt;
     float* grads;  // flat gradient buffer (state_dict order)
     int n_block;
+    int layer0;    // this launch covers the body layers [layer0, layer0 + n_layers) of the 2*n_block (gradient buckets, in
+    int n_layers;  // backward order, for the overlapped all-reduce: r2l_backward_part)
     int64_t N;
     int64_t units_per_layer;  // ceil(N / DW_CHUNK)
     int64_t units_per_wg;
@@ -292,8 +295,8 @@ __device__ __forceinline__ void dw_flush_slab(f32x16 (&acc)[4][4], f32x4& bsum, 
 // grads[layer] += sum of the workgroup partials of that layer, added in workgroup order (deterministic).  Workgroup w
 // covered units [w*upw, (w+1)*upw): its first layer is (w*upw)/upl and a layer's partial sits in slot layer - first.
 __global__ __launch_bounds__(256) void r2l_dw_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grads,
-                                                            int64_t upl, int64_t upw, int64_t wgs) {
-    const int layer = blockIdx.y;
+                                                            int64_t upl, int64_t upw, int64_t wgs, int layer0) {
+    const int layer = blockIdx.y;  // relative to layer0, like the work list
     const int i4 = blockIdx.x * 256 + threadIdx.x;
     if (i4 >= DW_SLAB_FLOATS / 4) return;
     const int64_t w0 = ((int64_t)layer * upl) / upw;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void r2l_dw_reduce_kernel(const float* __restr
         const int slot = layer - (int)((w * upw) / upl);
         s += *reinterpret_cast<const f32x4*>(slab + (w * 2 + slot) * (int64_t)DW_SLAB_FLOATS + 4 * i4);
     }
-    f32x4* g = reinterpret_cast<f32x4*>(grads + b_off_body_w(layer)) + i4;
+    f32x4* g = reinterpret_cast<f32x4*>(grads + b_off_body_w(layer0 + layer)) + i4;
     *g = *g + s;
 }
 
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wo = wave >> 1, wi = wave & 1;
     const int hh = lane >> 5, jl = lane & 31;
-    const int64_t total = a.units_per_layer * 2 * a.n_block;
+    const int64_t total = a.units_per_layer * a.n_layers;
     int64_t u0 = (int64_t)blockIdx.x * a.units_per_wg;
     int64_t u1 = u0 + a.units_per_wg;
     if (u1 > total) u1 = total;
@@ -328,9 +331,9 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     int64_t u = u0;
-    const int first_layer = (int)(u0 / a.units_per_layer);
+    const int first_layer = a.layer0 + (int)(u0 / a.units_per_layer);
     while (u < u1) {
-        const int layer = (int)(u / a.units_per_layer);
+        const int layer = a.layer0 + (int)(u / a.units_per_layer);
         const int64_t cu = u % a.units_per_layer;
         int64_t cend = cu + (u1 - u);
         if (cend > a.units_per_layer) cend = a.units_per_layer;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3_kernel(const R2LDwArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wo = wave >> 1, wi = wave & 1;
     const int hh = lane >> 5, jl = lane & 31;
-    const int64_t total = a.units_per_layer * 2 * a.n_block;
+    const int64_t total = a.units_per_layer * a.n_layers;
     int64_t u0 = (int64_t)blockIdx.x * a.units_per_wg;
     int64_t u1 = u0 + a.units_per_wg;
     if (u1 > total) u1 = total;
@@ -491,9 +494,9 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3_kernel(const R2LDwArgs a)
     const int64_t Np = R2L_PAD_ROWS(a.N);
 
     int64_t u = u0;
-    const int first_layer = (int)(u0 / a.units_per_layer);
+    const int first_layer = a.layer0 + (int)(u0 / a.units_per_layer);
     while (u < u1) {
-        const int layer = (int)(u / a.units_per_layer);
+        const int layer = a.layer0 + (int)(u / a.units_per_layer);
         const int64_t cu = u % a.units_per_layer;
         int64_t cend = cu + (u1 - u);
         if (cend > a.units_per_layer) cend = a.units_per_layer;
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wo = wave >> 1, wi = wave & 1;
-    const int64_t total = a.units_per_layer * 2 * a.n_block;
+    const int64_t total = a.units_per_layer * a.n_layers;
     int64_t u0 = (int64_t)blockIdx.x * a.units_per_wg;
     int64_t u1 = u0 + a.units_per_wg;
     if (u1 > total) u1 = total;
@@ -746,9 +749,9 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
     }
 
     int64_t u = u0;
-    const int first_layer = (int)(u0 / a.units_per_layer);
+    const int first_layer = a.layer0 + (int)(u0 / a.units_per_layer);
     while (u < u1) {
-        const int layer = (int)(u / a.units_per_layer);
+        const int layer = a.layer0 + (int)(u / a.units_per_layer);
         const int64_t cu = u % a.units_per_layer;
         int64_t cend = cu + (u1 - u);
         if (cend > a.units_per_layer) cend = a.units_per_layer;
@@ -1216,13 +1219,36 @@ extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS + 16; }
 extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_TRIO_SLOT(R2L_PAD_ROWS(N)); }
 
+extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                                 const float* emb, const float* rgb, const float* target, const float* drgb,
+                                 const float* save_x, const float* save_t,
+                                 const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
+                                 float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
+                                 void* stream_, int parts, int layer_lo, int layer_hi);
+
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
                             const float* save_x, const float* save_t,
                             const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
                             float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
                             void* stream_) {
+    return r2l_backward_part(rays_o, rays_d, t_rand, ztab, emb, rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block,
+                             grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, R2L_BWD_ALL, 0, 2 * n_block);
+}
+
+// The same backward cut into stages, so that a data-parallel host can hand finished gradient buckets to the collective
+// while the remaining stages still run: parts = OR of R2L_BWD_CHAIN (dX chain; must precede everything else of a step),
+// R2L_BWD_BODY (weight / bias gradients of the body layers [layer_lo, layer_hi) of the 2*n_block, complete in `grads`
+// when the call's kernels have run), R2L_BWD_HEAD, R2L_BWD_TAIL.  Stages of one step go to ONE stream (they share dw_slab).
+extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                                 const float* emb, const float* rgb, const float* target, const float* drgb,
+                                 const float* save_x, const float* save_t,
+                                 const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
+                                 float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
+                                 void* stream_, int parts, int layer_lo, int layer_hi) {
     if (N <= 0) return 0;
+    if (layer_lo < 0) layer_lo = 0;
+    if (layer_hi > 2 * n_block) layer_hi = 2 * n_block;
     hipStream_t stream = (hipStream_t)stream_;
     static int n_cu_cached = 0;  // one device type per process
     if (n_cu_cached == 0) {
@@ -1247,7 +1273,8 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         (void)frexpf(grad_scale, &e);
         gscale = ldexpf(1.0f, 8 - e);
     }
-    if (variant == R2L_VARIANT_COOP16) {
+    if (!(parts & R2L_BWD_CHAIN)) {
+    } else if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
                                            params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;
@@ -1282,16 +1309,17 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         R2L_CHECK(hipGetLastError());
     }
     // 2. body weight gradients
-    if (n_block > 0) {
+    if ((parts & R2L_BWD_BODY) && layer_hi > layer_lo) {
         R2LDwArgs a{};
         a.save_x = save_x; a.save_t = save_t; a.gx = gx; a.gt = gt; a.grads = grads; a.n_block = n_block; a.N = N;
+        a.layer0 = layer_lo; a.n_layers = layer_hi - layer_lo;
         a.units_per_layer = (N + DW_CHUNK - 1) / DW_CHUNK;
-        const int64_t total = a.units_per_layer * 2 * n_block;
+        const int64_t total = a.units_per_layer * a.n_layers;
         int64_t wgs = n_cu < DW_MAX_WGS ? n_cu : DW_MAX_WGS;
         if (wgs > total) wgs = total;
         a.units_per_wg = (total + wgs - 1) / wgs;
         wgs = (total + a.units_per_wg - 1) / a.units_per_wg;
-        // units_per_wg <= units_per_layer whenever wgs >= 2*n_block (always, for n_block <= 128): a range touches <= 2 layers
+        // units_per_wg <= units_per_layer whenever wgs >= n_layers (always, for n_block <= 128): a range touches <= 2 layers
         a.slab = (a.units_per_wg <= a.units_per_layer) ? dw_slab : nullptr;
         // bf16 matrix pipe at fp32 accuracy: operands split once per workgroup from the chunked stash of the bf16x3 chains
         // (r2l_dw_body3c), or per wave from the row-major stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
@@ -1318,13 +1346,13 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());
         if (a.slab != nullptr) {
-            hipLaunchKernelGGL(r2l_dw_reduce_kernel, dim3((DW_SLAB_FLOATS / 4 + 255) / 256, 2 * n_block), dim3(256), 0, stream,
-                               a.slab, grads, a.units_per_layer, a.units_per_wg, wgs);
+            hipLaunchKernelGGL(r2l_dw_reduce_kernel, dim3((DW_SLAB_FLOATS / 4 + 255) / 256, a.n_layers), dim3(256), 0, stream,
+                               a.slab, grads, a.units_per_layer, a.units_per_wg, wgs, a.layer0);
             R2L_CHECK(hipGetLastError());
         }
     }
     // 3. head weight gradient
-    {
+    if (parts & R2L_BWD_HEAD) {
         R2LDwHeadArgs a{};
         a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab; a.emb = emb; a.gh = gx; a.grads = grads; a.N = N;
         int64_t slices = n_cu / 4;
@@ -1352,7 +1380,7 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
         }
     }
     // 4. tail gradients
-    {
+    if (parts & R2L_BWD_TAIL) {
         int64_t wgs = 2 * n_cu;
         int64_t per = (N + wgs - 1) / wgs;
         if (per < 1) per = 1;

@@ -1,20 +1,58 @@
-"""The one collective of data-parallel R2L training: a SUM all-reduce of the flat fp32 gradient buffer
-(5 917 187 floats = 23.67 MB for W256 D88) over RCCL/xGMI (`nccl` backend on ROCm) — gloo on CPU tensors in tests.
-The division by world_size is folded into the Adam kernel (grad_scale).  Replaces nn.DataParallel's per-step
-parameter broadcast + input scatter + output gather + ReduceAddCoalesced (reference main.py:37-42, 472-479)."""
+"""Data-parallel plumbing of R2L training: one process per GPU, identical parameters on every rank, and ONE logical
+exchange per step — the SUM of the flat fp32 gradient buffer (5 917 187 floats = 23.67 MB for W256 D88) over RCCL/xGMI
+(`nccl` backend on ROCm; gloo on CPU tensors in tests).  The division by world_size is folded into the Adam kernel
+(grad_scale).  Replaces nn.DataParallel's per-step parameter broadcast + input scatter + output gather +
+ReduceAddCoalesced (reference main.py:37-42, 472-479, 1374, 1404).
+
+The exchange is cut into contiguous BUCKETS of the flat buffer that are handed to the collective in the order the
+backward finishes them (tail + the last body layers first, the head last: `bucket_plan`), each as an asynchronous
+all-reduce: on RCCL the collective's stream waits for the kernels already enqueued on the compute stream and runs
+beside the gradient kernels of the next bucket; `finish()` makes the compute stream (not the host) wait before Adam.
+"""
+import torch
 import torch.distributed as dist
+
+W = 256
+IN_DIM = 1008
+LAYER_FLOATS = W * W + W          # one body layer: weight [256,256] + bias [256]
+HEAD_FLOATS = IN_DIM * W + W      # head.0.weight + head.0.bias, at the start of the flat buffer
+TAIL_FLOATS = 3 * W + 3           # tail.0.weight + tail.0.bias, at its end
+
+
+def bucket_plan(n_block, n_buckets):
+    """Gradient buckets in backward order.  Returns a list of (layer_lo, layer_hi, flat_lo, flat_hi): the body layers
+    [layer_lo, layer_hi) of the 2*n_block (layer 2b = body.b.body.0, 2b+1 = body.b.body.2) whose gradients
+    r2l_backward_part(R2L_BWD_BODY, layer_lo, layer_hi) completes, and the range of the flat buffer to all-reduce then.
+    The first bucket's range also covers the tail (computed before the body), and a final (0, 0, 0, HEAD_FLOATS) entry
+    is the head.  Buckets hold whole blocks (layer pairs) so that a block's two GEMMs share a launch."""
+    n_buckets = max(1, min(int(n_buckets), max(n_block, 1)))
+    edges = [round(i * n_block / n_buckets) for i in range(n_buckets + 1)]
+    plan = []
+    end = HEAD_FLOATS + 2 * n_block * LAYER_FLOATS + TAIL_FLOATS
+    for i in reversed(range(n_buckets)):
+        lo, hi = 2 * edges[i], 2 * edges[i + 1]
+        flat_lo = HEAD_FLOATS + lo * LAYER_FLOATS
+        flat_hi = end if i == n_buckets - 1 else HEAD_FLOATS + hi * LAYER_FLOATS
+        plan.append((lo, hi, flat_lo, flat_hi))
+    plan.append((0, 0, 0, HEAD_FLOATS))
+    return plan
 
 
 class GradAllReducer:
     def __init__(self, process_group=None, bucket_floats=0):
         self.pg = process_group
-        self.bucket = bucket_floats  # 0: one call on the whole buffer
+        self.bucket = bucket_floats  # blocking form: 0 = one call on the whole buffer
+        self._works = []
 
     def world(self):
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.pg)
         return 1
 
+    def grad_scale(self):
+        return 1.0 / self.world()
+
+    # ---- blocking form ----------------------------------------------------------------------------------------------
     def allreduce(self, flat, async_op=False):
         """In-place sum over ranks; returns the list of work handles when async_op."""
         if self.world() == 1:
@@ -28,5 +66,39 @@ class GradAllReducer:
                 handles.append(h)
         return handles
 
-    def grad_scale(self):
-        return 1.0 / self.world()
+    # ---- overlapped form: submit finished buckets as the backward produces them ------------------------------------------
+    def submit(self, bucket):
+        """Start the all-reduce of a finished, contiguous range of the flat gradient (a view).  The kernels that wrote
+        it must already be enqueued on the current stream."""
+        if self.world() > 1:
+            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def pending(self):
+        return len(self._works)
+
+    def finish(self):
+        """Everything submitted is summed once this returns (GPU: once the current stream gets there; no host block)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
+def sync_parameters(flat, process_group=None, src=0):
+    """Every rank continues with rank `src`'s parameters (flat buffer, in place).  nn.DataParallel re-broadcast the one
+    module of GPU 0 every step (reference main.py:472-479); with one process per GPU the replicas are made identical
+    once, at trainer construction, and stay identical because every rank applies the same Adam update to the same
+    summed gradient."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(flat, src=src, group=process_group)
+        return True
+    return False
+
+
+def parameters_in_sync(flat, process_group=None):
+    """True on every rank iff all ranks hold bit-identical `flat` (a debugging / test aid: two all-reduces)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return True
+    lo, hi = flat.clone(), flat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=process_group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=process_group)
+    return bool(torch.equal(lo, hi))

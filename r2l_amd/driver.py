@@ -187,6 +187,8 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     model.eval()
     mine = list(range(rank, len(poses), world))
     rgbs, sq_err, psnrs, ssims, events = [], [], [], [], []
+    if savedir is not None:
+        os.makedirs(savedir, exist_ok=True)  # every rank writes its own frames: none may rely on rank 0's mkdir
     writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "8"))) if savedir is not None else None
     on_gpu = device.type == "cuda"
     t_loop = time.time()
@@ -249,6 +251,10 @@ def main(argv=None):
                                   "utils/create_data.py (its training is out of scope)")
     rank, world, device = init_distributed()
     np.random.seed(0)
+    # every rank must build the same student: torch's default generator is seeded per process otherwise (the reference had
+    # ONE module that nn.DataParallel re-broadcast every step, main.py:472-479); R2LTrainer additionally broadcasts rank 0's
+    # flat parameter buffer once, so a checkpoint-less start is identical on all ranks by construction
+    torch.manual_seed(int(os.environ.get("R2L_SEED", "0")))
     logger = Logger(args, rank)
 
     images, poses, render_poses, hwf, i_split = D.load_blender_data(args.datadir, args.half_res, args.testskip)
@@ -320,7 +326,12 @@ def main(argv=None):
         raise RuntimeError("R2L training runs on the HIP path and needs a ROCm GPU")
     datadir_kd = args.datadir_kd.split(":")[1] if ":" in args.datadir_kd else args.datadir_kd
     files = D.list_ray_shards(datadir_kd, args.pseudo_ratio, args.pseudo_data_hold_ratio)
-    loader = D.RayShardLoader(files, args.N_rand, rank=rank, world=world, device=device,
+    # --N_rand is the GLOBAL batch in shard files per step, as in the reference (its DataLoader builds one batch that
+    # nn.DataParallel then splits over the GPUs, main.py:794-806,1374): each rank loads N_rand / world shards, so the
+    # README command keeps its optimisation schedule (lrate, N_iters, hard-ray pool size) at any GPU count
+    if args.N_rand % world:
+        raise SystemExit("--N_rand %d (shard files per step, global) must be divisible by the %d ranks" % (args.N_rand, world))
+    loader = D.RayShardLoader(files, args.N_rand // world, rank=rank, world=world, device=device,
                               threads=max(1, min(args.num_workers, 16)))
     logger.info("Loaded data. Now total #train files: %d (this rank: %d)" % (len(files), len(loader.files)))
     trainer = R2LTrainer(model, point_sampler, lw_rgb=args.lw_rgb)

@@ -44,6 +44,8 @@ def supported_reason(module):
     for b in blocks:
         if type(b).__name__ != "ResMLP" or len(b.body) != 3 or b.outact is not None or float(b.res_scale) != 1.0:
             return "body must be ResMLP(256) blocks with n_learnable=2, res_scale=1, outact=none"
+        if not isinstance(b.body[1], torch.nn.ReLU):
+            return "only --trial.inact relu (the chain kernels apply a hard-coded ReLU inside a block)"
         if b.body[0].in_features != W or b.body[0].out_features != W:
             return "ResMLP width must be 256"
     return None

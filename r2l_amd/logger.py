@@ -13,6 +13,14 @@ class Logger:
     def __init__(self, args, rank=0):
         self.rank = rank
         stamp = time.strftime("%Y%m%d-%H%M%S")
+        try:  # one experiment folder per job: every rank uses rank 0's time stamp
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                box = [stamp]
+                dist.broadcast_object_list(box, src=0)
+                stamp = box[0]
+        except ImportError:
+            pass
         server = os.environ.get("R2L_SERVER_ID", "000")
         self.ExpID = "SERVER%s-%s" % (server, stamp)
         root = "Debug_Dir" if getattr(args, "debug", False) else getattr(args, "experiments_dir", "Experiments")

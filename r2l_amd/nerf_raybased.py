@@ -113,12 +113,13 @@ def get_activation(act):
 class ResMLP(nn.Module):
     """x + res_scale * body(x), body = Linear [act Linear]*(n_learnable-1); optional output activation."""
 
-    def __init__(self, width, inact=None, outact=None, res_scale=1, n_learnable=2):
+    def __init__(self, width, inact=nn.ReLU(True), outact=None, res_scale=1, n_learnable=2):
         super().__init__()
-        inact = nn.ReLU(True) if inact is None else inact
         layers = [nn.Linear(width, width)]
         for _ in range(n_learnable - 1):
-            layers += [inact, nn.Linear(width, width)]
+            if inact is not None:  # --trial.inact none: Linear, Linear with nothing in between (reference :453-455)
+                layers.append(inact)
+            layers.append(nn.Linear(width, width))
         self.body = nn.Sequential(*layers)
         self.res_scale = res_scale
         self.outact = outact
@@ -145,17 +146,24 @@ class NeRF_v3_2(nn.Module):
         act = get_activation(args.act)
         self.input_dim = input_dim
         self.head = nn.Sequential(nn.Linear(input_dim, widths[0]), act)
+        def plain_body():  # the reference default (not accelerated: CPU / torch ops only)
+            layers = []
+            for i in range(1, D - 1):
+                layers += [nn.Linear(widths[i - 1], widths[i]), act]
+            return layers
+
+        # The reference always constructs the plain D-2 layer body first and drops it when a --trial body replaces it
+        # (model/nerf_raybased.py:502-505, then 508-530).  Those nn.Linear initialisers consume RNG draws, so the same
+        # construction is replayed here: under torch.manual_seed(s) every parameter then coincides with the reference's.
+        body = plain_body()
         trial = getattr(args, "trial", None)
         if trial is not None and trial.body_arch == "resmlp":
             n_block = trial.n_block if trial.n_block > 0 else (D - 2) // 2
-            body = [
-                ResMLP(W, inact=get_activation(trial.inact), outact=get_activation(trial.outact),
-                       res_scale=trial.res_scale, n_learnable=trial.n_learnable) for _ in range(n_block)
-            ]
-        else:  # plain MLP body (reference default; not accelerated, CPU/torch only)
-            body = []
-            for i in range(1, D - 1):
-                body += [nn.Linear(widths[i - 1], widths[i]), act]
+            inact, outact = get_activation(trial.inact), get_activation(trial.outact)
+            body = [ResMLP(W, inact=inact, outact=outact, res_scale=trial.res_scale, n_learnable=trial.n_learnable)
+                    for _ in range(n_block)]
+        elif trial is not None and trial.body_arch == "mlp":
+            body = plain_body()  # built a second time there too
         self.body = nn.Sequential(*body)
         if getattr(args, "linear_tail", False):
             self.tail = nn.Linear(input_dim, output_dim)

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .dist_utils import GradAllReducer
+from .dist_utils import GradAllReducer, bucket_plan, sync_parameters
 from .engine import N_SAMPLE, W, _ptr, _stream, get_engine
 
 
@@ -36,6 +36,10 @@ class R2LTrainer:
         self.lib = self.eng.lib
         self.betas, self.eps, self.lw_rgb = betas, eps, lw_rgb
         self.reducer = GradAllReducer(process_group)
+        # world > 1: gradient buckets in backward order, each all-reduced (async, RCCL's own stream) while the gradient
+        # kernels of the next bucket run; R2L_AR_BUCKETS=0 selects one blocking all-reduce after the whole backward
+        self.n_buckets = int(os.environ.get("R2L_AR_BUCKETS", "4"))
+        self.force_staged = False  # tests: run the staged backward on one GPU (nothing is submitted at world == 1)
         self.step_count = 0
         self.cap = 0
         self.dw_slab = None
@@ -46,6 +50,9 @@ class R2LTrainer:
     def _alloc_state(self):
         eng = self.eng
         eng.ensure_packed()
+        if sync_parameters(eng.flat, self.reducer.pg):  # replicas start from rank 0's weights (per-rank RNG)
+            eng.mark_dirty()
+            eng.ensure_packed()
         dev, n = eng.device, eng.n_param
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -103,11 +110,21 @@ class R2LTrainer:
         if zero_grad:
             self.grads.zero_()
         grad_scale = 2.0 * self.lw_rgb / (3.0 * n)
-        _lib.check(
-            self.lib.r2l_backward(_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target),
-                                  None, _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat),
-                                  eng.n_block, grad_scale, _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt),
-                                  _ptr(self.sqerr), _ptr(self.grads), _ptr(self.dw_slab), n, _stream()), "r2l_backward")
+        args = (_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target), None,
+                _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat), eng.n_block, grad_scale,
+                _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt), _ptr(self.sqerr), _ptr(self.grads), _ptr(self.dw_slab), n,
+                _stream())
+        if (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
+            # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
+            # blocks to the first, the head last; every finished range of the flat gradient goes to the collective at once
+            part = self.lib.r2l_backward_part
+            _lib.check(part(*args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0), "r2l_backward_part(chain, tail)")
+            for lo, hi, flat_lo, flat_hi in bucket_plan(eng.n_block, self.n_buckets):
+                what = _lib.BWD_BODY if hi > lo else _lib.BWD_HEAD
+                _lib.check(part(*args, what, lo, hi), "r2l_backward_part(%d, %d)" % (lo, hi))
+                self.reducer.submit(self.grads[flat_lo:flat_hi])
+        else:
+            _lib.check(self.lib.r2l_backward(*args), "r2l_backward")
         _lib.check(
             self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
                                      _ptr(self.loss_out), _stream()), "r2l_loss_finish")
@@ -117,8 +134,12 @@ class R2LTrainer:
         return self.reducer.world()
 
     def allreduce_grads(self):
-        """ONE collective per step: sum of the flat fp32 gradient over ranks."""
-        self.reducer.allreduce(self.grads)
+        """The step's one exchange: sum of the flat fp32 gradient over ranks.  When forward_backward
+        already handed the buckets to the collective this only makes the stream wait for them."""
+        if self.reducer.pending():
+            self.reducer.finish()
+        else:
+            self.reducer.allreduce(self.grads)
 
     def adam(self, lr):
         self.step_count += 1

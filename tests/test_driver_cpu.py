@@ -118,6 +118,43 @@ avg = flat * red.grad_scale()
 ref = torch.cat([full[k].reshape(-1) for k in sd])
 err = (avg - ref).abs().max().item() / ref.abs().max().item()
 assert err < 1e-5, err
+# overlapped form: buckets in backward order, submitted one by one, == ONE all-reduce of the whole buffer, bit for bit
+from r2l_amd.dist_utils import bucket_plan, sync_parameters, parameters_in_sync, HEAD_FLOATS, LAYER_FLOATS, TAIL_FLOATS
+nb = 5
+total = HEAD_FLOATS + 2 * nb * LAYER_FLOATS + TAIL_FLOATS
+gg = torch.Generator().manual_seed(100 + rank)
+mine_g = torch.randn(total, generator=gg)
+single = mine_g.clone()
+dist.all_reduce(single)
+for n_buckets in (1, 2, 4, 9):
+    plan = bucket_plan(nb, n_buckets)
+    # the plan tiles the flat buffer exactly once, from its end to its start, in whole blocks
+    covered = sorted((lo, hi) for _, _, lo, hi in plan)
+    assert covered[0][0] == 0 and covered[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert [p[2] for p in plan] == sorted((p[2] for p in plan), reverse=True)
+    assert all(l0 %% 2 == 0 and l1 %% 2 == 0 for l0, l1, _, _ in plan)
+    assert sorted(l for l0, l1, _, _ in plan for l in range(l0, l1)) == list(range(2 * nb))
+    buf = mine_g.clone()
+    for _, _, lo, hi in plan:
+        red.submit(buf[lo:hi])
+    assert red.pending() == len(plan)
+    red.finish()
+    assert red.pending() == 0 and torch.equal(buf, single), n_buckets
+# replicas start identical: each rank builds its own random "parameters", rank 0's win
+params = torch.randn(1000, generator=gg)
+assert not parameters_in_sync(params)
+assert sync_parameters(params)
+assert parameters_in_sync(params)
+# one experiment folder per job: the logger's ExpID is rank 0's on every rank
+import argparse, time
+from r2l_amd.logger import Logger
+os.chdir(%(tmp)r)
+time.sleep(1.1 * rank)  # ranks read the clock in different seconds
+lg = Logger(argparse.Namespace(experiment_name="t", experiments_dir="Experiments", debug=False), rank)
+ids = [None] * world
+dist.all_gather_object(ids, lg.ExpID)
+assert len(set(ids)) == 1, ids
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", err)
@@ -126,10 +163,60 @@ print("rank", rank, "ok", err)
 
 def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
+    script.write_text(WORKER % {"root": ROOT, "tmp": str(tmp_path)})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launch_plan_spawns_or_refuses():
+    """`python bench.py --gpus N`: bare with N > 1 -> becomes the launcher of N ranks; fewer visible GPUs than asked for,
+    or a WORLD_SIZE that contradicts --gpus -> non-zero exit instead of a mislabelled single-GPU number."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.plan_launch(1, {}, 1) == ("run", 1, 0, 0)
+    kind, cmd = bench.plan_launch(4, {}, 8, argv=["--gpus", "4", "--steps", "5"], free_port=29999)
+    assert kind == "spawn"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "5"]
+    env = {"WORLD_SIZE": "4", "RANK": "2", "LOCAL_RANK": "2", "LOCAL_WORLD_SIZE": "4"}
+    assert bench.plan_launch(4, env, 4) == ("run", 4, 2, 2)
+    for gpus, e, vis in ((2, {}, 1), (8, {}, 4), (1, {"WORLD_SIZE": "2"}, 2), (4, {"WORLD_SIZE": "2"}, 4),
+                         (4, env, 2), (0, {}, 1)):
+        with pytest.raises(SystemExit) as ex:
+            bench.plan_launch(gpus, e, vis)
+        assert ex.value.code not in (0, None)
+
+
+def test_bench_gpus2_fails_loudly_without_two_gpus():
+    """The real command line on this (GPU-less) box: must exit non-zero and say why, never print a JSON line."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in r.stderr and "{" not in r.stdout
+
+
+def test_create_data_rank_index_ranges_never_overlap():
+    from r2l_amd.create_data import shard_index_base
+    fpf = (100 * 400 * 400) // 4096
+    for n_pose, world, chunk in ((301, 3, 100), (10000, 8, 100), (7, 4, 2), (1, 2, 100)):
+        fpf_ = (chunk * 400 * 400) // 4096
+        ranges = []
+        for rank in range(world):
+            mine = [i for i in range(1, n_pose + 1) if i % world == rank]
+            flushes = (len(mine) + chunk - 1) // chunk
+            base = shard_index_base(rank, world, n_pose, chunk, fpf_, n_existing=17)
+            ranges.append((base, base + flushes * fpf_))
+        assert min(r[0] for r in ranges) == 17  # numbering continues behind the files already there
+        ranges.sort()
+        assert all(a[1] <= b[0] for a, b in zip(ranges, ranges[1:])), (n_pose, world, chunk, ranges)
+    assert shard_index_base(2, 3, 301, 100, fpf) == 2 * 2 * fpf  # the advisor's example: flush counts 1, 2, 1
