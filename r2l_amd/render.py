@@ -144,10 +144,12 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
 # ---------------------------------------------------------------------------------------------------------------
 # raw2outputs / sample_pdf
 # ---------------------------------------------------------------------------------------------------------------
-def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, **_ignored):
-    """(rgb_map[R,3], disp_map[R], acc_map[R], weights[R,S], depth_map[R])   (create_data.py:335-402)."""
-    noise = None
-    if raw_noise_std > 0.:
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None, **_ignored):
+    """(rgb_map[R,3], disp_map[R], acc_map[R], weights[R,S], depth_map[R])   (create_data.py:335-402).
+    `noise` [R,S] (already scaled) replaces the internal draw of the reference when given (tests: same draw on both sides)."""
+    if noise is not None:
+        noise = noise.to(raw.device).float().contiguous()
+    elif raw_noise_std > 0.:
         if pytest:
             np.random.seed(0)
             noise = torch.Tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std)

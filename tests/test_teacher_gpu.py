@@ -60,6 +60,11 @@ def test_raw2outputs_shapes_vs_oracle(S, R):
     got = raw2outputs(raw.cuda(), z.cuda(), d.cuda(), 0, True)
     for a, b in zip(got, ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-5, atol=3e-6)
+    # raw_noise_std > 0 (create_data.py:368-378): the same draw added to sigma before the ReLU on both sides
+    ref = O.raw2outputs(raw, z, d, noise, False)
+    got = raw2outputs(raw.cuda(), z.cuda(), d.cuda(), 1.0, False, noise=noise.cuda())
+    for a, b in zip(got, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-5, atol=3e-6)
 
 
 def test_sample_pdf_sort_golden(golden_dir):

@@ -12,27 +12,34 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "main-bf16x3", "main-grad3", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "main-bf16x3-fwd", "main-bf16x3-trio", "main-grad3", "main-f32mfma", "coop",
+                                      "coop16"])
 def chain_variant(request, monkeypatch):
-    """Every test runs under each chain kernel family: one wave per tile with the fp16x2 forward (r2l_fwd2.hip, default)
-    or the bf16x3 forward (R2L_NO_FWD2=1) in front of the bf16x3 gradient kernels (r2l_bwd3.hip, r2l_dw_body3c; also with the
-    opt-in 3-product gradient GEMMs, R2L_GRAD_TERMS=3), everything on the fp32 MFMA (R2L_NO_FWD3=1), and the two cooperative
-    small-batch families."""
+    """Every test runs under each kernel family of the training step:
+      main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip), fp16x2 dX chain (r2l_bwd2.hip) and
+                       the fp16 dW body GEMMs, each range-guarded with its bf16x3 kernel behind it
+      main-bf16x3-fwd  R2L_NO_FWD2=1: bf16x3 forward (r2l_fwd3.hip) in front of the default gradient kernels
+      main-bf16x3-trio R2L_NO_FWD2 = R2L_NO_BWD2 = R2L_NO_DW2 = 1: the whole step on six bf16 products per fp32 product —
+                       exactly the kernels the range guards fall back to
+      main-grad3       R2L_GRAD_TERMS=3: bf16x3 chains, 3-product bf16 gradient GEMMs (opt-in)
+      main-f32mfma     R2L_NO_FWD3=1: everything on the exact-fp32 MFMA
+      coop / coop16    the cooperative small-batch families."""
     name = request.param
     monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
+    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_GRAD_TERMS"):
+        monkeypatch.delenv(k, raising=False)
     if name == "main-f32mfma":
         monkeypatch.setenv("R2L_NO_FWD3", "1")
-    else:
-        monkeypatch.delenv("R2L_NO_FWD3", raising=False)
     if name == "main-grad3":
         monkeypatch.setenv("R2L_GRAD_TERMS", "3")
-    else:
-        monkeypatch.delenv("R2L_GRAD_TERMS", raising=False)
-    if name == "main-bf16x3":
+    if name == "main-bf16x3-fwd":
         monkeypatch.setenv("R2L_NO_FWD2", "1")
-    else:
-        monkeypatch.delenv("R2L_NO_FWD2", raising=False)
+    if name == "main-bf16x3-trio":
+        for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
+            monkeypatch.setenv(k, "1")
     return name
+
+
 T = torch.from_numpy
 
 
@@ -201,6 +208,39 @@ def test_gradients_bit_reproducible_and_slab_matches_atomics(n):
     g3 = split_flat(tr.grads.cpu(), sd)
     for k, v in split_flat(g1.cpu(), sd).items():
         assert rel_err(g3[k], v) < 1e-5, k
+
+
+@pytest.mark.parametrize("n,buckets", [(700, 4), (5000, 1), (5000, 5), (5000, 43)])
+def test_staged_backward_equals_single_call(n, buckets):
+    """r2l_backward_part (dX chain + tail, body buckets from the last blocks to the first, head) — the form the
+    overlapped gradient all-reduce drives — leaves the gradients of the one-call r2l_backward (bit-identical with one
+    bucket; with several, equal up to the fp32 summation order of the per-workgroup partials)."""
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=43, seed=3)
+    m = build_model(sd, 43)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    tr = R2LTrainer(m, ps)
+    g = torch.Generator().manual_seed(n)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+    u = torch.rand(n, 16, generator=g).cuda()
+    tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    g1, l1 = tr.grads.clone(), tr.loss_out.clone()
+    tr.force_staged, tr.n_buckets = True, buckets
+    tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    assert tr.reducer.pending() == 0  # world == 1: nothing goes to a collective
+    assert torch.equal(l1, tr.loss_out)
+    if buckets == 1:  # same work list as the one-call form: same partial sums, same order
+        assert torch.equal(g1, tr.grads)
+    else:  # a bucket's (layer, ray-chunk) list is cut into other per-workgroup ranges: fp32 summation order only
+        a, b = split_flat(g1.cpu(), sd), split_flat(tr.grads.cpu(), sd)
+        for k in sd:
+            assert rel_err(b[k], a[k]) < 1e-5, k
+        staged = tr.grads.clone()
+        tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+        assert torch.equal(staged, tr.grads)  # and the staged form is bit-reproducible run to run as well
 
 
 def test_graph_replayed_steps_equal_eager_steps(monkeypatch):
