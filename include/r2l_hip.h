@@ -107,6 +107,20 @@ int r2l_backward_part(const float* rays_o, const float* rays_d, const float* t_r
                       float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N, void* stream, int parts,
                       int layer_lo, int layer_hi);
 
+/* ---- gradient all-reduce for hosts without torch.distributed ----------------------------------------------------------
+ * The one exchange of data-parallel training (replaces nn.DataParallel's ReduceAddCoalesced + parameter broadcast,
+ * main.py:37-42,472-479): in-place SUM of grads[n] over the ranks, RCCL over xGMI, enqueued on the caller's stream.  RCCL
+ * is dlopen'ed on first use (librccl.so.1; override with R2L_RCCL_PATH).  One communicator per process = per GPU (the
+ * device current at r2l_allreduce_init).  Rank 0 makes the 128-byte id, the host hands it to the other ranks.  Ranges of
+ * the flat buffer finished by r2l_backward_part can be reduced one by one (the call is asynchronous on `stream`).
+ * Errors: R2L_ERR_RCCL_BASE + ncclResult_t (R2L_ERR_RCCL_BASE alone: library missing / bad arguments). */
+#define R2L_ERR_RCCL_BASE 10000
+typedef struct r2l_comm r2l_comm;
+int r2l_allreduce_unique_id(void* id_out128);
+int r2l_allreduce_init(const void* id128, int world, int rank, r2l_comm** out);
+int r2l_grad_allreduce(r2l_comm* comm, float* grads, int64_t n, void* stream);
+int r2l_allreduce_destroy(r2l_comm* comm);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay 0) on flat buffers (main.py:465-467, 1406); `step` counts from 1;
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

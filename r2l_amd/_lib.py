@@ -36,6 +36,10 @@ SIGNATURES = {
     "r2l_dw_slab_floats": (_l, []),
     "r2l_backward": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p]),
     "r2l_backward_part": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p, _i, _i, _i]),
+    "r2l_allreduce_unique_id": (_i, [_p]),
+    "r2l_allreduce_init": (_i, [_p, _i, _i, _p]),
+    "r2l_grad_allreduce": (_i, [_p, _p, _l, _p]),
+    "r2l_allreduce_destroy": (_i, [_p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
     "r2l_adam_hyper": (_i, [_p, _f, _f, _f, _i, _p]),
     "r2l_adam_step_dev": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _p]),

@@ -102,3 +102,54 @@ def parameters_in_sync(flat, process_group=None):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=process_group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=process_group)
     return bool(torch.equal(lo, hi))
+
+
+class NativeGradAllReducer:
+    """The C-ABI form of the exchange (include/r2l_hip.h r2l_allreduce_*: RCCL dlopen'ed by libr2l_hip.so, no
+    torch.distributed) — what a non-PyTorch host binds.  Same submit/finish surface as GradAllReducer; the collective is
+    enqueued on the current stream, so `finish` has nothing to wait for."""
+
+    def __init__(self, unique_id, world, rank):
+        import ctypes
+        from . import _lib
+        self._lib, self._ctypes = _lib, ctypes
+        self.lib = _lib.load()
+        self._world, self.rank = int(world), int(rank)
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.lib.r2l_allreduce_init(ctypes.cast(buf, ctypes.c_void_p), self._world, self.rank,
+                                               ctypes.cast(ctypes.byref(self._h), ctypes.c_void_p)), "r2l_allreduce_init")
+
+    @staticmethod
+    def make_unique_id():
+        """128 opaque bytes, made on rank 0; the host distributes them to the other ranks."""
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().r2l_allreduce_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "r2l_allreduce_unique_id")
+        return buf.raw
+
+    def world(self):
+        return self._world
+
+    def grad_scale(self):
+        return 1.0 / self._world
+
+    def submit(self, bucket):
+        ct = self._ctypes
+        self._lib.check(self.lib.r2l_grad_allreduce(self._h, ct.c_void_p(bucket.data_ptr()), bucket.numel(),
+                                                    ct.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "r2l_grad_allreduce")
+
+    allreduce = submit
+
+    def pending(self):
+        return 0
+
+    def finish(self):
+        pass
+
+    def close(self):
+        if self._h:
+            self._lib.check(self.lib.r2l_allreduce_destroy(self._h), "r2l_allreduce_destroy")
+            self._h = self._ctypes.c_void_p()
