@@ -126,12 +126,6 @@ int r2l_allreduce_destroy(r2l_comm* comm);
 int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
-/* The same update in hipGraph-capturable form: lr and the bias corrections of `step` are read from hyper_dev[4], which
- * r2l_adam_hyper refreshes (one tiny launch, outside the captured graph) before every replay. */
-int r2l_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, int step, void* stream);
-int r2l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                      const float* hyper_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
-
 /* out2[0] = inv_denom * sum(sqerr_partial) (= img2mse * lw_rgb, helpers:19), out2[1] = psnr (helpers:20). */
 int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_denom, float* out2, void* stream);
 

@@ -41,8 +41,6 @@ SIGNATURES = {
     "r2l_grad_allreduce": (_i, [_p, _p, _l, _p]),
     "r2l_allreduce_destroy": (_i, [_p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
-    "r2l_adam_hyper": (_i, [_p, _f, _f, _f, _i, _p]),
-    "r2l_adam_step_dev": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _p]),
     "r2l_loss_finish": (_i, [_p, _l, _f, _p, _p]),
     "r2l_teacher_param_count": (_l, []),
     "r2l_teacher_stream_floats": (_l, []),

@@ -31,50 +31,6 @@ extern "C" int r2l_adam_step(float* params, const float* grads, float* exp_avg, 
     return 0;
 }
 
-// ---- graph-capturable form: the per-step scalars (lr, bias corrections) live in a 4-float device buffer ------------------
-// A captured hipGraph bakes kernel arguments in; r2l_adam_hyper (one tiny launch outside the graph, values passed by
-// value in its own launch packet) refreshes the buffer before every replay.
-__global__ void r2l_adam_hyper_kernel(float* __restrict__ hyper, float lr, float bc1, float sqrt_bc2) {
-    hyper[0] = lr;
-    hyper[1] = bc1;
-    hyper[2] = sqrt_bc2;
-    hyper[3] = 0.f;
-}
-__global__ void r2l_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                    float* __restrict__ v, int64_t n, const float* __restrict__ hyper, float b1, float b2,
-                                    float eps, float gscale) {
-    const float step_size = hyper[0] / hyper[1];
-    const float sqrt_bc2 = hyper[2];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-        const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-        p[i] = p[i] - step_size * (mi / denom);
-    }
-}
-
-extern "C" int r2l_adam_hyper(float* hyper_dev, float lr, float beta1, float beta2, int step, void* stream) {
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(r2l_adam_hyper_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper_dev, lr, (float)bc1,
-                       (float)sqrt(bc2));
-    R2L_CHECK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int r2l_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                 const float* hyper_dev, float beta1, float beta2, float eps, float grad_scale,
-                                 void* stream) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(r2l_adam_dev_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, hyper_dev, beta1, beta2, eps, grad_scale);
-    R2L_CHECK(hipGetLastError());
-    return 0;
-}
-
 // out[0] = sum(partials) / denom (mse*lw), out[1] = psnr = -10 log10(out[0]); single block, deterministic order
 __global__ void r2l_loss_finish_kernel(const float* __restrict__ partial, int64_t n, float inv_denom,
                                        float* __restrict__ out) {

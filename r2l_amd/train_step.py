@@ -43,7 +43,6 @@ class R2LTrainer:
         self.step_count = 0
         self.cap = 0
         self.dw_slab = None
-        self._graphs, self._graph_seen, self._hyper = {}, {}, None
         self._alloc_state()
 
     # ---- buffers --------------------------------------------------------------------------------------------------
@@ -152,79 +151,11 @@ class R2LTrainer:
 
     def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None):
         """zero_grad + forward + backward + all-reduce + Adam.  Returns (rgb[N,3], loss_out[2] = [loss, psnr]) on
-        the device (no host sync).  With R2L_USE_GRAPH=1 small single-GPU batches replay a captured hipGraph of the
-        whole step (off by default: measured SLOWER than the eager launches on ROCm 7.2, see _graph_eligible)."""
-        if self._graph_eligible(rays_o, perturb, t_rand):
-            return self._step_graphed(rays_o, rays_d, target, lr, perturb)
+        the device (no host sync)."""
         rgb = self.forward_backward(rays_o, rays_d, target, perturb, t_rand)
         self.allreduce_grads()
         self.adam(lr)
         return rgb, self.loss_out
-
-    # ---- hipGraph replay of the whole step ---------------------------------------------------------------------------------
-    # A 4096-ray step is ~18 launches in 1.4 ms, the regime graphs are meant for — but the eager launches already run back
-    # to back (kernel times sum to 1.35 ms of the 1.38 ms step) and on this stack (ROCm 7.2, PyTorch 2.10) the replay of the
-    # captured step is slower: same-box A/B 1.558 ms (graph) vs 1.377 ms (eager).  Kept as an opt-in (R2L_USE_GRAPH=1) with
-    # a bit-exactness test; off by default.
-    GRAPH_MAX_RAYS = 16384
-
-    def _graph_eligible(self, rays_o, perturb, t_rand):
-        if not os.environ.get("R2L_USE_GRAPH") or not rays_o.is_cuda or t_rand is not None:
-            return False
-        n = rays_o.shape[0]
-        if n > self.GRAPH_MAX_RAYS or self.world() > 1 or torch.cuda.is_current_stream_capturing():
-            return False
-        key = (n, perturb > 0)
-        seen = self._graph_seen.get(key, 0)
-        self._graph_seen[key] = seen + 1
-        return seen >= 1 and self._graphs.get(key) is not False  # the first step of a shape runs eagerly (allocations)
-
-    def _step_graphed(self, rays_o, rays_d, target, lr, perturb):
-        eng, n = self.eng, rays_o.shape[0]
-        key = (n, perturb > 0)
-        gs = self._graphs.get(key)
-        if gs is None:
-            f = dict(dtype=torch.float32, device=eng.device)
-            gs = {"o": torch.empty(n, 3, **f), "d": torch.empty(n, 3, **f), "t": torch.empty(n, 3, **f)}
-            if self._hyper is None:
-                self._hyper = torch.zeros(4, **f)
-            self._ensure_capacity(n)
-            eng.ensure_packed()
-            eng.ztab(self.ps.z_vals, perturb)  # cached table: no H2D inside the capture
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            try:
-                self._capture(graph, gs, perturb)
-            except Exception as e:  # capture unsupported in this context: stay on the eager launches for this shape
-                self._graphs[key] = False
-                print("[r2l] hipGraph capture of the %d-ray step failed (%s); using eager launches" % (n, e))
-                rgb = self.forward_backward(rays_o, rays_d, target, perturb, None)
-                self.adam(lr)
-                return rgb, self.loss_out
-            gs["graph"] = graph
-            self._graphs[key] = gs
-        gs["o"].copy_(rays_o)
-        gs["d"].copy_(rays_d)
-        gs["t"].copy_(target)
-        self.step_count += 1
-        _lib.check(self.lib.r2l_adam_hyper(_ptr(self._hyper), float(lr), self.betas[0], self.betas[1], self.step_count,
-                                           _stream()), "r2l_adam_hyper")
-        gs["graph"].replay()
-        eng.mark_dirty()  # parameters changed behind the version counters; the graph itself re-packs at its start
-        return gs["rgb"], self.loss_out
-
-    def _capture(self, graph, gs, perturb):
-        eng = self.eng
-        with torch.cuda.graph(graph):
-            eng.pack_now()
-            _lib.check(self.lib.r2l_pack_backward(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), _stream()),
-                       "r2l_pack_backward")
-            self._bwd_packed = {16: eng.version(), 32: eng.version(), 3: eng.version(), 2: eng.version()}  # (pack_now did the forward stream)
-            gs["rgb"] = self.forward_backward(gs["o"], gs["d"], gs["t"], perturb)
-            _lib.check(
-                self.lib.r2l_adam_step_dev(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                           eng.n_param, _ptr(self._hyper), self.betas[0], self.betas[1], self.eps, 1.0,
-                                           _stream()), "r2l_adam_step_dev")
 
     # ---- torch.optim.Adam-compatible state (checkpoint surface: 'optimizer_state_dict', main.py:1528-1529) --------------
     def optimizer_state_dict(self, lr):

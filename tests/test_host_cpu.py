@@ -228,15 +228,26 @@ def test_convert_images_to_ray_shards(tmp_path):
     assert len(files) == 2  # 'train_*' files count as original data in BlenderDataset_v2's selection rule
 
 
-def test_all_blender_scene_configs_parse():
-    """configs/: teacher and student files for the 8 NeRF-synthetic scenes at 400x400 and 800x800 (tools/gen_configs.py)."""
+def test_all_blender_scene_configs_parse(tmp_path):
+    """Teacher and student config files for the 8 NeRF-synthetic scenes at 400x400 and 800x800, as tools/gen_configs.py
+    writes them (the repo tracks the lego ones, the scene BASELINE.json names; they must equal the generator's output)."""
+    import importlib.util
     from r2l_amd.options import parse_args
+    spec = importlib.util.spec_from_file_location("gen_configs", os.path.join(ROOT, "tools", "gen_configs.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
     scenes = ["chair", "drums", "ficus", "hotdog", "lego", "materials", "mic", "ship"]
+    assert gen.SCENES == scenes
+    gen.write_configs(scenes, str(tmp_path))
+    tracked = sorted(os.listdir(os.path.join(ROOT, "configs")))
+    assert tracked == ["lego.txt", "lego_800x800.txt", "lego_noview.txt", "lego_noview_800x800.txt"]
+    for name in tracked:
+        assert open(os.path.join(ROOT, "configs", name)).read() == open(str(tmp_path / name)).read()
     for scene in scenes:
         for student in (False, True):
             for full in (False, True):
                 name = scene + ("_noview" if student else "") + ("_800x800" if full else "") + ".txt"
-                a = parse_args(["--config", os.path.join(ROOT, "configs", name)])
+                a = parse_args(["--config", str(tmp_path / name)])
                 assert a.datadir.endswith("nerf_synthetic/" + scene) and a.dataset_type == "blender"
                 assert a.half_res == (not full) and a.use_viewdirs == (not student) and a.white_bkgd
                 assert (a.N_samples, a.N_importance, a.lrate_decay) == (64, 128, 500)

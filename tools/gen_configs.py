@@ -62,16 +62,27 @@ basedir=./logs
 '''
 
 
-def main():
-    for scene in SCENES:
+def write_configs(scenes, out_dir):
+    os.makedirs(out_dir, exist_ok=True)
+    for scene in scenes:
         for student in (False, True):
             for full_res in (False, True):
                 name = scene + ("_noview" if student else "") + ("_800x800" if full_res else "") + ".txt"
                 kw = dict(scene=scene, res="800x800" if full_res else "400x400", half="False" if full_res else "True",
                           note="the full-size renders" if full_res else "half_res of the 800x800 renders")
-                with open(os.path.join(ROOT, name), "w") as f:
+                with open(os.path.join(out_dir, name), "w") as f:
                     f.write((STUDENT if student else TEACHER).format(**kw))
-    print(len(os.listdir(ROOT)), "config files in", ROOT)
+
+
+def main():
+    """The repo tracks only the lego files (the scene BASELINE.json names); `python tools/gen_configs.py all [dir]` writes
+    the other seven scenes when they are wanted."""
+    import sys
+    scenes = SCENES if "all" in sys.argv[1:] else ["lego"]
+    dirs = [a for a in sys.argv[1:] if a != "all"]
+    out = dirs[0] if dirs else ROOT
+    write_configs(scenes, out)
+    print(len(os.listdir(out)), "config files in", out)
 
 
 if __name__ == "__main__":
