@@ -9,16 +9,8 @@
 //   3. r2l_dw_head_kernel   : dW_head = G_head^T PE(rays) with the 1008-d positional encoding recomputed on the fly.
 //   4. r2l_dw_tail_kernel   : tail weight/bias gradients (3x256) by plain reduction.
 #include "r2l_common.h"
+#include "r2l_dw.h"
 #include "r2l_hip.h"
-
-// ---- flat parameter offsets (same as r2l_forward.hip) ---------------------------------------------------------
-__host__ __device__ static inline int64_t b_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
-__host__ __device__ static inline int64_t b_off_body_w(int layer) {
-    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
-}
-__host__ __device__ static inline int64_t b_off_body_b(int layer) { return b_off_body_w(layer) + R2L_W * R2L_W; }
-__host__ __device__ static inline int64_t b_off_tail_w(int n_block) { return b_off_body_w(2 * n_block); }
-__host__ __device__ static inline int64_t b_off_tail_b(int n_block) { return b_off_tail_w(n_block) + 3 * R2L_W; }
 
 struct R2LBwdArgs {
     const float* rgb;      // [N,3] forward output
@@ -208,38 +200,6 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
 // order: deterministic, and ~0.2 ms cheaper per step than the 65 536 scattered fp32 atomics per flush it replaced
 // (which remain as the dw_slab == NULL path).  The gradient buffer is zeroed by the caller (accumulation for free).
 // =================================================================================================================
-#define DW_CHUNK 64  // rays per work unit
-#ifndef DW_DEPTH
-#define DW_DEPTH 4  // rotating operand buffers = k-steps of load latency covered (must divide 32)
-#endif
-#ifndef DW_LONG_TRIP
-#define DW_LONG_TRIP 128  // k-steps per trip of the main loop
-#endif
-
-struct R2LDwArgs {
-    const float* save_x;
-    const float* save_t;
-    const float* gx;
-    const float* gt;
-    float* grads;  // flat gradient buffer (state_dict order)
-    int n_block;
-    int layer0;    // this launch covers the body layers [layer0, layer0 + n_layers) of the 2*n_block (gradient buckets, in
-    int n_layers;  // backward order, for the overlapped all-reduce: r2l_backward_part)
-    int64_t N;
-    int64_t units_per_layer;  // ceil(N / DW_CHUNK)
-    int64_t units_per_wg;
-    float* slab;  // [wgs][2][DW_SLAB_FLOATS] per-workgroup partial (dW, db) of the <= 2 layers its range touches, or
-                  // nullptr -> fp32 atomics straight into grads
-    float unscale = 1.0f;  // the gradient operands carry a power-of-two scale (r2l_bwd3): dW, db are multiplied by its inverse
-    // range guard of the fp16 variant (r2l_dw_body3c_kernel<3, true>): it raises *status when an operand value leaves fp16's
-    // safe range; the bf16 variant launched behind it with run_if = status then redoes the launch (else returns at once)
-    unsigned* status = nullptr;
-    const unsigned* run_if = nullptr;
-};
-
-#define DW_SLAB_FLOATS (R2L_W * R2L_W + R2L_W)  // one layer: dW[256][256] then db[256], as in the flat gradient
-#define DW_MAX_WGS 256
-#define DW_HEAD_SLAB_MAX ((int64_t)64 * R2L_W * 1024)  // head partials: up to 64 ray slices of [256][1024] at the slab start
 
 __device__ __forceinline__ void dw_flush(f32x16 (&acc)[4][4], f32x4& bsum, float* __restrict__ gw, float* __restrict__ gb,
                                          int wo, int wi, int lane) {
@@ -1273,6 +1233,17 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         (void)frexpf(grad_scale, &e);
         gscale = ldexpf(1.0f, 8 - e);
     }
+    // the default trio of one-wave-per-tile MSE-mode steps: fp16 chains + fp16 weight-gradient GEMMs on fp16 stage pieces
+    const bool trio16 = split && target != nullptr && r2l_use_trio16();
+    if (split && target == nullptr && r2l_use_trio16()) {
+        r2l_set_error_msg("r2l_backward: generic mode (drgb) after r2l_forward_rays needs the fp32 stash of the bf16x3 trio: set "
+                          "R2L_NO_DW2=1 around both calls (MSE mode and the pre-embedded path are unaffected)");
+        return (int)hipErrorInvalidValue;
+    }
+    const float* w3 = wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
+    const float* w2 = w3 + r2l_bwd3_stream_floats(n_block);
+    // raised by r2l_bwd2_kernel when this step has to run on the bf16x3 kernels (range guard / the forward fell back)
+    unsigned* bwd_status = reinterpret_cast<unsigned*>(const_cast<float*>(w2) + r2l_bwd2_status_offset(n_block));
     if (!(parts & R2L_BWD_CHAIN)) {
     } else if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
@@ -1283,21 +1254,18 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
                                          gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;
     } else if (split) {
-        // one-wave-per-tile dX chain.  MSE mode (scaled chain, values in fp16's range up to the guard): two-way fp16 splits,
-        // 3 fp16 products per fp32 product (r2l_bwd2.hip), with the bf16x3 chain behind it as range-guard fallback (returns at
-        // once unless the status word behind the bwd2 stream was raised); otherwise the bf16x3 chain (r2l_bwd3.hip)
-        const float* w3 = wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
-        const float* w2 = w3 + r2l_bwd3_stream_floats(n_block);
-        const bool bwd16 = target != nullptr && r2l_use_bwd2();
-        unsigned* status = reinterpret_cast<unsigned*>(const_cast<float*>(w2) + r2l_bwd2_status_offset(n_block));
-        if (bwd16) {
-            R2L_CHECK(hipMemsetAsync(status, 0, 64, stream));
-            const int rc = r2l_bwd2_backward(rgb, target, drgb, save_x, save_t, w2, params, n_block, grad_scale, dpre, gx, gt,
-                                             sqerr_partial, N, stream, gscale, status);
-            if (rc) return rc;
+        // one-wave-per-tile dX chain.  Default trio (MSE mode: scaled chain, values in fp16's range up to the guard): two-way fp16
+        // splits, 3 fp16 products per fp32 product (r2l_bwd2.hip), stashing fp16 stage pieces for r2l_dw16.hip, with the
+        // bf16x3 chain behind it as fallback (returns at once unless the status word behind the bwd2 stream was raised: range
+        // guard, or the forward already fell back and left an fp32 stash); otherwise the bf16x3 chain (r2l_bwd3.hip)
+        if (trio16) {
+            R2L_CHECK(hipMemsetAsync(bwd_status, 0, 64, stream));
+            const int rc2 = r2l_bwd2_backward(rgb, target, drgb, save_x, save_t, w2, params, n_block, grad_scale, dpre, gx, gt,
+                                              sqerr_partial, N, stream, gscale, bwd_status);
+            if (rc2) return rc2;
         }
         const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t, w3, params, n_block, grad_scale, dpre, gx, gt,
-                                         sqerr_partial, N, stream, gscale, bwd16 ? status : nullptr);
+                                         sqerr_partial, N, stream, gscale, trio16 ? bwd_status : nullptr);
         if (rc) return rc;
     } else {
         R2LBwdArgs a{};
@@ -1325,20 +1293,14 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         // (r2l_dw_body3c), or per wave from the row-major stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
         // chunked stash: the gradient operands carry the chain's power-of-two scale
         if (split) a.unscale = 1.0f / gscale;
-        // default in MSE mode (operand range known up to the guard): two-way fp16 splits, 3 fp16 products per fp32 product,
-        // with the bf16 6-product kernel behind it as range-guard fallback (status word at the end of dw_slab)
-        const bool dw16 = split && target != nullptr && a.slab != nullptr && r2l_grad_terms() == 6 && !getenv("R2L_NO_DW2");
-        if (dw16) {
-            unsigned* status = reinterpret_cast<unsigned*>(dw_slab + (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS);
-            R2L_CHECK(hipMemsetAsync(status, 0, 64, stream));
-            a.status = status;
-            hipLaunchKernelGGL((r2l_dw_body3c_kernel<3, true>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
-            R2L_CHECK(hipGetLastError());
-            a.status = nullptr;
-            a.run_if = status;
+        // default trio: one fp16 product per fp32 product on the fp16 stage pieces the chains stashed (r2l_dw16.hip); when the
+        // dX chain raised its status word (this step fell back to the bf16x3 chains and their fp32 stash) it returns at once
+        // and the bf16x3 kernel behind it does the work
+        if (trio16) {
+            const int rc = r2l_dw16_launch(a, wgs, bwd_status, stream);
+            if (rc) return rc;
+            a.run_if = bwd_status;
             hipLaunchKernelGGL((r2l_dw_body3c_kernel<6, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
-        } else if (split && r2l_grad_terms() == 3) {
-            hipLaunchKernelGGL((r2l_dw_body3c_kernel<3, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
         } else if (split) {
             hipLaunchKernelGGL((r2l_dw_body3c_kernel<6, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
         }

@@ -58,6 +58,8 @@ struct B2Args {
     float grad_scale;
     float gscale, ginv;  // the chain runs on gscale * g (a power of two; what it stashes is scaled), gx[0] is scaled back
     unsigned* status;    // range guard: raised when a chain value leaves fp16's safe range (the bf16x3 kernel then redoes it)
+    const unsigned* fmt; // stash format word of the forward (r2l_common.h): != 0 -> chunked fp32 stash (the forward fell back to
+                         // the bf16x3 kernel): this launch raises *status and leaves the work to the bf16x3 chain as well
     float* dpre;
     float* gx;
     float* gt;
@@ -66,28 +68,25 @@ struct B2Args {
 };
 
 // gatherers: four B values of the next stage (+ their stash store)
-struct B3TakeG {  // g values (identity), stored to gx[b+1]
+// (what the weight-gradient GEMMs read of g / the masked u is the fp16 hi operand these values are converted to: stashed by
+// the stage that assembles it, r2l_f2.h F2Hst — gx[b+1] and gt[b] hold fp16 stage pieces, scaled by gscale)
+struct B3TakeG {  // g values (identity)
     const f32x16& frag;
     int c0;
-    float* stash;  // lane base (r2l_chunk_lane) in the gx slot: chunked layout
-    int T;
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = frag[c0 + s];
-        r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
     }
 };
-struct B3TakeU {  // u values masked by relu'(t_b) (mask words of the forward: bit (T&1)*16 + c of word T>>1), stored to gt[b]
+struct B3TakeU {  // u values masked by relu'(t_b) (mask words of the forward: bit (T&1)*16 + c of word T>>1)
     const f32x16& frag;
     int c0;
-    float* stash;
     int T;
     const u32x4& mb;
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
         const unsigned w = mb[T >> 1] >> ((T & 1) * 16 + c0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = ((w >> s) & 1u) ? frag[c0 + s] : 0.f;
-        r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
     }
 };
 
@@ -95,6 +94,10 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
 
+    if (__builtin_nontemporal_load(a.fmt) != 0u) {  // the forward's stash is the bf16x3 trio's: so is this step's backward
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
+        return;
+    }
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // a wave whose tile lies past the end recomputes the last live tile (identical values to identical addresses): nothing in
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&mring[0][0][0] +
                               (unsigned)wave * (B3_RING * 1024u);
     const unsigned char* ring_lane = &mring[0][0][0] + wave * (B3_RING * 1024) + lane * 16;
-    const int64_t lane_off = r2l_chunk_lane(tile, lane & 31, h);  // this lane's base in a (chunked) slot
     const int64_t slot = R2L_TRIO_SLOT(Np);
+    const int64_t lane_unit = tile * R2L_H16_TILE_UNITS + lane;  // this lane's 16-byte unit of stage piece 0 in a slot
     const unsigned mvoff = (unsigned)((R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) * 4);  // byte offset of the lane's mask words
 
 #pragma unroll 1
@@ -204,25 +207,27 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
         const u32x4 trs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta),
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ta >> 32)) & 0xffffu, 0xffffffffu,
                            0x00020000u};
-        float* gxs = a.gx + (int64_t)(b + 1) * slot + lane_off;
-        float* gts = a.gt + (int64_t)b * slot + lane_off;
+        u32x4* gxh = reinterpret_cast<u32x4*>(a.gx + (int64_t)(b + 1) * slot) + lane_unit;
+        u32x4* gth = reinterpret_cast<u32x4*>(a.gt + (int64_t)b * slot) + lane_unit;
         const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
         const F3Dma mask_dma{true, trs, mvoff, 0u, ring_lds + (unsigned)(b & 1) * 1024u};
         // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
-        f2_stage<true, true, false>(u, P, B3TakeG{g[0], 0, gxs, 0}, B3TakeG{g[0], 4, gxs, 0}, mask_dma, no_dma);
+        f2_stage<true, true, false>(u, P, B3TakeG{g[0], 0}, B3TakeG{g[0], 4}, mask_dma, no_dma, F2Hst{true, gxh});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f2_stage<false, false, false>(u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gxs, (kb + 1) >> 1},
-                                          B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gxs, (kb + 1) >> 1});
+            f2_stage<false, false, false>(u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
+                                          B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4}, no_dma, no_dma,
+                                          F2Hst{true, gxh + 64 * (kb + 1)});
         // (the mask piece was requested 16 stages ago: every stage wait since has retired all but the newest loads)
         const u32x4 mb = *reinterpret_cast<const u32x4*>(ring_lane + (b & 1) * 1024);
         f2_stage<false, false, true>(u, P, F3None{}, F3None{});
         // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
-        f2_stage<true, false, false>(g, P, B3TakeU{u[0], 0, gts, 0, mb}, B3TakeU{u[0], 4, gts, 0, mb});
+        f2_stage<true, false, false>(g, P, B3TakeU{u[0], 0, 0, mb}, B3TakeU{u[0], 4, 0, mb}, no_dma, no_dma, F2Hst{true, gth});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f2_stage<false, false, false>(g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), gts, (kb + 1) >> 1, mb},
-                                          B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, gts, (kb + 1) >> 1, mb});
+            f2_stage<false, false, false>(g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), (kb + 1) >> 1, mb},
+                                          B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, (kb + 1) >> 1, mb}, no_dma, no_dma,
+                                          F2Hst{true, gth + 64 * (kb + 1)});
         f2_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
     }
 
@@ -230,17 +235,25 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
 
     // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] ---------------------------------------------------------
     {
-        const float* r = a.save_x + lane_off;  // x_0: chunked like every slot the forward chain stashes
-        float* o = a.gx + ray * R2L_W + 4 * h;  // row-major: the head weight gradient reads rows
+        // x_0 = relu(head): its fp16 stage pieces (slot 0 of save_x); stage kb = 2T + r holds fragment registers c = 8r .. 8r+7
+        // of tile T.  Only the sign matters; fp16 rounds x_0 < 3e-8 to zero (such a unit counts as inactive).
+        const u32x4* r = reinterpret_cast<const u32x4*>(a.save_x) + lane_unit;
+        float* o = a.gx + ray * R2L_W + 4 * h;  // row-major fp32: the head weight gradient reads rows
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(r + R2L_CHUNK_PIECE * (4 * T + q));
-                f32x4 ov;
+            for (int rr = 0; rr < 2; ++rr) {
+                const f16x8 xv = __builtin_bit_cast(f16x8, r[64 * (2 * T + rr)]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? (g[T][4 * q + j] + dy[T][4 * q + j]) * a.ginv : 0.f;
-                *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = ov;
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    f32x4 ov;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 8 * rr + 4 * q2 + j;
+                        ov[j] = (float)xv[4 * q2 + j] > 0.f ? (g[T][c] + dy[T][c]) * a.ginv : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * (2 * rr + q2)) = ov;
+                }
             }
     }
 }
@@ -260,6 +273,7 @@ int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, 
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status) {
     B2Args a{};
     a.status = status;
+    a.fmt = reinterpret_cast<const unsigned*>(save_x) + R2L_STASH_FMT_WORD(n_block, R2L_PAD_ROWS(N));
     a.gscale = gscale; a.ginv = 1.0f / gscale;
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;

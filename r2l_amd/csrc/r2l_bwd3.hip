@@ -274,8 +274,7 @@ int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, 
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    if (r2l_grad_terms() == 3) hipLaunchKernelGGL(r2l_bwd3_kernel<3>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(r2l_bwd3_kernel<6>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(r2l_bwd3_kernel<6>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

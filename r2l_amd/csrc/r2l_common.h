@@ -189,6 +189,10 @@ __device__ __forceinline__ void r2l_stash_store_nt(float* p, const f32x4& v) {
 // written by the forward chain, read back by the dX chain with ONE 1 KiB LDS-DMA piece per block)
 #define R2L_TRIO_SLOT(Np) ((int64_t)(Np) * (R2L_W + 8))
 #define R2L_MASK_OFFSET(Np) ((int64_t)(Np) * R2L_W)
+// slot n_block of save_x (y = x_n + x_0, row-major) has no mask words: the first word of that area tells the backward which
+// format the forward left in the other slots: 0 = fp16 stage pieces (r2l_f2.h: the default fp16 trio), 1 = chunked fp32 (the
+// bf16x3 forward, also when it ran as the range-guard fallback of the fp16 one)
+#define R2L_STASH_FMT_WORD(n_block, Np) ((int64_t)(n_block) * R2L_TRIO_SLOT(Np) + R2L_MASK_OFFSET(Np))
 __device__ __forceinline__ int64_t r2l_chunk_lane(int64_t tile, int j, int h) {
     return tile * R2L_CHUNK_TILE + j * 8 + 4 * h;
 }
@@ -444,23 +448,23 @@ static inline int r2l_chain_variant(int64_t N) {
     return coop_t < main_t ? R2L_VARIANT_COOP : R2L_VARIANT_MAIN;
 }
 
-// The bf16x3 training trio keeps its stash (save_x[0..n-1], save_t, gx[1..n], gt) in the chunked layout above; slot n of
-// save_x then holds y = x_n + x_0 row-major (all the tail gradient needs) and gx[0] stays row-major (head gradient).
+// The one-wave-per-tile training trios keep their stash (save_x[0..n-1], save_t, gx[1..n], gt) in a private layout: fp16
+// stage pieces (the default trio, r2l_f2.h) or the chunked fp32 layout above (bf16x3 trio); slot n of save_x then holds
+// y = x_n + x_0 row-major (all the tail gradient needs) and gx[0] stays row-major (head gradient).
 // Every other combination (cooperative chains, fp32 chains, the pre-embedded module-boundary path) is row-major throughout.
 static inline bool r2l_stash_chunked(int64_t N, bool pre_embedded) {
     return !pre_embedded && N > 0 && r2l_chain_variant(N) == R2L_VARIANT_MAIN && r2l_use_fwd3();
 }
 
-// bf16 products per fp32 product in the GRADIENT GEMMs of the bf16x3 trio (dX chain, dW body): 6 = fp32-accurate (default);
-// R2L_GRAD_TERMS=3 in the environment keeps the three largest (operands to 16 mantissa bits, product error ~2^-16: between
-// TF32 and fp32) at half the matrix work.  The forward always uses 6.
-static inline int r2l_grad_terms() {
-    const char* e = getenv("R2L_GRAD_TERMS");
-    return (e && e[0] == '3') ? 3 : 6;
+// The default TRAINING trio of one-wave-per-tile MSE-mode steps: fp16x2 forward (r2l_fwd2.hip) and dX chain (r2l_bwd2.hip)
+// stashing fp16 stage pieces, and the fp16 weight-gradient GEMMs on them (r2l_dw16.hip).  Any of R2L_NO_FWD3 / R2L_NO_FWD2 /
+// R2L_NO_BWD2 / R2L_NO_DW2 = 1 puts the whole step on the bf16x3 trio (r2l_fwd3 / r2l_bwd3 / r2l_dw_body3c, chunked fp32
+// stash) — the kernels the range guards fall back to.  (Forward-only launches look at R2L_NO_FWD2 alone.)
+static inline bool r2l_env_on(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] && e[0] != '0';
 }
-
-// dX chain of the trio on two-way fp16 splits (MSE mode; R2L_NO_BWD2=1 or R2L_GRAD_TERMS=3: bf16 kernels only)
-static inline bool r2l_use_bwd2() { return r2l_grad_terms() == 6 && !getenv("R2L_NO_BWD2"); }
+static inline bool r2l_use_trio16() { return r2l_use_fwd2() && !r2l_env_on("R2L_NO_BWD2") && !r2l_env_on("R2L_NO_DW2"); }
 
 // error plumbing shared by the C-ABI translation units
 extern "C" const char* r2l_last_error(void);

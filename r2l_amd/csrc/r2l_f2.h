@@ -53,6 +53,22 @@ __device__ __forceinline__ void f2_dma_piece_i(int i, u32x4 rsrc, unsigned voff,
 struct F2Split {
     f16x8 h, m;
 };
+
+// ---- fp16 stash of the training trio (r2l_fwd2<SAVE> / r2l_bwd2 -> r2l_dw16.hip) ------------------------------------------
+// What the weight-gradient GEMMs read of a layer input / output gradient is its fp16 `hi` part only (dW = G_hi^T A_hi, one
+// fp16 MFMA product per fp32 product: the rounding of both operands to 11 bits moves dW by ~5e-5 relative, the level at
+// which two fp32 evaluations of this 88-layer net differ).  The hi halves ARE the B operand of the chain's next
+// stage, so a chain stashes a stage's B operand as it stands: ONE 16-byte store per lane and stage, the 64 lanes writing one
+// contiguous KiB.  A slot of the buffers then holds, per 32-ray tile, 16 stage pieces of 1 KiB:
+//     byte  tile*16384 + kb*1024 + lane*16 + 2*s   <->   ray 32*tile + (lane & 31),
+//                                                        feature 16*kb + 8*(s >> 2) + 4*(lane >> 5) + (s & 3)
+// (half the bytes of the fp32 stash of the bf16x3 trio, which keeps the slot size: the range-guard fallback rewrites a slot
+// in that format).  Word R2L_STASH_FMT_WORD of save_x says which format the forward left behind (0: this one).
+#define R2L_H16_TILE_UNITS 1024  // 16-byte units per tile and slot
+struct F2Hst {                   // where this lane's 16 B of the NEXT stage's B operand go (on == false: no stash)
+    bool on;
+    u32x4* dst;
+};
 struct F2A4 {  // A operands (fp16 pairs) of four output tiles
     f16x8 h[4], m[4];
 };
@@ -70,6 +86,8 @@ struct F2Side {
     F3Dma dma;
     float& amax;  // running max |B value| of this lane (range guard: fp16 ends at 65504)
     F3Dma extra = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};  // one more 1 KiB piece, issued with step 5 (backward: mask tile)
+    F2Hst hst = F2Hst{false, nullptr};  // second half stage only: stash the assembled hi operand (step 4)
+    const unsigned* uh_first = nullptr;  // the first half stage's packed hi pairs (values 0-3 of the operand)
     float x[4];
     unsigned uh[2], um[2];  // packed fp16 pairs: values (0,1) and (2,3)
     static __device__ __forceinline__ unsigned pk(float a0, float a1) {
@@ -118,6 +136,9 @@ struct F2Side {
         } else if (i == 3) {
             um[0] = pk(x[0], x[1]);
             um[1] = pk(x[2], x[3]);
+        } else if (i == 4) {
+            // whole 128-byte lines, written once, read back milliseconds later by another kernel: non-temporal
+            if (hst.on) __builtin_nontemporal_store(u32x4{uh_first[0], uh_first[1], uh[0], uh[1]}, hst.dst);
         }
     }
 };
@@ -202,12 +223,13 @@ struct F2Pipe {
 template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
 __device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi,
                                          F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
-                                         F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u}) {
+                                         F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
+                                         F2Hst hst = F2Hst{false, nullptr}) {
     F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax, extra_a};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
     P.sync_next();
-    F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax, extra_b};
+    F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax, extra_b, hst, sa.uh};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {

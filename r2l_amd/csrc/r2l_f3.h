@@ -239,7 +239,9 @@ __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], Pipe& P, GLo glo
 }
 
 // gatherers of four B values
-template <bool RELU, bool STASH = false>
+// STASH: training launch (RELU: the block's ReLU mask bits are collected); STORE: the fp32 values go to the chunked stash
+// here (the bf16x3 trio; the fp16 trio stashes the assembled fp16 operand instead: r2l_f2.h F2Hst)
+template <bool RELU, bool STASH = false, bool STORE = STASH>
 struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile (tile T given for the stash address)
     const f32x16& frag;
     int c0;
@@ -252,7 +254,7 @@ struct F3Take4 {  // four consecutive fragment registers c0 .. c0+3 of one tile 
         // the B values ARE the layer input (x_b, relu(t_b)): the stash store rides along, one 16-byte piece per half stage
         // (unconditional when STASH: a data-dependent branch per piece would cut the half stage's schedule in two)
         // chunked layout: the 64 lanes of a piece write one contiguous KiB (whole 128-byte lines, written once: non-temporal)
-        if (STASH) r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
+        if (STORE) r2l_chunk_store(stash + R2L_CHUNK_PIECE * (4 * T + (c0 >> 2)), f32x4{v[0], v[1], v[2], v[3]});
         if (STASH && RELU) {  // relu'(t) for the backward: word = 2*word + [t > 0]  (v_cmp + v_addc per value)
             unsigned w = *mword;
 #pragma unroll

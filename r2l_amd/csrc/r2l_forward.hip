@@ -265,7 +265,8 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
     if (variant == R2L_VARIANT_COOP)
         return r2l_coop_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream, params, n_block, rgb, save_x,
                                 save_t, N, (hipStream_t)stream);
-    if (N > 0 && r2l_use_fwd2()) {
+    // (with the training stash: only as part of the default fp16 trio, whose stash format it writes)
+    if (N > 0 && (save_x != nullptr ? r2l_use_trio16() : r2l_use_fwd2())) {
         const float* w3 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
         const float* w2 = w3 + r2l_fwd3_stream_floats(n_block);
         const int rc = r2l_fwd2_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w2, params, n_block, rgb, save_x,

@@ -88,8 +88,8 @@ struct F2Args {
     const float* params;
     int n_block;
     float* rgb;
-    float* save_x;  // training: [(n_block+1)][Np][256] X_0 .. X_n and [n_block][Np][256] relu(hidden) (r2l_forward.hip), or
-    float* save_t;  //           nullptr
+    float* save_x;  // training: the stash slots of X_0 .. X_{n-1} / relu(hidden) as fp16 stage pieces (r2l_f2.h), slot n of
+    float* save_t;  //           save_x = X_n + X_0 row-major fp32; or nullptr
     int64_t N;
 };
 
@@ -234,30 +234,37 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
         }
 
     // ---- body -----------------------------------------------------------------------------------------------------------
-    // training (SAVE): the B values of every stage are the layer's input, so the stash (x_b for the first layer of a block,
-    // relu(t_b) for the second) is stored by the gatherers, two 16-byte pieces per stage (chunked layout: whole lines)
+    // training (SAVE): the B values of every stage are the layer's input (x_b for the first layer of a block, relu(t_b) for the
+    // second): their fp16 hi halves — the assembled B operand of the next stage — are the stash, ONE 16-byte store per lane and
+    // stage, a contiguous KiB per wave (r2l_f2.h F2Hst; r2l_dw16.hip reads it back)
     const int64_t Np = R2L_PAD_ROWS(a.N);
     // (rows of the padding rays of the last tile exist: Np rows per slot)
-    // chunked stash layout (r2l_common.h): lane base of the tile, pieces 1 KiB apart
-    float* sx = SAVE ? a.save_x + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
-    float* st = SAVE ? a.save_t + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
     const int64_t slot = R2L_TRIO_SLOT(Np);
+    u32x4* hx = SAVE ? reinterpret_cast<u32x4*>(a.save_x) + tile * R2L_H16_TILE_UNITS + lane : nullptr;
+    u32x4* ht = SAVE ? reinterpret_cast<u32x4*>(a.save_t) + tile * R2L_H16_TILE_UNITS + lane : nullptr;
+    const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
+        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
-        f2_stage<true, true, false>(t, P, F3Take4<false, SAVE>{x[0], 0, sx, 0}, F3Take4<false, SAVE>{x[0], 4, sx, 0});
+        f2_stage<true, true, false>(t, P, F3Take4<false, SAVE, false>{x[0], 0, nullptr, 0}, F3Take4<false, SAVE, false>{x[0], 4, nullptr, 0},
+                                    no_dma, no_dma, F2Hst{SAVE, hx});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f2_stage<false, false, false>(t, P, F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), sx, (kb + 1) >> 1},
-                                          F3Take4<false, SAVE>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, sx, (kb + 1) >> 1});
+            f2_stage<false, false, false>(t, P, F3Take4<false, SAVE, false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, (kb + 1) >> 1},
+                                          F3Take4<false, SAVE, false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, (kb + 1) >> 1},
+                                          no_dma, no_dma, F2Hst{SAVE, hx + 64 * (kb + 1)});
         f2_stage<false, false, true>(t, P, F3None{}, F3None{});
         // x += W2 relu(t) + b2   (training: the gatherers also shift [t > 0] into the block's four mask words)
         unsigned mw[4] = {0u, 0u, 0u, 0u};
-        f2_stage<true, false, false>(x, P, F3Take4<true, SAVE>{t[0], 0, st, 0, &mw[0]}, F3Take4<true, SAVE>{t[0], 4, st, 0, &mw[0]});
+        f2_stage<true, false, false>(x, P, F3Take4<true, SAVE, false>{t[0], 0, nullptr, 0, &mw[0]},
+                                     F3Take4<true, SAVE, false>{t[0], 4, nullptr, 0, &mw[0]}, no_dma, no_dma, F2Hst{SAVE, ht});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f2_stage<false, false, false>(x, P, F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), st, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
-                                          F3Take4<true, SAVE>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, st, (kb + 1) >> 1, &mw[(kb + 1) >> 2]});
+            f2_stage<false, false, false>(x, P, F3Take4<true, SAVE, false>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
+                                          F3Take4<true, SAVE, false>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
+                                          no_dma, no_dma, F2Hst{SAVE, ht + 64 * (kb + 1)});
         f2_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
         if (SAVE) {  // values were shifted in MSB-first: bit (T&1)*16 + c after the reversal
             u32x4 mv;
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
             *reinterpret_cast<u32x4*>(a.save_t + (int64_t)b * slot + R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) = mv;
         }
         if (SAVE) {
-            sx += slot;
-            st += slot;
+            hx += slot / 4;  // (slots are whole 16-byte units: Np * 264 floats, Np a multiple of 32)
+            ht += slot / 4;
         }
     }
     if (SAVE) {  // slot n: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)

@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     const int64_t Np = R2L_PAD_ROWS(a.N);
     // (rows of the padding rays of the last tile exist: Np rows per slot)
     // chunked stash layout (r2l_common.h): lane base of the tile, pieces 1 KiB apart
+    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: chunked fp32 (also when this is the fallback launch)
+        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 1u;
     float* sx = SAVE ? a.save_x + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
     float* st = SAVE ? a.save_t + r2l_chunk_lane(tile, lane & 31, h) : nullptr;
     const int64_t slot = R2L_TRIO_SLOT(Np);

@@ -141,8 +141,7 @@ extern "C" int r2l_variant_for(int64_t N) { return r2l_chain_variant(N); }
 extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
-    (void)with_stash;
-    if (v == R2L_VARIANT_MAIN && r2l_use_fwd2()) return 2;
+    if (v == R2L_VARIANT_MAIN && (with_stash ? r2l_use_trio16() : r2l_use_fwd2())) return 2;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return 3;
     return 32;
 }
@@ -151,7 +150,7 @@ extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
 extern "C" int r2l_backward_layout_for(int64_t N) {
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
-    if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return r2l_use_bwd2() ? 2 : 3;
+    if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return r2l_use_trio16() ? 2 : 3;
     return 32;
 }
 extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream) {

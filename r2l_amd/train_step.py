@@ -217,25 +217,27 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
 
     dt, step_ms = timed(train_step, steps, warm, distributed, device)
     achieved = n * flop_per_ray / (step_ms * 1e-3) / 1e12
-    # which matrix path the step's GEMM kernels take: one-wave-per-tile launches run forward, dX chain and dW GEMMs with
-    # fp32-accurate products on the bf16 MFMA (6 bf16 products per fp32 product: peak = bf16 dense / 6); the cooperative
-    # small-batch chains stay on the fp32 MFMA (only their dW GEMMs use the bf16 path)
+    # Which matrix path the step's GEMM kernels take, and the matrix-pipe bound that goes with it in ALGORITHMIC FLOP/s: a
+    # kernel that evaluates an fp32 product as p 16-bit MFMA products can at best reach (dense 16-bit MFMA peak) / p.
+    #   default trio (one wave per tile, > 4096 rays): forward 11.79 MFLOP/ray x 3 fp16 products, dX chain 11.27 x 3, dW body
+    #   11.27 x 1 (fp16 hi operands), head dW 0.52 on the fp32 MFMA (priced at 16: 2500/157.3)
+    #   bf16x3 trio: 6 products everywhere; cooperative small-batch chains: fp32 MFMA + bf16x3 dW
     fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")
     big = tr.lib.r2l_variant_for(int(n)) == 0
-    f16 = [not os.environ.get(k, "0").strip("0") for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2")]
-    terms3 = os.environ.get("R2L_GRAD_TERMS", "6").startswith("3")
+    off = [k for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2") if os.environ.get(k, "0").strip("0")]
     peak_fp32 = peak
     path = "fp32 MFMA"
-    if fwd3 and big:
-        if all(f16) and not terms3:
-            # every GEMM of the step as 3 fp16 MFMA products per fp32 product (two-way fp16 operand splits, ~2^-21)
-            peak = 2500.0 / 3.
-            path = "fp16x2: forward, dX chain and dW body with 3 fp16 products per fp32 product (range-guarded, bf16x3 fallback)"
-        else:
-            peak = 2500.0 / 6.
-            path = ("bf16x3 (6 bf16 products per fp32 product) for: %s; fp16x2 (3 products) for the rest"
-                    % ", ".join(nm for nm, on in zip(("forward", "dX chain", "dW body"), f16) if not on or terms3)) \
-                if any(f16) else "bf16x3: forward, dX chain and dW body with 6 bf16 products per fp32 product"
+    extra = {}
+    fwd_f, dx_f, dw_f, head_f = 11789824. - 516096., 2 * 86 * 256 * 256., 2 * 86 * 256 * 256., 2 * 1008 * 256.
+    if fwd3 and big and not off:
+        mfma_flops = 3 * (fwd_f + head_f) + 3 * dx_f + 1 * dw_f + (2500.0 / peak_fp32) * head_f
+        peak = 2500.0 * flop_per_ray / mfma_flops
+        path = ("fp16 trio: forward and dX chain with 3 fp16 MFMA products per fp32 product (two-way operand splits), dW body "
+                "with 1 (fp16 hi operands from the fp16 stash); range-guarded, bf16x3 trio behind it")
+        extra = {"peak_if_every_gemm_took_3_products": 2500.0 / 3., "frac_of_3_product_peak": achieved / (2500.0 / 3.)}
+    elif fwd3 and big:
+        peak = 2500.0 / 6.
+        path = "bf16x3 trio: forward, dX chain and dW body with 6 bf16 products per fp32 product (%s)" % ", ".join(off)
     elif fwd3:
         path = "fp32 MFMA chains + bf16x3 dW"
     return {"value": n * steps * world / dt, "unit": "rays/s", "steps": steps, "warmup": warm,
@@ -246,5 +248,5 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
                          "frac": achieved / peak, "peak_fp32_mfma": peak_fp32,
                          "frac_of_fp32_mfma_peak": achieved / peak_fp32,
                          "matrix_path": path,
-                         "flop_per_ray": flop_per_ray, "step_ms_device": step_ms},
+                         "flop_per_ray": flop_per_ray, "step_ms_device": step_ms, **extra},
             "final_loss": tr.loss_out[0].item()}

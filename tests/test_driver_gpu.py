@@ -101,7 +101,7 @@ def trained_student():
         idx = torch.randint(0, train.shape[0], (8192,), device="cuda", generator=g)
         b = train[idx]
         _, lo = tr.step(b[:, :3], b[:, 3:6], b[:, 6:], lr_schedule(it, 5e-4, 500, "0.0001,200"), perturb=1.)
-        losses.append(lo[0])
+        losses.append(lo[0].clone())  # loss_out is ONE device buffer the trainer rewrites every step
         if it == 150:
             psnr150 = held_psnr()
     losses = torch.stack(losses).cpu().numpy()

@@ -31,20 +31,23 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     the environment switches, and the caller-side buffer sizes that go with them."""
     from r2l_amd import _lib
     lib = _lib.load()
-    for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_GRAD_TERMS"):
+    for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
         monkeypatch.delenv(k, raising=False)
     # defaults: 16-ray cooperative kernels up to 4096 rays, one wave per tile (fp16x2, with the bf16x3 stream behind it) above
     assert lib.r2l_variant_for(4096) == 2 and lib.r2l_variant_for(4097) == 0 and lib.r2l_variant_for(160000) == 0
     assert lib.r2l_forward_layout_for(4096, 1) == 16
     assert lib.r2l_forward_layout_for(98304, 1) == 2 and lib.r2l_forward_layout_for(160000, 0) == 2
     assert lib.r2l_backward_layout_for(98304) == 2 and lib.r2l_backward_layout_for(4096) == 16
+    # any switch of the fp16 training trio puts the WHOLE step on the bf16x3 trio (one stash format per step); forward-only
+    # launches look at R2L_NO_FWD2 alone
+    for k in ("R2L_NO_BWD2", "R2L_NO_DW2"):
+        monkeypatch.setenv(k, "1")
+        assert lib.r2l_forward_layout_for(98304, 1) == 3 and lib.r2l_backward_layout_for(98304) == 3
+        assert lib.r2l_forward_layout_for(160000, 0) == 2
+        monkeypatch.delenv(k)
     monkeypatch.setenv("R2L_NO_FWD2", "1")
-    assert lib.r2l_forward_layout_for(98304, 1) == 3 and lib.r2l_backward_layout_for(98304) == 2
-    monkeypatch.setenv("R2L_NO_BWD2", "1")
-    assert lib.r2l_backward_layout_for(98304) == 3
-    monkeypatch.delenv("R2L_NO_BWD2")
-    monkeypatch.setenv("R2L_GRAD_TERMS", "3")
-    assert lib.r2l_backward_layout_for(98304) == 3
+    assert lib.r2l_forward_layout_for(98304, 1) == 3 and lib.r2l_backward_layout_for(98304) == 3
+    assert lib.r2l_forward_layout_for(160000, 0) == 3
     monkeypatch.setenv("R2L_NO_FWD3", "1")  # everything on the fp32 MFMA: the small-batch kernels win up to 20 480 rays again
     assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_backward_layout_for(98304) == 32
     assert lib.r2l_variant_for(20480) == 2 and lib.r2l_variant_for(24576) == 0

@@ -12,28 +12,22 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "main-bf16x3-fwd", "main-bf16x3-trio", "main-grad3", "main-f32mfma", "coop",
-                                      "coop16"])
+@pytest.fixture(autouse=True, params=["main", "main-bf16x3-trio", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
     """Every test runs under each kernel family of the training step:
-      main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip), fp16x2 dX chain (r2l_bwd2.hip) and
-                       the fp16 dW body GEMMs, each range-guarded with its bf16x3 kernel behind it
-      main-bf16x3-fwd  R2L_NO_FWD2=1: bf16x3 forward (r2l_fwd3.hip) in front of the default gradient kernels
-      main-bf16x3-trio R2L_NO_FWD2 = R2L_NO_BWD2 = R2L_NO_DW2 = 1: the whole step on six bf16 products per fp32 product —
-                       exactly the kernels the range guards fall back to
-      main-grad3       R2L_GRAD_TERMS=3: bf16x3 chains, 3-product bf16 gradient GEMMs (opt-in)
+      main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip) and dX chain (r2l_bwd2.hip) stashing
+                       fp16 stage pieces, fp16 weight-gradient GEMMs on them (r2l_dw16.hip); range-guarded, with the bf16x3
+                       kernels launched behind them
+      main-bf16x3-trio R2L_NO_FWD2 = R2L_NO_BWD2 = R2L_NO_DW2 = 1 (any one of them would do): the whole step on six bf16
+                       products per fp32 product and the chunked fp32 stash — exactly the kernels the guards fall back to
       main-f32mfma     R2L_NO_FWD3=1: everything on the exact-fp32 MFMA
       coop / coop16    the cooperative small-batch families."""
     name = request.param
     monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
-    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_GRAD_TERMS"):
+    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
         monkeypatch.delenv(k, raising=False)
     if name == "main-f32mfma":
         monkeypatch.setenv("R2L_NO_FWD3", "1")
-    if name == "main-grad3":
-        monkeypatch.setenv("R2L_GRAD_TERMS", "3")
-    if name == "main-bf16x3-fwd":
-        monkeypatch.setenv("R2L_NO_FWD2", "1")
     if name == "main-bf16x3-trio":
         for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
             monkeypatch.setenv(k, "1")
