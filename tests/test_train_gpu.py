@@ -99,7 +99,7 @@ def test_full_grads_vs_oracle(n, perturb):
         assert rel_err(grads[k], gref[k]) < 2e-3, (k, rel_err(grads[k], gref[k]))
 
 
-def test_three_adam_steps_vs_oracle():
+def test_three_adam_steps_vs_oracle(chain_variant):
     """3 fused steps (warm-up LR schedule, main.py:1181-1195) vs oracle autograd + Adam: losses and parameters."""
     from model.nerf_raybased import PointSampler
     from r2l_amd.train_step import R2LTrainer, lr_schedule
@@ -125,9 +125,22 @@ def test_three_adam_steps_vs_oracle():
         _, lo = tr.step(o.cuda(), d.cuda(), tgt.cuda(), lr)
         assert abs(lo[0].item() - loss.item()) < 2e-6, step
     new = m.state_dict()
+    travel = sum(lr_schedule(s, 5e-4, 500, "0.0001,200") for s in (1, 2, 3))  # how far Adam can move a weight in 3 steps
     for k in ref:
         # Adam's first steps move every weight by ~lr regardless of gradient size; compare on that scale
-        assert (new[k].cpu() - ref[k]).abs().max().item() < 2e-5, k
+        diff = (new[k].cpu() - ref[k]).abs()
+        if chain_variant == "main" and ".body." in k:
+            # default trio: the body's weight-gradient GEMMs take fp16-rounded operands (r2l_dw16.hip).  Each gradient entry
+            # is a sum over the rays whose rounding errors average out (per-tensor error ~1e-4 of its max here, 512 rays),
+            # but Adam normalises every entry by its own magnitude: the few entries whose true gradient nearly cancels
+            # (|g| below ~1e-3 of the tensor's typical entry) can change sign and travel the other way.  A CPU model of the
+            # rounding (fp32 chain, dW operands through .half()) reproduces this test's numbers: 1e-4 of the entries beyond
+            # 2e-5, the largest 1.8e-4, 99.7 % within 1e-6.  Bars: those three, with margin.
+            assert (diff > 2e-5).float().mean().item() < 5e-4, k
+            assert (diff > 1e-6).float().mean().item() < 2e-2, k
+            assert diff.max().item() < 2 * travel, k
+        else:
+            assert diff.max().item() < 2e-5, k
     # torch.optim.Adam-format state round trip
     osd = tr.optimizer_state_dict(lr)
     assert osd["state"][0]["exp_avg"].shape == sd["head.0.weight"].shape
