@@ -896,45 +896,6 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
 // columns; wave w of it owns columns kq*256 + w*64 .. +63 (two 32-column tiles) x all 256 output rows (8 tiles).
 // Lane (i, h) evaluates encoding column k = base + i (+32) for ray 2s+h: one sin or cos (or the identity) per tile.
 // =================================================================================================================
-struct R2LDwHeadArgs {
-    const float* rays_o;
-    const float* rays_d;
-    const float* t_rand;
-    const float* ztab;
-    const float* emb;  // [N,1008] given encoding (module-boundary path) or nullptr -> recompute from the rays
-    const float* gh;   // [N,256] = gx[0]
-    float* slab;       // [n_slices][256][1024] per-slice partial dW (plain stores, reduced in fixed order) or nullptr
-    float* grads;
-    int64_t N;
-    int64_t rays_per_wg;
-};
-
-// Per-lane description of one encoding column k (fixed for the whole kernel): which sample / axis it reads and what it
-// applies.  column k of PositionalEmbedder's output: coord c = k/21 (sample c/3, axis c%3), slot f = k%21
-// (f < 10: sin(2^f x), 10 <= f < 20: cos(2^(f-10) x), f == 20: x).
-struct PECol {
-    int smp, ax;
-    float scale;  // 2^freq (trig columns)
-    int kind;     // 0 sin, 1 cos, 2 identity, 3 padding (k >= 1008)
-};
-__device__ __forceinline__ PECol pe_col(int k) {
-    PECol c;
-    if (k >= R2L_IN) { c.smp = 0; c.ax = 0; c.scale = 0.f; c.kind = 3; return c; }
-    const int co = k / 21, f = k - 21 * co;
-    c.smp = co / 3;
-    c.ax = co - 3 * c.smp;
-    c.kind = f == 20 ? 2 : (f < 10 ? 0 : 1);
-    c.scale = f == 20 ? 1.f : (float)(1 << (f < 10 ? f : f - 10));
-    return c;
-}
-// value of the column for the point x = o + d*z of one ray
-__device__ __forceinline__ float pe_eval(const PECol& c, float x) {
-    float s, co;
-    r2l_sincos(x * c.scale, s, co);
-    const float t = c.kind == 0 ? s : co;
-    return c.kind == 2 ? x : (c.kind == 3 ? 0.f : t);
-}
-
 struct HeadStep {  // raw operands of one k-step (two rays), as loaded
     f32x4 g0, g1;
     float o0, d0, u0, o1, d1, u1;
@@ -944,6 +905,7 @@ struct HeadStep {  // raw operands of one k-step (two rays), as loaded
 // emit per-load branches, spills and vmcnt(0) drains).
 template <bool FROM_EMB, bool JITTER>
 __global__ __launch_bounds__(256, 1) void r2l_dw_head_kernel(const R2LDwHeadArgs a) {
+    if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;  // fallback behind r2l_dw_head16_kernel
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hh = lane >> 5, jl = lane & 31;
     const int kq = blockIdx.x & 3;
@@ -1331,6 +1293,17 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         if (slices > 1 && dw_slab != nullptr && slab_floats <= DW_HEAD_SLAB_MAX) a.slab = dw_slab;
         else a.slab = (slices > 1 && slab_floats <= gt_floats) ? gt : nullptr;
         const dim3 hg((unsigned)(slices * 4)), hb(256);
+        if (trio16 && emb == nullptr) {
+            // default trio: the same GEMM on the fp16 matrix pipe (r2l_dw_head16.hip); the fp32 kernel behind it runs only when
+            // the dX chain raised its status word (range guard / bf16x3 fallback step)
+            a.gscale = gscale;
+            a.unscale = 1.0f / gscale;
+            a.run_unless = bwd_status;
+            const int rc = r2l_dw_head16_launch(a, slices, stream);
+            if (rc) return rc;
+            a.run_unless = nullptr;
+            a.run_if = bwd_status;
+        }
         if (emb != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<true, false>), hg, hb, 0, stream, a);
         else if (t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<false, true>), hg, hb, 0, stream, a);
         else hipLaunchKernelGGL((r2l_dw_head_kernel<false, false>), hg, hb, 0, stream, a);

@@ -46,6 +46,54 @@ struct R2LDwArgs {
 #define DW_MAX_WGS 256
 #define DW_HEAD_SLAB_MAX ((int64_t)64 * R2L_W * 1024)  // head partials: up to 64 ray slices of [256][1024] at the slab start
 
+// ---- head weight gradient (r2l_backward.hip: fp32 MFMA; r2l_dw_head16.hip: fp16 MFMA of the default trio) ----------------------
+struct R2LDwHeadArgs {
+    const float* rays_o;
+    const float* rays_d;
+    const float* t_rand;
+    const float* ztab;
+    const float* emb;  // [N,1008] given encoding (module-boundary path) or nullptr -> recompute from the rays
+    const float* gh;   // [N,256] = gx[0]
+    float* slab;       // [n_slices][256][1024] per-slice partial dW (plain stores, reduced in fixed order) or nullptr
+    float* grads;
+    int64_t N;
+    int64_t rays_per_wg;
+    // default fp16 trio (r2l_dw_head16.hip): gh is multiplied by gscale (the dX chain's power-of-two scale) before it is rounded
+    // to fp16 and the result by unscale = 1 / gscale; run_unless / run_if: the dX chain's status word (the fp16 kernel returns
+    // at once when it is raised, the fp32 kernel launched behind it when it is not)
+    float gscale = 1.0f, unscale = 1.0f;
+    const unsigned* run_unless = nullptr;
+    const unsigned* run_if = nullptr;
+};
+
+// Per-lane description of one encoding column k (fixed for the whole kernel): which sample / axis it reads and what it
+// applies.  column k of PositionalEmbedder's output: coord c = k/21 (sample c/3, axis c%3), slot f = k%21
+// (f < 10: sin(2^f x), 10 <= f < 20: cos(2^(f-10) x), f == 20: x).
+struct PECol {
+    int smp, ax;
+    float scale;  // 2^freq (trig columns)
+    int kind;     // 0 sin, 1 cos, 2 identity, 3 padding (k >= 1008)
+};
+__device__ __forceinline__ PECol pe_col(int k) {
+    PECol c;
+    if (k >= R2L_IN) { c.smp = 0; c.ax = 0; c.scale = 0.f; c.kind = 3; return c; }
+    const int co = k / 21, f = k - 21 * co;
+    c.smp = co / 3;
+    c.ax = co - 3 * c.smp;
+    c.kind = f == 20 ? 2 : (f < 10 ? 0 : 1);
+    c.scale = f == 20 ? 1.f : (float)(1 << (f < 10 ? f : f - 10));
+    return c;
+}
+// value of the column for the point x = o + d*z of one ray
+__device__ __forceinline__ float pe_eval(const PECol& c, float x) {
+    float s, co;
+    r2l_sincos(x * c.scale, s, co);
+    const float t = c.kind == 0 ? s : co;
+    return c.kind == 2 ? x : (c.kind == 3 ? 0.f : t);
+}
+
+int r2l_dw_head16_launch(const R2LDwHeadArgs& a, int64_t slices, hipStream_t stream);
+
 // fp16 weight-gradient GEMMs of the default trio (r2l_dw16.hip): operands are the fp16 stage pieces the chains stashed
 // (r2l_f2.h).  run_unless: the dX chain's status word — when the step fell back to the bf16x3 chains (fp32 stash) this launch
 // raises *status and returns, and the bf16x3 weight-gradient kernel launched behind it (run_if = status) does the work.
