@@ -129,16 +129,21 @@ def test_three_adam_steps_vs_oracle(chain_variant):
     for k in ref:
         # Adam's first steps move every weight by ~lr regardless of gradient size; compare on that scale
         diff = (new[k].cpu() - ref[k]).abs()
-        if chain_variant == "main" and ".body." in k:
-            # default trio: the body's weight-gradient GEMMs take fp16-rounded operands (r2l_dw16.hip).  Each gradient entry
-            # is a sum over the rays whose rounding errors average out (per-tensor error ~1e-4 of its max here, 512 rays),
-            # but Adam normalises every entry by its own magnitude: the few entries whose true gradient nearly cancels
-            # (|g| below ~1e-3 of the tensor's typical entry) can change sign and travel the other way.  A CPU model of the
-            # rounding (fp32 chain, dW operands through .half()) reproduces this test's numbers: 1e-4 of the entries beyond
-            # 2e-5, the largest 1.8e-4, 99.7 % within 1e-6.  Bars: those three, with margin.
-            assert (diff > 2e-5).float().mean().item() < 5e-4, k
-            assert (diff > 1e-6).float().mean().item() < 2e-2, k
+        if chain_variant == "main" and not k.startswith("tail"):
+            # default trio: the weight-gradient GEMMs of head and body take fp16-rounded operands (r2l_dw16.hip,
+            # r2l_dw_head16.hip).  Each gradient entry is a sum over the rays whose rounding errors average out (per-tensor
+            # error ~1e-4 of its max here, 512 rays), but Adam normalises every entry by its own magnitude: the entries whose
+            # true gradient nearly cancels (|g| below ~1e-3 of the tensor's typical entry; many of the head's, whose encoding
+            # columns oscillate) can change sign and travel the other way.  A CPU model of the rounding (fp32 chain, dW
+            # operands through .half()) reproduces this test's numbers: body tensors 1e-4 of the entries beyond 2e-5 (head
+            # 1.1e-3), the largest 1.8e-4 (2.7e-4), 99.7 % (95 %) within 1e-6; update direction cosine >= 0.99995.
+            # Bars: those, with margin.
+            head = k.startswith("head")
+            assert (diff > 2e-5).float().mean().item() < (1e-2 if head else 5e-4), k
+            assert (diff > 1e-6).float().mean().item() < (0.15 if head else 2e-2), k
             assert diff.max().item() < 2 * travel, k
+            a, b = (new[k].cpu() - sd[k]).flatten().double(), (ref[k] - sd[k]).flatten().double()
+            assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.9998, k
         else:
             assert diff.max().item() < 2e-5, k
     # torch.optim.Adam-format state round trip
