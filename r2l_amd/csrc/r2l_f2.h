@@ -88,7 +88,6 @@ struct F2Side {
     F3Dma extra = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};  // one more 1 KiB piece, issued with step 5 (backward: mask tile)
     F2Hst hst = F2Hst{false, nullptr};  // second half stage only: stash the assembled hi operand (step 4)
     const unsigned* uh_first = nullptr;  // the first half stage's packed hi pairs (values 0-3 of the operand)
-    bool skip_loads = false;             // f2_stage_lo4: no A operands of tiles 4-7 to fetch
     float x[4];
     unsigned uh[2], um[2];  // packed fp16 pairs: values (0,1) and (2,3)
     static __device__ __forceinline__ unsigned pk(float a0, float a1) {
@@ -115,7 +114,7 @@ struct F2Side {
         }
     }
     __device__ __forceinline__ void step(int i) {
-        if (!skip_loads) loads(i);
+        loads(i);
         if (dma.on && i < 4) {
             if (i == 0) f2_dma_base(dma.la);
             f2_dma_piece_i(i, dma.rs, dma.voff, dma.so);
@@ -232,49 +231,6 @@ __device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo g
     P.sync_next();
     F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax, extra_b, hst, sa.uh};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (BIAS_NEXT) {
-        P.sb = P.ones;
-    } else {
-        P.sb.h = __builtin_bit_cast(f16x8, u32x4{sa.uh[0], sa.uh[1], sb2.uh[0], sb2.uh[1]});
-        P.sb.m = __builtin_bit_cast(f16x8, u32x4{sa.um[0], sa.um[1], sb2.um[0], sb2.um[1]});
-    }
-}
-
-// A stage of a layer with only 128 outputs (tiles 0-3; the NeRF teacher's views layer): 12 MFMAs instead of 24.  The A
-// operands of the stage are in `cur`; those of the NEXT stage's tiles 0-3 are fetched into `nxt` (the MFMAs behind the barrier
-// still read `cur`), so consecutive calls alternate the two register sets.  Side work: the first MFMA group carries the whole
-// gather + split of B values 0-3, the barrier follows, the other two groups carry the next stage's A operand reads, the DMA
-// request and B values 4-7.
-template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
-__device__ __forceinline__ void f2_stage_lo4(f32x16 (&acc)[R2L_NT], F2Pipe& P, F2A4& cur, F2A4& nxt, GLo glo, GHi ghi) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const F3Dma none{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
-    F2Side<BIAS_K, GLo> sa{nxt, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax, none, F2Hst{false, nullptr}, nullptr, true};
-    if (BIAS_K) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h[t], P.sb.h, ZERO_K ? zero : acc[t], 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.m[t], P.sb.h, ZERO_K ? zero : acc[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sa.step(i);
-    __builtin_amdgcn_sched_barrier(0);
-    P.sync_next();
-    F2Side<BIAS_NEXT, GHi> sb2{nxt, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax};
-    if (BIAS_K) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sb2.step(i);
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h[t], P.sb.m, acc[t], 0, 0, 0);
-        sb2.step(0); sb2.step(1); sb2.step(2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.h[t], P.sb.h, acc[t], 0, 0, 0);
-        sb2.step(3); sb2.step(4); sb2.step(5);
-    }
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {
         P.sb = P.ones;

@@ -295,23 +295,15 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
     }
 
     // ---- views layer: v[128] = Wv [feature, dir-embedding] + bv in tiles 0-3 of t (ReLU applied by the rgb head) ---------
-    // 128 outputs = four tiles: half stages (f2_stage_lo4: 12 MFMAs each instead of 24; the A operands of consecutive stages
-    // alternate between the two register sets) — 19 of the kernel's 164 stages
     typedef F3Take4<false> Id4;
-    f2_stage_lo4<true, true, false>(t, P, P.a1, P.a2, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 4, nullptr, 0});
+    f2_stage<true, true, false>(t, P, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 4, nullptr, 0});
 #pragma unroll
-    for (int kb = 0; kb < 15; ++kb) {
-        if (kb & 1)
-            f2_stage_lo4<false, false, false>(t, P, P.a1, P.a2, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
-                                              Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
-        else
-            f2_stage_lo4<false, false, false>(t, P, P.a2, P.a1, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
-                                              Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
-    }
-    // (stage i of the layer reads its A operands from a1 when i is even: bias = 0, feature blocks 1 .. 16, direction 17, 18)
-    f2_stage_lo4<false, false, false>(t, P, P.a1, P.a2, Dir4{vd, h, 0}, Dir4{vd, h, 4});
-    f2_stage_lo4<false, false, false>(t, P, P.a2, P.a1, Dir4{vd, h, 8}, Dir4{vd, h, 12});
-    f2_stage_lo4<false, false, true>(t, P, P.a1, P.a2, F3None{}, F3None{});  // next: stream padding
+    for (int kb = 0; kb < 15; ++kb)
+        f2_stage<false, false, false>(t, P, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
+                                      Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
+    f2_stage<false, false, false>(t, P, Dir4{vd, h, 0}, Dir4{vd, h, 4});
+    f2_stage<false, false, false>(t, P, Dir4{vd, h, 8}, Dir4{vd, h, 12});
+    f2_stage<false, false, true>(t, P, F3None{}, F3None{});  // next: stream padding
 
     // rgb = Wrgb relu(v) + b
     float acc3[3] = {0.f, 0.f, 0.f};
