@@ -1181,7 +1181,14 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         else
             n_cu_cached = 256;
     }
-    const int n_cu = n_cu_cached;
+    // Data-parallel hosts overlap the gradient all-reduce with the weight-gradient stages (r2l_backward_part).  Those kernels
+    // are persistent workgroups that take every register of their CU, so a collective launched beside them would wait for
+    // a whole stage to finish: R2L_RESERVE_CUS=n (set by the host when world_size > 1; r2l_amd/train_step.py uses 8) keeps n
+    // CUs out of the weight-gradient launches for the RCCL kernels.  Default 0.
+    int reserve = 0;
+    if (const char* e = getenv("R2L_RESERVE_CUS")) reserve = atoi(e);
+    if (reserve < 0 || reserve > n_cu_cached / 2) reserve = 0;
+    const int n_cu = n_cu_cached - reserve;
     // 1. dX chain
     const int variant = r2l_chain_variant(N);
     // the bf16x3 trio (r2l_fwd3 wrote the stash): chunked stash layout, see r2l_common.h

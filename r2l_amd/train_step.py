@@ -40,6 +40,10 @@ class R2LTrainer:
         # kernels of the next bucket run; R2L_AR_BUCKETS=0 selects one blocking all-reduce after the whole backward
         self.n_buckets = int(os.environ.get("R2L_AR_BUCKETS", "4"))
         self.force_staged = False  # tests: run the staged backward on one GPU (nothing is submitted at world == 1)
+        if self.reducer.world() > 1 and self.n_buckets > 0:
+            # the weight-gradient kernels are persistent workgroups that fill every CU: leave a few to the RCCL kernels that
+            # run beside them (r2l_backward_part reads this per call)
+            os.environ.setdefault("R2L_RESERVE_CUS", "8")
         self.step_count = 0
         self.cap = 0
         self.dw_slab = None
