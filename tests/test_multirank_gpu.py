@@ -20,7 +20,7 @@ from oracle import r2l_oracle as O
 from tests.test_forward_gpu import build_model
 from model.nerf_raybased import PointSampler
 from r2l_amd.train_step import R2LTrainer, lr_schedule
-from r2l_amd.dist_utils import parameters_in_sync
+from r2l_amd.dist_utils import bucket_plan, parameters_in_sync
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
@@ -50,7 +50,7 @@ for step in (1, 2, 3):
     for k in ref:
         ref[k], mo[k], vo[k] = O.adam_step(ref[k], gr[k], mo[k], vo[k], step, lr)
     tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda())
-    assert tr.reducer.pending() == 5                    # 4 body buckets + the head, in flight until Adam needs them
+    assert tr.reducer.pending() == len(bucket_plan(nb, tr.n_buckets)) == 4   # 3 body buckets (one per block) + the head, in flight until Adam needs them
     tr.allreduce_grads()
     assert tr.reducer.pending() == 0
     tr.adam(lr)
