@@ -85,5 +85,5 @@ def test_two_ranks_train_like_one_process(tmp_path, variant):
                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count(" ok: ") == 2
+    assert r.stdout.count("ok: max |param") == 2  # (the two ranks' lines may interleave)
     print(r.stdout[-400:])
