@@ -8,21 +8,48 @@
 // takes the place of eight v_mfma_f32_32x32x2_f32 — the same argument as r2l_dw16.hip: a reduction over ~10^5 rays of
 // independently rounded products.  The fp32 kernel took 0.71 ms of an 8.3 ms step (46 % of the fp32 MFMA peak).
 //
-// Workgroup (kq, slice): kq selects 256 encoding columns; wave w owns columns kq*256 + 64 w .. +63 (two 32-column tiles) x all
-// 256 output rows (eight 32-row tiles): 16 accumulator tiles.  One k-step = 16 rays: lane (m, kg) supplies, for rays 8 kg .. 8 kg + 7
-// of the step, Gh[ray][32 e + m] (A operands, e = 0..7: coalesced 128-byte rows) and PE[ray][column m of its two tiles] (B
-// operands: 16 sin / cos / identity evaluations).  This kernel is VALU-bound (the encoding), not matrix-bound.  Rows past the end of a slice are
-// out-of-range buffer loads (zero fill): no tails, no predicates.  Per-slice partials go to the slab and are added in slice
-// order by r2l_head_reduce_kernel, like the fp32 kernel's.
+// Workgroup (kq, slice); wave w of it owns 32 column PAIRS x all 256 output rows (eight 32-row tiles): 16 accumulator tiles.
+// A pair is (sin, cos) of one frequency of one point coordinate — one r2l_sincos evaluation feeds both of the lane's B
+// operands — or two identity columns (pairs 480 .. 503), or padding (504 .. 511): pair P = 128 kq + 32 w + m, tile 0 holds
+// the pair's first column, tile 1 its second.  One k-step = 16 rays: lane (m, kg) supplies, for rays 8 kg .. 8 kg + 7 of the
+// step, Gh[ray][32 e + m] (A operands, e = 0..7: coalesced 128-byte rows) and its pair's two encoding values (B operands).
+// The kernel is VALU-bound (the encoding), not matrix-bound.  Rows past the end of a slice are out-of-range buffer loads
+// (zero fill): no tails, no predicates.  Per-slice partials go to the slab and are added in slice order by
+// r2l_head_reduce_kernel, like the fp32 kernel's.
 #include "r2l_f2.h"
 #include "r2l_dw.h"
 
 struct Head16G {  // gradient rows of one k-step as loaded: [tile e][ray i of this lane's k half]
     float g[8][8];
 };
-struct Head16Rays {  // ray data of one k-step for this lane's two encoding columns
-    float o0[8], d0[8], u0[8], o1[8], d1[8], u1[8];
+struct Head16Rays {  // ray data of one k-step for this lane's column pair: coordinate A (and B: identity pairs only)
+    float oa[8], da[8], ua[8], ob[8], db[8], ub[8];
 };
+// the column pair of a lane: encoding columns ka / kb (-1: padding), the point coordinate(s) they read, the frequency
+struct Head16Pair {
+    int ka, kb;        // columns of head.0.weight (PositionalEmbedder order: 21 per coordinate: 10 sin, 10 cos, x)
+    int smp_a, ax_a;   // coordinate of ka (and of kb for a trig pair)
+    int smp_b, ax_b;   // coordinate of kb for an identity pair
+    float scale;       // 2^f (trig pairs)
+    bool trig;
+};
+__device__ __forceinline__ Head16Pair head16_pair(int P) {
+    Head16Pair c;
+    if (P < 480) {
+        const int co = P / 10, f = P - 10 * co;
+        c.ka = 21 * co + f; c.kb = 21 * co + 10 + f;
+        c.smp_a = c.smp_b = co / 3; c.ax_a = c.ax_b = co % 3;
+        c.scale = (float)(1 << f); c.trig = true;
+    } else {
+        const int i = P - 480, ca = 2 * i, cb = 2 * i + 1;  // 48 identity columns = 24 pairs; 504 ..: padding
+        const bool live = i < 24;
+        c.ka = live ? 21 * ca + 20 : -1; c.kb = live ? 21 * cb + 20 : -1;
+        c.smp_a = live ? ca / 3 : 0; c.ax_a = live ? ca % 3 : 0;
+        c.smp_b = live ? cb / 3 : 0; c.ax_b = live ? cb % 3 : 0;
+        c.scale = 1.f; c.trig = false;
+    }
+    return c;
+}
 
 typedef __amdgpu_buffer_rsrc_t h16_rsrc_t;
 __device__ __forceinline__ float h16_load(h16_rsrc_t rs, unsigned voff, unsigned imm) {
@@ -46,10 +73,10 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     if (r1 > a.N) r1 = a.N;
     if (r0 >= r1) return;
     const int nrays = (int)(r1 - r0);
-    const int kbase = kq * 256 + wave * 64;
-    const PECol c0 = pe_col(kbase + m), c1 = pe_col(kbase + 32 + m);
-    const float zl0 = a.ztab[c0.smp], zs0 = JITTER ? a.ztab[16 + c0.smp] : 0.f;
-    const float zl1 = a.ztab[c1.smp], zs1 = JITTER ? a.ztab[16 + c1.smp] : 0.f;
+    const Head16Pair pc = head16_pair(kq * 128 + wave * 32 + m);
+    const bool trig_wave = kq * 128 + wave * 32 + 31 < 480;  // wave-uniform: every lane of this wave holds a (sin, cos) pair
+    const float zla = a.ztab[pc.smp_a], zsa = JITTER ? a.ztab[16 + pc.smp_a] : 0.f;
+    const float zlb = a.ztab[pc.smp_b], zsb = JITTER ? a.ztab[16 + pc.smp_b] : 0.f;
 
     f32x16 acc[8][2];
 #pragma unroll
@@ -67,8 +94,8 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     const h16_rsrc_t drs = h16_rsrc(a.rays_d + r0 * 3, (unsigned)nrays * 12u);
     const h16_rsrc_t urs = h16_rsrc(JITTER ? a.t_rand + r0 * 16 : a.rays_o, JITTER ? (unsigned)nrays * 64u : 0u);
     unsigned vg = (unsigned)((8 * kg * R2L_W + m) * 4);          // Gh[8kg + i][32 e + m]: + i*1024 + e*128
-    unsigned vp0 = (unsigned)((8 * kg * 3 + c0.ax) * 4), vp1 = (unsigned)((8 * kg * 3 + c1.ax) * 4);     // + i*12
-    unsigned vu0 = (unsigned)((8 * kg * 16 + c0.smp) * 4), vu1 = (unsigned)((8 * kg * 16 + c1.smp) * 4);  // + i*64
+    unsigned vp0 = (unsigned)((8 * kg * 3 + pc.ax_a) * 4), vp1 = (unsigned)((8 * kg * 3 + pc.ax_b) * 4);     // + i*12
+    unsigned vu0 = (unsigned)((8 * kg * 16 + pc.smp_a) * 4), vu1 = (unsigned)((8 * kg * 16 + pc.smp_b) * 4);  // + i*64
     const int nsteps = (nrays + 15) / 16;
 
     // the k-step the offsets point at, then advance them by 16 rays
@@ -84,15 +111,15 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     auto ld_rays = [&](Head16Rays& v) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v.o0[i] = h16_load(ors, vp0, (unsigned)i * 12u);
-            v.d0[i] = h16_load(drs, vp0, (unsigned)i * 12u);
-            v.o1[i] = h16_load(ors, vp1, (unsigned)i * 12u);
-            v.d1[i] = h16_load(drs, vp1, (unsigned)i * 12u);
-            if (JITTER) {
-                v.u0[i] = h16_load(urs, vu0, (unsigned)i * 64u);
-                v.u1[i] = h16_load(urs, vu1, (unsigned)i * 64u);
+            v.oa[i] = h16_load(ors, vp0, (unsigned)i * 12u);
+            v.da[i] = h16_load(drs, vp0, (unsigned)i * 12u);
+            v.ua[i] = JITTER ? h16_load(urs, vu0, (unsigned)i * 64u) : 0.f;
+            if (!trig_wave) {  // identity pairs read a second coordinate (a (sin, cos) pair shares one)
+                v.ob[i] = h16_load(ors, vp1, (unsigned)i * 12u);
+                v.db[i] = h16_load(drs, vp1, (unsigned)i * 12u);
+                v.ub[i] = JITTER ? h16_load(urs, vu1, (unsigned)i * 64u) : 0.f;
             } else {
-                v.u0[i] = v.u1[i] = 0.f;
+                v.ob[i] = v.db[i] = v.ub[i] = 0.f;
             }
         }
         vp0 += 16u * 12u; vp1 += 16u * 12u;
@@ -119,14 +146,20 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
         __builtin_amdgcn_sched_barrier(0);
         ld_g(rg);  // (one step past the end: every load out of range, zeros)
         __builtin_amdgcn_sched_barrier(0);
-        // B operands: the two encoding columns of this lane for its 8 rays (point = fl(o + fl(d*z)), as the forward)
+        // B operands: the lane's column pair for its 8 rays (point = fl(o + fl(d*z)), as the forward)
         float p0[8], p1[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float z0 = JITTER ? zl0 + zs0 * rr.u0[i] : zl0;
-            const float z1 = JITTER ? zl1 + zs1 * rr.u1[i] : zl1;
-            p0[i] = pe_eval(c0, rr.o0[i] + rr.d0[i] * z0);
-            p1[i] = pe_eval(c1, rr.o1[i] + rr.d1[i] * z1);
+            const float xa = rr.oa[i] + rr.da[i] * (JITTER ? zla + zsa * rr.ua[i] : zla);
+            if (trig_wave) {
+                r2l_sincos(xa * pc.scale, p0[i], p1[i]);
+            } else {
+                const float xb = rr.ob[i] + rr.db[i] * (JITTER ? zlb + zsb * rr.ub[i] : zlb);
+                float sn, cs;
+                r2l_sincos(xa * pc.scale, sn, cs);  // (pairs 480 .. 511, one wave: identity columns and padding; pc.trig is false)
+                p0[i] = pc.trig ? sn : (pc.ka >= 0 ? xa : 0.f);
+                p1[i] = pc.trig ? cs : (pc.kb >= 0 ? xb : 0.f);
+            }
         }
         const f16x8 b0 = __builtin_bit_cast(f16x8, u32x4{pk(p0[0], p0[1]), pk(p0[2], p0[3]), pk(p0[4], p0[5]), pk(p0[6], p0[7])});
         const f16x8 b1 = __builtin_bit_cast(f16x8, u32x4{pk(p1[0], p1[1]), pk(p1[2], p1[3]), pk(p1[4], p1[5]), pk(p1[6], p1[7])});
@@ -139,12 +172,12 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
             acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[e], b1, acc[e][1], 0, 0, 0);
         }
     }
-    // flush: D row 8 (c>>2) + 4 kg + (c&3) of tile e -> output row o = 32 e + that; column k = kbase + 32 ei + m
+    // flush: D row 8 (c>>2) + 4 kg + (c&3) of tile e -> output row o = 32 e + that; column = the pair's ka (tile 0) / kb (tile 1)
     float* sl = a.slab ? a.slab + slice * (int64_t)(R2L_W * 1024) : nullptr;
 #pragma unroll
     for (int ei = 0; ei < 2; ++ei) {
-        const int k = kbase + ei * 32 + m;
-        if (k >= R2L_IN) continue;  // padding columns 1008 .. 1023
+        const int k = ei == 0 ? pc.ka : pc.kb;  // the real column of this lane's tile-ei values
+        if (k < 0) continue;                    // padding pairs
         if (sl) {
             float* p = sl + (4 * kg) * 1024 + k;
 #pragma unroll
