@@ -659,6 +659,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
     __shared__ __attribute__((aligned(16))) unsigned char img[2][DW3C_BUF_BYTES];
     static_assert(!F16 || TERMS == 3, "the fp16 variant is the 3-product scheme");
     if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
+    const float unscale = a.scale_dev != nullptr ? a.scale_dev[1] : a.unscale;
     float amax = 0.f;  // F16: largest |operand value| this lane converted
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * a.unscale;
+                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * unscale;
                             acc[eo][ei][c] = 0.f;
                         }
             } else {
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * a.unscale);
+                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * unscale);
                             acc[eo][ei][c] = 0.f;
                         }
             }
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                 for (int m = 2; m <= 16; m <<= 1)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], m);
-                v *= a.unscale;
+                v *= unscale;
                 if (lj == 0) {
                     const int f = 8 * (8 * wave + 2 * k + lcc) + 4 * lhf;
                     if (sl != nullptr) *reinterpret_cast<f32x4*>(sl + R2L_W * R2L_W + f) = v;
@@ -1132,6 +1133,31 @@ __global__ __launch_bounds__(256) void r2l_tail_reduce_kernel(const float* __res
     }
 }
 
+// Generic mode of the fp16 trio: the caller's dL/drgb has no known scale, so the power of two that puts the dX chain into
+// fp16's range is chosen on the device: out = {gscale, 1 / gscale}, gscale = 2^(8 - e) for max |drgb| = m * 2^e — the rule
+// r2l_backward_part applies on the host to the MSE gradient scale.  One workgroup (generic mode is not the training loop's).
+__global__ __launch_bounds__(1024) void r2l_gscale_kernel(const float* __restrict__ drgb, int64_t n, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(drgb[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float g = 1.0f;
+        if (red[0] > 0.f && red[0] < 3.0e38f) {
+            int e = 0;
+            (void)frexpf(red[0], &e);
+            g = ldexpf(1.0f, 8 - e);
+        }
+        out[0] = g;
+        out[1] = 1.0f / g;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
@@ -1202,17 +1228,16 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         (void)frexpf(grad_scale, &e);
         gscale = ldexpf(1.0f, 8 - e);
     }
-    // the default trio of one-wave-per-tile MSE-mode steps: fp16 chains + fp16 weight-gradient GEMMs on fp16 stage pieces
-    const bool trio16 = split && target != nullptr && r2l_use_trio16();
-    if (split && target == nullptr && r2l_use_trio16()) {
-        r2l_set_error_msg("r2l_backward: generic mode (drgb) after r2l_forward_rays needs the fp32 stash of the bf16x3 trio: set "
-                          "R2L_NO_DW2=1 around both calls (MSE mode and the pre-embedded path are unaffected)");
-        return (int)hipErrorInvalidValue;
-    }
+    // the default trio of one-wave-per-tile steps: fp16 chains + fp16 weight-gradient GEMMs on fp16 stage pieces (the forward
+    // of such a step wrote that stash: r2l_forward_rays decides by the same rule)
+    const bool trio16 = split && r2l_use_trio16();
     const float* w3 = wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
     const float* w2 = w3 + r2l_bwd3_stream_floats(n_block);
     // raised by r2l_bwd2_kernel when this step has to run on the bf16x3 kernels (range guard / the forward fell back)
     unsigned* bwd_status = reinterpret_cast<unsigned*>(const_cast<float*>(w2) + r2l_bwd2_status_offset(n_block));
+    // generic mode (dL/drgb from the caller, no known scale): {gscale, 1 / gscale} are chosen on the device from max |drgb| and
+    // live in words 4, 5 of the status area; every kernel of the step reads them there
+    const float* scale_dev = (trio16 && target == nullptr) ? reinterpret_cast<const float*>(bwd_status + 4) : nullptr;
     if (!(parts & R2L_BWD_CHAIN)) {
     } else if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
@@ -1229,12 +1254,16 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         // guard, or the forward already fell back and left an fp32 stash); otherwise the bf16x3 chain (r2l_bwd3.hip)
         if (trio16) {
             R2L_CHECK(hipMemsetAsync(bwd_status, 0, 64, stream));
+            if (scale_dev != nullptr) {
+                hipLaunchKernelGGL(r2l_gscale_kernel, dim3(1), dim3(1024), 0, stream, drgb, 3 * N, const_cast<float*>(scale_dev));
+                R2L_CHECK(hipGetLastError());
+            }
             const int rc2 = r2l_bwd2_backward(rgb, target, drgb, save_x, save_t, w2, params, n_block, grad_scale, dpre, gx, gt,
-                                              sqerr_partial, N, stream, gscale, bwd_status);
+                                              sqerr_partial, N, stream, gscale, bwd_status, scale_dev);
             if (rc2) return rc2;
         }
         const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t, w3, params, n_block, grad_scale, dpre, gx, gt,
-                                         sqerr_partial, N, stream, gscale, trio16 ? bwd_status : nullptr);
+                                         sqerr_partial, N, stream, gscale, trio16 ? bwd_status : nullptr, scale_dev);
         if (rc) return rc;
     } else {
         R2LBwdArgs a{};
@@ -1262,6 +1291,7 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         // (r2l_dw_body3c), or per wave from the row-major stash of the other chains (R2L_NO_FWD3: fp32 MFMA)
         // chunked stash: the gradient operands carry the chain's power-of-two scale
         if (split) a.unscale = 1.0f / gscale;
+        a.scale_dev = scale_dev;
         // default trio: one fp16 product per fp32 product on the fp16 stage pieces the chains stashed (r2l_dw16.hip); when the
         // dX chain raised its status word (this step fell back to the bf16x3 chains and their fp32 stash) it returns at once
         // and the bf16x3 kernel behind it does the work
@@ -1305,6 +1335,7 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
             // the dX chain raised its status word (range guard / bf16x3 fallback step)
             a.gscale = gscale;
             a.unscale = 1.0f / gscale;
+            a.scale_dev = scale_dev;
             a.run_unless = bwd_status;
             const int rc = r2l_dw_head16_launch(a, slices, stream);
             if (rc) return rc;

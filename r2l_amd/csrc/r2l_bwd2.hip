@@ -57,6 +57,7 @@ struct B2Args {
     int n_block;
     float grad_scale;
     float gscale, ginv;  // the chain runs on gscale * g (a power of two; what it stashes is scaled), gx[0] is scaled back
+    const float* scale_dev;  // generic mode: {gscale, 1 / gscale} chosen on the device from max |drgb| (r2l_gscale_kernel), or nullptr
     unsigned* status;    // range guard: raised when a chain value leaves fp16's safe range (the bf16x3 kernel then redoes it)
     const unsigned* fmt; // stash format word of the forward (r2l_common.h): != 0 -> chunked fp32 stash (the forward fell back to
                          // the bf16x3 kernel): this launch raises *status and leaves the work to the bf16x3 chain as well
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
         return;
     }
+    const float gscale = a.scale_dev != nullptr ? a.scale_dev[0] : a.gscale;
+    const float ginv = a.scale_dev != nullptr ? a.scale_dev[1] : a.ginv;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // a wave whose tile lies past the end recomputes the last live tile (identical values to identical addresses): nothing in
@@ -149,9 +152,9 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
                 for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = wv[0][j] * (dp[0] * a.gscale);
-                    v = __builtin_fmaf(wv[1][j], dp[1] * a.gscale, v);
-                    v = __builtin_fmaf(wv[2][j], dp[2] * a.gscale, v);
+                    float v = wv[0][j] * (dp[0] * gscale);
+                    v = __builtin_fmaf(wv[1][j], dp[1] * gscale, v);
+                    v = __builtin_fmaf(wv[2][j], dp[2] * gscale, v);
                     g[T][4 * q + j] = v;
                     dy[T][4 * q + j] = v;
                 }
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = 8 * rr + 4 * q2 + j;
-                        ov[j] = (float)xv[4 * q2 + j] > 0.f ? (g[T][c] + dy[T][c]) * a.ginv : 0.f;
+                        ov[j] = (float)xv[4 * q2 + j] > 0.f ? (g[T][c] + dy[T][c]) * ginv : 0.f;
                     }
                     *reinterpret_cast<f32x4*>(o + 32 * T + 8 * (2 * rr + q2)) = ov;
                 }
@@ -270,9 +273,11 @@ int r2l_bwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t
 
 int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status) {
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
+                      const float* scale_dev) {
     B2Args a{};
     a.status = status;
+    a.scale_dev = scale_dev;
     a.fmt = reinterpret_cast<const unsigned*>(save_x) + R2L_STASH_FMT_WORD(n_block, R2L_PAD_ROWS(N));
     a.gscale = gscale; a.ginv = 1.0f / gscale;
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;

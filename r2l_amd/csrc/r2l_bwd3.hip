@@ -67,6 +67,7 @@ struct B3Args {
     int n_block;
     float grad_scale;
     float gscale, ginv;  // the chain runs on gscale * g (a power of two; what it stashes is scaled), gx[0] is scaled back
+    const float* scale_dev;  // {gscale, 1 / gscale} chosen on the device (generic mode behind the fp16 chain), or nullptr
     const unsigned* run_if;  // nullptr, or: return at once while this word is 0 (range-guard fallback of r2l_bwd2.hip)
     float* dpre;
     float* gx;
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[B3_NBUF][F3_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
     if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
+    const float gscale = a.scale_dev != nullptr ? a.scale_dev[0] : a.gscale;
+    const float ginv = a.scale_dev != nullptr ? a.scale_dev[1] : a.ginv;
 
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -158,9 +161,9 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
                 for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = wv[0][j] * (dp[0] * a.gscale);
-                    v = __builtin_fmaf(wv[1][j], dp[1] * a.gscale, v);
-                    v = __builtin_fmaf(wv[2][j], dp[2] * a.gscale, v);
+                    float v = wv[0][j] * (dp[0] * gscale);
+                    v = __builtin_fmaf(wv[1][j], dp[1] * gscale, v);
+                    v = __builtin_fmaf(wv[2][j], dp[2] * gscale, v);
                     g[T][4 * q + j] = v;
                     dy[T][4 * q + j] = v;
                 }
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(r + R2L_CHUNK_PIECE * (4 * T + q));
                 f32x4 ov;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? (g[T][4 * q + j] + dy[T][4 * q + j]) * a.ginv : 0.f;
+                for (int j = 0; j < 4; ++j) ov[j] = xv[j] > 0.f ? (g[T][4 * q + j] + dy[T][4 * q + j]) * ginv : 0.f;
                 *reinterpret_cast<f32x4*>(o + 32 * T + 8 * q) = ov;
             }
     }
@@ -266,10 +269,12 @@ int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t
 
 int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, const unsigned* run_if) {
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, const unsigned* run_if,
+                      const float* scale_dev) {
     B3Args a{};
     a.run_if = run_if;
     a.gscale = gscale; a.ginv = 1.0f / gscale;
+    a.scale_dev = scale_dev;
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;

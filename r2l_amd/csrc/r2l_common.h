@@ -395,12 +395,13 @@ int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t
 int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale = 1.0f,
-                      const unsigned* run_if = nullptr);
+                      const unsigned* run_if = nullptr, const float* scale_dev = nullptr);
 // the same chain on two-way fp16 splits (r2l_bwd2.hip); status: range-guard word (behind the bwd2 stream region)
 int r2l_bwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream);
 int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status);
+                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
+                      const float* scale_dev = nullptr);
 // forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
 // kernel (R2L_NO_FWD3=1: fp32 MFMA)
 static inline bool r2l_use_fwd3() {

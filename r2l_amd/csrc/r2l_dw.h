@@ -36,6 +36,7 @@ struct R2LDwArgs {
     float* slab;  // [wgs][2][DW_SLAB_FLOATS] per-workgroup partial (dW, db) of the <= 2 layers its range touches, or
                   // nullptr -> fp32 atomics straight into grads
     float unscale = 1.0f;  // the gradient operands carry a power-of-two scale (r2l_bwd3): dW, db are multiplied by its inverse
+    const float* scale_dev = nullptr;  // generic mode of the fp16 trio: {gscale, 1 / gscale} chosen on the device; overrides unscale
     // range guard of the fp16 variant (r2l_dw_body3c_kernel<3, true>): it raises *status when an operand value leaves fp16's
     // safe range; the bf16 variant launched behind it with run_if = status then redoes the launch (else returns at once)
     unsigned* status = nullptr;
@@ -62,6 +63,7 @@ struct R2LDwHeadArgs {
     // to fp16 and the result by unscale = 1 / gscale; run_unless / run_if: the dX chain's status word (the fp16 kernel returns
     // at once when it is raised, the fp32 kernel launched behind it when it is not)
     float gscale = 1.0f, unscale = 1.0f;
+    const float* scale_dev = nullptr;  // {gscale, 1 / gscale} on the device (generic mode); overrides the two above
     const unsigned* run_unless = nullptr;
     const unsigned* run_if = nullptr;
 };

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
         if (blockIdx.x == 0 && threadIdx.x == 0 && a.status != nullptr) atomicOr(a.status, 1u);
         return;
     }
+    const float unscale = a.scale_dev != nullptr ? a.scale_dev[1] : a.unscale;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wo = wave >> 1, wi = wave & 1;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * a.unscale;
+                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * unscale;
                             acc[eo][ei][c] = 0.f;
                         }
             } else {
@@ -209,14 +210,14 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * a.unscale);
+                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * unscale);
                             acc[eo][ei][c] = 0.f;
                         }
             }
             if (wi == 0) {  // db: the two k halves of a feature sit in lanes n and n + 32
 #pragma unroll
                 for (int eo = 0; eo < 4; ++eo) {
-                    const float v = (bsum[eo] + __shfl_xor(bsum[eo], 32)) * a.unscale;
+                    const float v = (bsum[eo] + __shfl_xor(bsum[eo], 32)) * unscale;
                     if (hh == 0) {
                         if (sl != nullptr) sl[R2L_W * R2L_W + wo * 128 + 32 * eo + n] = v;
                         else atomicAdd(gbias + wo * 128 + 32 * eo + n, v);

@@ -63,6 +63,8 @@ __device__ __forceinline__ h16_rsrc_t h16_rsrc(const float* base, unsigned bytes
 template <bool JITTER>
 __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadArgs a) {
     if (a.run_unless != nullptr && __builtin_nontemporal_load(a.run_unless) != 0u) return;  // the fp32 kernel behind does it
+    const float gscale = a.scale_dev != nullptr ? a.scale_dev[0] : a.gscale;
+    const float unscale = a.scale_dev != nullptr ? a.scale_dev[1] : a.unscale;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int m = lane & 31, kg = lane >> 5;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     ld_rays(rr);
     for (int s = 0; s < nsteps; ++s) {
         f16x8 ga[8];
-        const float sc = a.gscale;
+        const float sc = gscale;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             ga[e] = __builtin_bit_cast(f16x8, u32x4{pk(rg.g[e][0] * sc, rg.g[e][1] * sc), pk(rg.g[e][2] * sc, rg.g[e][3] * sc),
@@ -183,13 +185,13 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) p[(32 * e + 8 * (c >> 2) + (c & 3)) * 1024] = acc[e][ei][c] * a.unscale;
+                for (int c = 0; c < 16; ++c) p[(32 * e + 8 * (c >> 2) + (c & 3)) * 1024] = acc[e][ei][c] * unscale;
         } else {
             float* p = a.grads + (int64_t)(4 * kg) * R2L_IN + k;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) atomicAdd(p + (32 * e + 8 * (c >> 2) + (c & 3)) * R2L_IN, acc[e][ei][c] * a.unscale);
+                for (int c = 0; c < 16; ++c) atomicAdd(p + (32 * e + 8 * (c >> 2) + (c & 3)) * R2L_IN, acc[e][ei][c] * unscale);
         }
     }
     if (kq == 0 && wave == 0) {

@@ -257,6 +257,41 @@ def test_staged_backward_equals_single_call(n, buckets, monkeypatch):
         assert torch.equal(staged, tr.grads)  # and the staged form is bit-reproducible run to run as well
 
 
+def test_generic_mode_backward_after_forward_rays():
+    """C-ABI generic mode: r2l_forward_rays (with stash) followed by r2l_backward(target = NULL, drgb = caller's dL/drgb).  On
+    the default trio the stash is fp16 and the dX chain needs a power-of-two scale it cannot derive from an MSE scale: it is
+    chosen on the device from max |drgb| (r2l_gscale_kernel).  Same gradients as MSE mode fed the equivalent dL/drgb."""
+    from model.nerf_raybased import PointSampler
+    from r2l_amd import _lib
+    from r2l_amd.engine import _ptr, _stream
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=43, seed=11)
+    m = build_model(sd, 43)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    tr = R2LTrainer(m, ps)
+    g = torch.Generator().manual_seed(12)
+    n = 4500
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+    rgb = tr.forward_backward(o, d, tgt)
+    g_mse = split_flat(tr.grads.clone().cpu(), sd)
+    eng = tr.eng
+    rgb2 = eng.forward_rays(o, d, ps.z_vals, 0., None, save=(tr.save_x, tr.save_t))
+    assert torch.equal(rgb, rgb2)
+    drgb = ((2.0 / (3.0 * n)) * (rgb2 - tgt)).contiguous()
+    tr.grads.zero_()
+    _lib.check(tr.lib.r2l_backward(_ptr(o), _ptr(d), None, _ptr(eng.ztab(ps.z_vals, 0.)), None, _ptr(rgb2), None, _ptr(drgb),
+                                   _ptr(tr.save_x), _ptr(tr.save_t), _ptr(tr.wstream_bwd), _ptr(eng.flat), eng.n_block, 0.0,
+                                   _ptr(tr.dpre), _ptr(tr.gx), _ptr(tr.gt), None, _ptr(tr.grads), _ptr(tr.dw_slab), n,
+                                   _stream()), "r2l_backward (generic)")
+    g_gen = split_flat(tr.grads.cpu(), sd)
+    for k in sd:
+        assert torch.isfinite(g_gen[k]).all(), k
+        # same masks, same chain; only the power-of-two scale (hence the fp16 rounding of the scaled gradients) may differ
+        assert rel_err(g_gen[k], g_mse[k]) < 3e-4, (k, rel_err(g_gen[k], g_mse[k]))
+
+
 def test_fp16_range_guards_in_training():
     """Activations beyond fp16's range (head scaled up until |x| ~ 1e5): the fp16 forward and the fp16 dW kernel raise
     their status words and the bf16x3 kernels behind them redo the launches: gradients still match the oracle."""
