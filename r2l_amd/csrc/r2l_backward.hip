@@ -554,8 +554,8 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3_kernel(const R2LDwArgs a)
 //   * db: the loader lanes add up their raw fp32 gradient quads (4 adds per quad); the 16 rays of a quad column are
 //     combined by xor-shuffles at the flush.
 // Work split, accumulators and the slab reduce are those of r2l_dw_body_kernel; tile eo of a wave's 128-feature slice is
-// features 32 eo .. 32 eo + 31 here (row m of the MFMA result = feature 32 eo + m).  TERMS == 3 (R2L_GRAD_TERMS=3): only
-// the (m,h) (h,m) (h,h) products, no lo split.
+// features 32 eo .. 32 eo + 31 here (row m of the MFMA result = feature 32 eo + m).
+// (Round 1's 3-product and fp16 variants of this kernel were retired with r2l_dw16.hip.)
 // =================================================================================================================
 #define DW3C_OP_BYTES 24576   // one operand, one step: 3 splits x 32 chunks x 256 B
 #define DW3C_BUF_BYTES 49152  // G image, A image
@@ -575,12 +575,11 @@ __device__ __forceinline__ dw3_bf16x8 dw3c_read(unsigned p0, unsigned p1, unsign
 struct Dw3cRegs {
     Dw3Split gs[4], xs[4];
 };
-// fragment F of a step (TERMS == 6: 24 fragments, F < 12: activation tile F/3, split F%3, else gradient tile (F-12)/3, split
-// (F-12)%3;  TERMS == 3: 16 fragments, F < 8: activation tile F/2, split F%2, else gradient);  gp / ap [t]: lane bases in the
+// fragment F of a step (24 fragments, F < 12: activation tile F/3, split F%3, else gradient tile (F-12)/3, split (F-12)%3);
+// gp / ap [t]: lane bases in the
 // G / A image for ray quad t
-template <int TERMS>
 __device__ __forceinline__ void dw3c_frag(int F, Dw3cRegs& R, const unsigned (&gp)[2], const unsigned (&ap)[2]) {
-    constexpr int NS = TERMS == 6 ? 3 : 2;
+    constexpr int NS = 3;
     const bool grad = F >= 4 * NS;
     const int f = grad ? F - 4 * NS : F, e = f / NS, sp = f % NS;
     const dw3_bf16x8 val = grad ? dw3c_read(gp[0], gp[1], (unsigned)(e * 1024 + sp * 8192))
@@ -602,38 +601,8 @@ struct Dw3cQuad {
     float r[4];
     unsigned uh[2], um[2], ul[2];
 };
-__device__ __forceinline__ unsigned dw3c_pk16(float a0, float a1) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, h2));
-}
-__device__ __forceinline__ float dw3c_lo16(unsigned u) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    return (float)__builtin_bit_cast(h2, u)[0];
-}
-__device__ __forceinline__ float dw3c_hi16(unsigned u) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    return (float)__builtin_bit_cast(h2, u)[1];
-}
-// part 0: hi + first residual; part 1: mid + second residual; part 2: lo  (TERMS == 3: parts 0, 1 only).
-// F16: two-way fp16 split (hi = fp16(x), mid = fp16(x - hi): x to ~2^-22) instead of bf16 parts
-template <bool F16>
+// part 0: hi + first residual; part 1: mid + second residual; part 2: lo
 __device__ __forceinline__ void dw3c_split_part(Dw3cQuad& q, const f32x4& x, int part) {
-    if (F16) {
-        if (part == 0) {
-            q.uh[0] = dw3c_pk16(x[0], x[1]);
-            q.uh[1] = dw3c_pk16(x[2], x[3]);
-            // x - half in one v_fma_mix_f32 each (r2l_f2.h)
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q.r[0]) : "v"(q.uh[0]), "v"(x[0]));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q.r[1]) : "v"(q.uh[0]), "v"(x[1]));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q.r[2]) : "v"(q.uh[1]), "v"(x[2]));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q.r[3]) : "v"(q.uh[1]), "v"(x[3]));
-        } else {
-            q.um[0] = dw3c_pk16(q.r[0], q.r[1]);
-            q.um[1] = dw3c_pk16(q.r[2], q.r[3]);
-        }
-        return;
-    }
     if (part == 0) {
         q.uh[0] = dw3_pk(x[0], x[1]);
         q.uh[1] = dw3_pk(x[2], x[3]);
@@ -654,13 +623,11 @@ __device__ __forceinline__ void dw3c_write(unsigned addr, unsigned d0, unsigned 
     *(lds_u2*)(size_t)addr = dw3c_u32x2{d0, d1};
 }
 
-template <int TERMS, bool F16>
 __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char img[2][DW3C_BUF_BYTES];
-    static_assert(!F16 || TERMS == 3, "the fp16 variant is the 3-product scheme");
+    constexpr int TERMS = 6;  // bf16 products per fp32 product
     if (a.run_if != nullptr && __builtin_nontemporal_load(a.run_if) == 0u) return;
     const float unscale = a.scale_dev != nullptr ? a.scale_dev[1] : a.unscale;
-    float amax = 0.f;  // F16: largest |operand value| this lane converted
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wo = wave >> 1, wi = wave & 1;
@@ -746,17 +713,13 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                 dw3c_wait7(raw[k]);
                 // (raw holds step s_next - 1: a clamped reload past the end must not be counted)
                 if (k < 4) bacc[k] += raw[k] * ((s_next - 1 < nsteps) ? 1.f : 0.f);
-                if (F16) {
-                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][0])), __builtin_fabsf(raw[k][1]));
-                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][2])), __builtin_fabsf(raw[k][3]));
-                }
             }
-            dw3c_split_part<F16>(qs, raw[k], part);
-            if (part == (TERMS == 6 ? 2 : 1)) {
+            dw3c_split_part(qs, raw[k], part);
+            if (part == 2) {
                 const unsigned wa = wbase[k & 1] + (unsigned)buf * DW3C_BUF_BYTES + (unsigned)(k >> 2) * DW3C_OP_BYTES + (unsigned)(k & 3) * 512u;
                 dw3c_write(wa, qs.uh[0], qs.uh[1]);
                 dw3c_write(wa + 8192u, qs.um[0], qs.um[1]);
-                if (TERMS == 6) dw3c_write(wa + 16384u, qs.ul[0], qs.ul[1]);
+                dw3c_write(wa + 16384u, qs.ul[0], qs.ul[1]);
                 load(s_next, k);
             }
         };
@@ -771,34 +734,17 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
 #pragma unroll
             for (int g = 0; g < 4 * TERMS; ++g) {
                 const int eo = g / TERMS, term = g % TERMS;
-                // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h);  TERMS == 3: the last three
-                const int tk = TERMS == 6 ? term : term + 3;
+                // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+                const int tk = term;
                 const dw3_bf16x8& ga2 = (tk == 0) ? C.gs[eo].l : (tk == 2 || tk == 3) ? C.gs[eo].m : C.gs[eo].h;
 #pragma unroll
                 for (int ei = 0; ei < 4; ++ei) {
                     const dw3_bf16x8& xb = (tk == 1) ? C.xs[ei].l : (tk == 2 || tk == 4) ? C.xs[ei].m : C.xs[ei].h;
-                    if (F16) {
-                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ga2), __builtin_bit_cast(f16x8, xb),
-                                                                             acc[eo][ei], 0, 0, 0);
-                    } else {
-                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga2, xb, acc[eo][ei], 0, 0, 0);
-                    }
+                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga2, xb, acc[eo][ei], 0, 0, 0);
                 }
-                if (TERMS == 6) {  // 24 groups: 24 fragments, 8 quads x 3 parts
-                    dw3c_frag<6>(g, Nx, gp, ap);
-                    quad_part(g / 3, g % 3, buf, s + 3);
-                } else {  // 12 groups: 16 fragments, 8 quads x 2 parts
-                    if (g < 4) {
-                        dw3c_frag<3>(2 * g, Nx, gp, ap);
-                        dw3c_frag<3>(2 * g + 1, Nx, gp, ap);
-                        quad_part(g, 0, buf, s + 3);
-                        quad_part(g, 1, buf, s + 3);
-                    } else {
-                        dw3c_frag<3>(g + 4, Nx, gp, ap);
-                        quad_part(4 + (g - 4) / 2, (g - 4) % 2, buf, s + 3);
-                    }
-                }
+                // 24 groups: 24 fragments, 8 quads x 3 parts
+                dw3c_frag(g, Nx, gp, ap);
+                quad_part(g / 3, g % 3, buf, s + 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -814,22 +760,18 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
                     dw3c_wait0(raw[k]);
                     if (k < 4) bacc[k] += raw[k];
 #pragma unroll
-                    for (int part = 0; part < (TERMS == 6 ? 3 : 2); ++part) dw3c_split_part<F16>(qs, raw[k], part);
-                    if (F16) {
-                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][0])), __builtin_fabsf(raw[k][1]));
-                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(raw[k][2])), __builtin_fabsf(raw[k][3]));
-                    }
+                    for (int part = 0; part < 3; ++part) dw3c_split_part(qs, raw[k], part);
                     const unsigned wa = wbase[k & 1] + (unsigned)s * DW3C_BUF_BYTES + (unsigned)(k >> 2) * DW3C_OP_BYTES + (unsigned)(k & 3) * 512u;
                     dw3c_write(wa, qs.uh[0], qs.uh[1]);
                     dw3c_write(wa + 8192u, qs.um[0], qs.um[1]);
-                    if (TERMS == 6) dw3c_write(wa + 16384u, qs.ul[0], qs.ul[1]);
+                    dw3c_write(wa + 16384u, qs.ul[0], qs.ul[1]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) load(2, k);
             __syncthreads();
 #pragma unroll
-            for (int F = 0; F < (TERMS == 6 ? 24 : 16); ++F) dw3c_frag<TERMS>(F, RA, gb0, ab0);  // step 0 from buffer 0
+            for (int F = 0; F < 24; ++F) dw3c_frag(F, RA, gb0, ab0);  // step 0 from buffer 0
             for (int s = 0; s < nsteps; s += 2) {
                 step(RA, RB, s, 0);
                 step(RB, RA, s + 1, 1);
@@ -888,7 +830,6 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body3c_kernel(const R2LDwArgs a
         }
         u += cend - cu;
     }
-    if (F16 && a.status != nullptr && !(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
 }
 
 // =================================================================================================================
@@ -1299,9 +1240,9 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
             const int rc = r2l_dw16_launch(a, wgs, bwd_status, stream);
             if (rc) return rc;
             a.run_if = bwd_status;
-            hipLaunchKernelGGL((r2l_dw_body3c_kernel<6, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         } else if (split) {
-            hipLaunchKernelGGL((r2l_dw_body3c_kernel<6, false>), dim3((unsigned)wgs), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         }
         else if (r2l_use_fwd3()) hipLaunchKernelGGL(r2l_dw_body3_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(r2l_dw_body_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);

@@ -102,7 +102,6 @@ struct B3TakeU {  // u values masked by relu'(t_b) (mask words of the forward: b
     }
 };
 
-template <int TERMS>
 __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[B3_NBUF][F3_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
     }
 
     // ---- weight staging (6 buffers beside the 8 KiB mask ring) ----------------------------------------------------------------
-    typedef F3PipeT<B3_NBUF, TERMS> Pipe;
+    typedef F3PipeT<B3_NBUF> Pipe;
     Pipe P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
@@ -279,7 +278,7 @@ int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, 
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd3); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    hipLaunchKernelGGL(r2l_bwd3_kernel<6>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(r2l_bwd3_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

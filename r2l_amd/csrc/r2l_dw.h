@@ -37,8 +37,8 @@ struct R2LDwArgs {
                   // nullptr -> fp32 atomics straight into grads
     float unscale = 1.0f;  // the gradient operands carry a power-of-two scale (r2l_bwd3): dW, db are multiplied by its inverse
     const float* scale_dev = nullptr;  // generic mode of the fp16 trio: {gscale, 1 / gscale} chosen on the device; overrides unscale
-    // range guard of the fp16 variant (r2l_dw_body3c_kernel<3, true>): it raises *status when an operand value leaves fp16's
-    // safe range; the bf16 variant launched behind it with run_if = status then redoes the launch (else returns at once)
+    // fallback chaining of the default trio: r2l_dw16_kernel raises *status (if given) when it hands the launch over; a kernel
+    // launched with run_if returns at once while that word is 0
     unsigned* status = nullptr;
     const unsigned* run_if = nullptr;
 };

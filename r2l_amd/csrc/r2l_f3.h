@@ -112,9 +112,7 @@ struct F3Side {
 // acc[4 tiles of `half`] (+)= W . b: six bf16 MFMAs per tile, small terms first, term-major so that an accumulator is
 // touched every fourth MFMA; after every group of four MFMAs one step of `side`.  BIAS stage: one MFMA per tile (hi,
 // mid, lo of the bias in k slots 0..2 against ones), then all the side work.
-// TERMS == 3 (gradient GEMMs on request, R2L_GRAD_TERMS=3): only the products (m,h) (h,m) (h,h) — 16 mantissa bits per
-// operand instead of 24 (product error ~2^-16 instead of 2^-24), half the matrix work; two side steps per group.
-template <bool BIAS, bool ZERO_INIT, int TERMS, class Side>
+template <bool BIAS, bool ZERO_INIT, class Side>
 __device__ __forceinline__ void f3_mfma_half(f32x16 (&acc)[R2L_NT], int half, const F3A4& a, const F3Split& b, Side& side) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (BIAS) {
@@ -130,27 +128,6 @@ __device__ __forceinline__ void f3_mfma_half(f32x16 (&acc)[R2L_NT], int half, co
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[t], BB, acc[4 * half + t], 0, 0, 0);                                  \
     side.step(I);                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);
-    if (TERMS == 3) {
-#define F3_GROUP2(AA, BB, I)                                                                                            \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) acc[4 * half + t] =                                                   \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[t], BB, acc[4 * half + t], 0, 0, 0);                                  \
-    side.step(I);                                                                                                       \
-    side.step(I + 1);                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);
-        if (ZERO_INIT) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[t], b.h, zero, 0, 0, 0);
-            side.step(0);
-            side.step(1);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            F3_GROUP2(a.m, b.h, 0)
-        }
-        F3_GROUP2(a.h, b.m, 2)
-        F3_GROUP2(a.h, b.h, 4)
-#undef F3_GROUP2
-        return;
-    }
     if (ZERO_INIT) {  // first k-block of a GEMM without bias: C = 0 (inline constant) in the first group
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[4 * half + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[t], b.h, zero, 0, 0, 0);
@@ -168,9 +145,8 @@ __device__ __forceinline__ void f3_mfma_half(f32x16 (&acc)[R2L_NT], int half, co
 }
 
 // state of the weight-staging pipeline (everything wave-uniform except lane-derived offsets)
-template <int NBUF, int TERMS_ = 6>
+template <int NBUF>
 struct F3PipeT {
-    static constexpr int TERMS = TERMS_;  // bf16 products per fp32 product in the stages driven through this pipe
     u32x4 rs;            // buffer descriptor of the stage stream
     unsigned lds0;       // LDS address of buffer 0
     unsigned voff, wq;   // lane * 16 ; this wave's quarter of a stage
@@ -223,11 +199,11 @@ template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class Pipe, class GLo, class
 __device__ __forceinline__ void f3_stage(f32x16 (&acc)[R2L_NT], Pipe& P, GLo glo, GHi ghi, F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
                                          F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u}) {
     F3Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, extra_a};
-    f3_mfma_half<BIAS_K, ZERO_K, Pipe::TERMS>(acc, 0, P.a1, P.sb, sa);
+    f3_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
     P.sync_next();
     F3Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), extra_b};
-    f3_mfma_half<BIAS_K, ZERO_K, Pipe::TERMS>(acc, 1, P.a2, P.sb, sb2);
+    f3_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {
         P.sb = P.ones;
