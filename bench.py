@@ -11,8 +11,9 @@ Workload (config.workload): BASELINE.json configs[1] — render 400x400 frames (
 L=10, W256 D88, seeded weights, synthetic pose_spherical poses).  One "step" = one frame per GPU through the fused
 HIP forward (ray sampling + positional encoding + 88-layer ResMLP + RGB head).  Inputs (pose, weights) are resident
 before the timed region.  Frames shard across ranks with no collective -> "scaling": "weak".
-When the training path is built the same JSON line carries a "train" object (distillation step: forward + backward
-+ Adam, RCCL all-reduce of the flat gradient at N>1), timed by the same barrier-bracketed recipe.
+The same JSON line carries a "train" object (distillation step: forward + backward + Adam; at N > 1 the bucketed RCCL
+all-reduce of the flat gradient overlapped with the weight-gradient stages), "train_strong" (N > 1: the single-GPU batch
+split over the ranks), "train_4096" and "teacher", timed by the same barrier-bracketed recipe.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -290,8 +291,9 @@ def main():
     peak_note = ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); the default forward-only kernel (r2l_fwd2.hip) "
                  "evaluates every fp32 product as 3 fp16 MFMA products (operands as fp16 hi + mid: 22 mantissa bits; measured "
                  "max |dRGB| 1.3e-6 against the fp32 oracle, bar 1e-4), so its matrix-pipe peak in algorithmic FLOP/s is the "
-                 "dense 16-bit MFMA peak 2500 TF / 3; the chip is power-limited under such a stream (1.5-1.8 GHz instead of "
-                 "the nominal 2.4 GHz the peak assumes: profiles/r01_summary.md, r01_clock_probe.txt)" if fwd2 else
+                 "dense 16-bit MFMA peak 2500 TF / 3; under such a stream the chip sits at its 1.4 kW power cap at 1.85-1.9 GHz "
+                 "instead of the nominal 2.4 GHz the peak assumes (the vendor's plain bf16 GEMM: 55-56 % of 2500 TF on the "
+                 "same box): profiles/r02_power_trace.txt, r02_summary.md" if fwd2 else
                  ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); this kernel evaluates every fp32 product as 6 "
                   "bf16 MFMA products (exact bf16 hi/mid/lo splits): peak = dense bf16 MFMA peak 2500 TF / 6; the chip runs at "
                   "1.72-1.77 GHz (power limit) under that load" if fwd3 else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"))

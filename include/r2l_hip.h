@@ -47,8 +47,9 @@ int r2l_pack_backward_layout(const float* params, int n_block, float* wstream, i
  * ztab[32] = z_lower[16] ++ z_span[16]; depth of sample s = z_lower[s] + z_span[s]*t_rand[ray,s], or z_lower[s]
  * when t_rand == NULL (perturb == 0; then z_lower = PointSampler.z_vals).
  * save_x [(n_block+1) slots] / save_t [n_block slots] of r2l_stash_slot_floats(N) floats each: optional activation stash
- * for r2l_backward (both or none); opaque to the caller (row-major fp32 [Np,256] per slot or bf16 triples, depending on the
- * kernel variant the library picks for N; Np = r2l_padded_rows(N) = N rounded up to 32). */
+ * for r2l_backward (both or none); opaque to the caller (row-major fp32 [Np,256], chunked fp32 or fp16 stage pieces per slot,
+ * depending on the kernel family the library picks for N and the R2L_* environment — which must be the same for this call
+ * and the r2l_backward that consumes the stash; Np = r2l_padded_rows(N) = N rounded up to 32). */
 int r2l_forward_rays(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
                      float* save_t, int64_t N, void* stream);
@@ -70,7 +71,8 @@ int r2l_forward_emb(const float* emb, const float* wstream, const float* params,
  * per-layer weight-gradient GEMMs (reduction over rays) and the head gradient with the encoding recomputed.
  *   MSE mode  (target != NULL): dL/drgb = grad_scale * (rgb - target)   [grad_scale = 2*lw_rgb / (3*N_global)];
  *                               sqerr_partial[r2l_num_tiles(N)] receives per-32-ray sums of (rgb-target)^2.
- *   generic   (target == NULL): dL/drgb = drgb[N,3] supplied by the caller (autograd bridge).
+ *   generic   (target == NULL): dL/drgb = drgb[N,3] supplied by the caller (autograd bridge); grad_scale is ignored (the
+ *                               power-of-two scale the fp16 kernels run the chain on is derived from max |drgb| on the device).
  * Head input: emb[N,1008] if given, else recomputed from (rays_o, rays_d, t_rand, ztab) exactly as the forward did.
  * save_x/save_t: the stash written by the forward of the same N (r2l_forward_rays, or r2l_forward_emb when emb is given).
  * Scratch owned by the caller: dpre[N,3], gx[(n_block+1) slots], gt[n_block slots] (slots of r2l_stash_slot_floats(N)
@@ -81,8 +83,8 @@ int r2l_forward_emb(const float* emb, const float* wstream, const float* params,
 int64_t r2l_num_tiles(int64_t N);
 int64_t r2l_padded_rows(int64_t N);
 /* Floats per stash slot: size save_x / gx as (n_block+1) * r2l_stash_slot_floats(N) floats and save_t / gt as
- * n_block * r2l_stash_slot_floats(N) (>= Np*256: the bf16x3 chains keep every stashed value as a bf16 triple, 1.5 KiB
- * per ray and slot; the layout inside the buffers is private to the library). */
+ * n_block * r2l_stash_slot_floats(N) (Np*264: 1 KiB per ray of data + the forward's ReLU mask words; the layout inside the
+ * buffers is private to the library). */
 int64_t r2l_stash_slot_floats(int64_t N);
 int64_t r2l_dw_slab_floats(void);
 int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* emb,
