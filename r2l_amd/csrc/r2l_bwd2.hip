@@ -4,6 +4,7 @@
 // kernel launched behind it redoes the launch.  Stage order, mask ring and stash stores are r2l_bwd3.hip's; six 16 KiB
 // weight buffers fit beside the 32 KiB mask ring.
 #include "r2l_f2.h"
+#include "r2l_coopf.h"
 
 #define B3_RING 2  // mask pieces (one per block) per wave
 
@@ -275,6 +276,9 @@ int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, 
                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
                       const float* scale_dev) {
+    if (r2l_use_coopf(N, n_block))  // small launches: the cooperative chain (r2l_coopf_bwd.hip), same stream / stash / status word
+        return r2l_coopf_backward(rgb, target, drgb, save_x, save_t, wstream_bwd2, params, n_block, grad_scale, dpre, gx, gt,
+                                  sqerr_partial, N, stream, gscale, status, scale_dev);
     B2Args a{};
     a.status = status;
     a.scale_dev = scale_dev;

@@ -435,10 +435,32 @@ int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_ra
 #define R2L_C16_ROUND 0.174
 #endif
 enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP = 1, R2L_VARIANT_COOP16 = 2 };
+// Cooperative fp16x2 kernels (r2l_coopf.h: one 32-ray tile per WORKGROUP): a sub-family of the MAIN variant — same streams,
+// stash and fallbacks as r2l_fwd2 / r2l_bwd2, taken instead of them for launches of at most R2L_COOPF_MAX_RAYS rays
+// (R2L_FORCE_VARIANT=coopf: always; =main: never).  Only with the whole fp16 trio enabled (no R2L_NO_* switch).
+#ifndef R2L_COOPF_MAX_RAYS
+#define R2L_COOPF_MAX_RAYS 16384
+#endif
+static inline bool r2l_env_on(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
+static inline bool r2l_fp16_trio_env() {
+    return !r2l_env_on("R2L_NO_FWD3") && !r2l_env_on("R2L_NO_FWD2") && !r2l_env_on("R2L_NO_BWD2") && !r2l_env_on("R2L_NO_DW2");
+}
+static inline bool r2l_use_coopf(int64_t N, int n_block) {
+    if (n_block <= 0 || !r2l_fp16_trio_env()) return false;
+    const char* e = getenv("R2L_FORCE_VARIANT");
+    if (e && e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return true;
+    if (e && e[0]) return false;
+    return N <= R2L_COOPF_MAX_RAYS;
+}
 static inline int r2l_chain_variant(int64_t N) {
     const char* e = getenv("R2L_FORCE_VARIANT");  // read per call (~100 ns) so tests can flip it
     if (e && e[0] == 'm') return R2L_VARIANT_MAIN;
+    if (e && e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return R2L_VARIANT_MAIN;  // coopf: kernels of the MAIN family
     if (e && e[0] == 'c') return (e[1] && e[2] && e[3] && e[4] == '1') ? R2L_VARIANT_COOP16 : R2L_VARIANT_COOP;
+    if (r2l_fp16_trio_env() && N <= R2L_COOPF_MAX_RAYS) return R2L_VARIANT_MAIN;  // served by the cooperative fp16x2 kernels
     // (one main round on the fp16x2 kernels costs 0.30 of a round of the fp32-MFMA kernel the unit was defined on; measured,
     // tools/variant_sweep.py: 98 304-ray-style steps of 6144 rays 1.99 ms on the one-wave-per-tile kernels vs 2.11 ms on the
     // 16-ray cooperative ones, 20 480 rays 2.9 vs 5.9 ms; 4096 rays 1.94 vs 1.34 ms)
@@ -461,10 +483,6 @@ static inline bool r2l_stash_chunked(int64_t N, bool pre_embedded) {
 // stashing fp16 stage pieces, and the fp16 weight-gradient GEMMs on them (r2l_dw16.hip).  Any of R2L_NO_FWD3 / R2L_NO_FWD2 /
 // R2L_NO_BWD2 / R2L_NO_DW2 = 1 puts the whole step on the bf16x3 trio (r2l_fwd3 / r2l_bwd3 / r2l_dw_body3c, chunked fp32
 // stash) — the kernels the range guards fall back to.  (Forward-only launches look at R2L_NO_FWD2 alone.)
-static inline bool r2l_env_on(const char* name) {
-    const char* e = getenv(name);
-    return e && e[0] && e[0] != '0';
-}
 static inline bool r2l_use_trio16() { return r2l_use_fwd2() && !r2l_env_on("R2L_NO_BWD2") && !r2l_env_on("R2L_NO_DW2"); }
 
 // error plumbing shared by the C-ABI translation units

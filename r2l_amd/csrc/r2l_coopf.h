@@ -1,0 +1,154 @@
+// r2l_coopf.h — machinery of the COOPERATIVE fp16x2 chains (r2l_coopf_fwd.hip, r2l_coopf_bwd.hip): the default fp16 trio for
+// launches too small to fill the chip with one wave per 32-ray tile.
+//
+// The one-wave-per-tile kernels (r2l_fwd2 / r2l_bwd2) need 32 768 rays to occupy the 1024 SIMDs, and every workgroup streams
+// the whole 25 MB of packed weights for its 128 rays.  Here the FOUR waves of a workgroup share ONE 32-ray tile: wave w owns
+// output tiles 2w, 2w+1 (64 of the 256 features) of every layer, so 4096 rays already give 128 workgroups x 4 waves and a
+// step of <= 8192 rays is one round.  Everything else is the fp16 trio's: the same packed stage streams (16 KiB stages,
+// [split][tile][lane][8 fp16]; a wave reads the four 1 KiB pieces of its two tiles), the same 32x32x16 MFMA fragments, three
+// fp16 products per fp32 product, the same fp16 stage-piece stash, mask words and range-guard protocol — so r2l_dw16 /
+// r2l_dw_head16 and the bf16x3 fallbacks serve these launches unchanged.
+//   * B operands (the layer input, all 256 features x 32 rays) are shared through LDS: wave w's output fragments of tiles
+//     2w, 2w+1 ARE, lane for lane, the B operands of stages 4w .. 4w+3 of the next layer (fragment registers c = 8r .. 8r+7 of
+//     tile T = stage 2T + r), so each wave converts its own 32 values per lane to (hi, mid), writes them to the image
+//     [stage][split][lane][16 B] and — training — stores the hi quad as the stash piece; ONE barrier per layer.
+//   * A operands come straight from L2 into a four-stage register ring (16 loads in flight per wave), no LDS: a wave reads
+//     only its own quarter of a stage.  The ring slot of every stage is a compile-time constant: a layer has 17 stages, so
+//     the phase advances by one per layer and the body is unrolled over two blocks (68 stages).
+//   * The kernel is bound by that weight stream (256 KiB per layer and workgroup from L2), not by the matrix pipe.
+#pragma once
+#include "r2l_f2.h"
+
+#define FC_RING 4
+#define FC_BOP_BYTES 32768   // one B-operand image: 16 stages x (hi, mid) x 1 KiB
+
+typedef __attribute__((address_space(3))) u32x4 fc_lds_u32x4;
+__device__ __forceinline__ u32x4 fc_lds_read(unsigned addr) { return *(fc_lds_u32x4*)(size_t)addr; }
+__device__ __forceinline__ void fc_lds_write(unsigned addr, u32x4 v) { *(fc_lds_u32x4*)(size_t)addr = v; }
+
+struct FcRing {  // four stages x (hi tile 0, hi tile 1, mid tile 0, mid tile 1) of this wave
+    u32x4 a[FC_RING][4];
+};
+struct FcStream {
+    u32x4 rs;       // descriptor of the stage stream
+    unsigned voff;  // lane*16 + wave*2048: tile 2w of split 0; + 1024: tile 2w+1; + 8192: split 1
+    unsigned g;     // next stage to LOAD
+};
+
+template <int IMM>
+__device__ __forceinline__ void fc_load(u32x4& dst, u32x4 rs, unsigned voff, unsigned soff) {
+    // untracked by the compiler (it would drain vmcnt at every barrier and loop header): consumers wait with fc_wait
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
+    const unsigned so = p.g * (unsigned)F2_STAGE_BYTES;
+    fc_load<0>(a[0], p.rs, p.voff, so);
+    fc_load<1024>(a[1], p.rs, p.voff, so);
+    fc_load<0>(a[2], p.rs, p.voff + 8192u, so);
+    fc_load<1024>(a[3], p.rs, p.voff + 8192u, so);
+    ++p.g;
+}
+// the four loads of the oldest stage in flight have landed: three younger stages (12 loads) may still fly; vmcnt retires in
+// order, and anything else in the queue (stash stores) only makes the wait stricter
+__device__ __forceinline__ void fc_wait(u32x4 (&a)[4]) {
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+}
+__device__ __forceinline__ void fc_barrier() {  // LDS writes of this wave done, then the workgroup barrier (no vmcnt drain)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// stash / ride-along global store the compiler does not track either
+__device__ __forceinline__ void fc_store_nt(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fc_store_b32(void* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
+// acc[2 tiles] (+)= stage: BIAS: one MFMA per tile (bias hi / mid in k slots 0, 1 against ones), else the three products,
+// small terms first.  Then the slot is refilled with the stage four positions ahead.
+template <int SLOT, bool BIAS, bool ZERO>
+__device__ __forceinline__ void fc_stage(f32x16 (&acc)[2], FcRing& W, FcStream& p, const f16x8& bh, const f16x8& bm) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    fc_wait(W.a[SLOT]);
+    const f16x8 h0 = __builtin_bit_cast(f16x8, W.a[SLOT][0]), h1 = __builtin_bit_cast(f16x8, W.a[SLOT][1]);
+    const f16x8 m0 = __builtin_bit_cast(f16x8, W.a[SLOT][2]), m1 = __builtin_bit_cast(f16x8, W.a[SLOT][3]);
+    if (BIAS) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh, ZERO ? zero : acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh, ZERO ? zero : acc[1], 0, 0, 0);
+    } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m0, bh, ZERO ? zero : acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m1, bh, ZERO ? zero : acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bm, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bm, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh, acc[1], 0, 0, 0);
+    }
+    fc_issue(W.a[SLOT], p);
+}
+
+// One layer: its bias (or zero) stage in ring slot PH, then the 16 k-stages against the B-operand image at `bop`
+// (LDS byte address of this lane's 16 bytes of stage 0, split 0).  ZERO_FIRST: the bias stage initialises acc (C = 0).
+template <int PH, bool ZERO_FIRST>
+__device__ __forceinline__ void fc_layer(f32x16 (&acc)[2], FcRing& W, FcStream& p, unsigned bop, const f16x8& ones) {
+    fc_stage<PH, true, ZERO_FIRST>(acc, W, p, ones, ones);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)kb * 2048u));
+        const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)kb * 2048u + 1024u));
+        if ((PH + 1 + kb) % 4 == 0) fc_stage<0, false, false>(acc, W, p, bh, bm);
+        else if ((PH + 1 + kb) % 4 == 1) fc_stage<1, false, false>(acc, W, p, bh, bm);
+        else if ((PH + 1 + kb) % 4 == 2) fc_stage<2, false, false>(acc, W, p, bh, bm);
+        else fc_stage<3, false, false>(acc, W, p, bh, bm);
+    }
+}
+
+// Eight values of one stage -> (hi, mid) fp16 quads (r2l_f2.h's split: hi = fp16(x), mid = fp16(x - hi)); amax tracks the
+// largest |value| for the range guard
+__device__ __forceinline__ void fc_split8(const float (&v)[8], u32x4& uh, u32x4& um, float& amax) {
+    typedef F2Side<false, F3None> S;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2 * k])), __builtin_fabsf(v[2 * k + 1]));
+        uh[k] = S::pk(v[2 * k], v[2 * k + 1]);
+        um[k] = S::pk(f2_res_lo(uh[k], v[2 * k]), f2_res_hi(uh[k], v[2 * k + 1]));
+    }
+}
+
+// This wave's output fragments (tiles 2w, 2w+1) become the B operands of stages 4w .. 4w+3 of the next GEMM: convert, write
+// to the image at `bopw` (LDS byte address of this lane's 16 bytes of stage 4w, split 0), stash the hi quads (training) at
+// hst[64 * i], i = 0..3.  RELU: values are max(x, 0) (and, MASK, bit tt*16 + c of *mword = [frag[tt][c] > 0]).
+struct FcIdentity {
+    __device__ __forceinline__ float operator()(float v, int, int) const { return v; }
+};
+template <bool RELU, bool SAVE, bool MASK, class Sel = FcIdentity>
+__device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bopw, u32x4* hst, unsigned* mword, float& amax,
+                                           const Sel& sel = Sel()) {
+    unsigned mw = 0u;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float x = sel(frag[tt][8 * r + s], tt, 8 * r + s);
+                v[s] = RELU ? fmaxf(x, 0.f) : x;
+                if (MASK) mw |= (x > 0.f ? 1u : 0u) << (tt * 16 + 8 * r + s);
+            }
+            u32x4 uh, um;
+            fc_split8(v, uh, um, amax);
+            fc_lds_write(bopw + (unsigned)(2 * tt + r) * 2048u, uh);
+            fc_lds_write(bopw + (unsigned)(2 * tt + r) * 2048u + 1024u, um);
+            if (SAVE) fc_store_nt(hst + 64 * (2 * tt + r), uh);
+        }
+    if (MASK) *mword = mw;
+}
+
+// launchers (called from r2l_fwd2_forward / r2l_bwd2_backward when the launch is small: r2l_use_coopf)
+int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* c2w_host12,
+                      int H, int W, float focal, const float* wstream2, const float* params, int n_block, float* rgb,
+                      float* save_x, float* save_t, int64_t N, hipStream_t stream);
+int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
+                       const float* scale_dev);

@@ -1,0 +1,209 @@
+// r2l_coopf_bwd.hip — cooperative fp16x2 dX chain (see r2l_coopf.h; the chain itself is r2l_bwd2.hip's): dL/drgb -> sigmoid'
+// -> tail^T -> the 2*n_block transposed layers, stashing the fp16 hi operands of g and of the masked u for r2l_dw16.hip and
+// writing gx[0] = dL/d(head pre-activation) for the head gradient — the dX half of loss.backward()
+// (/root/reference/main.py:1377-1404) for launches of a few thousand rays.  One 32-ray tile per workgroup; wave w owns output
+// tiles 2w, 2w+1 of every transposed layer; the stream is r2l_pack_bwd2_kernel's (per block: zero stage, 16 stages of W2^T,
+// zero stage, 16 stages of W1^T).
+#include "r2l_coopf.h"
+#include <type_traits>
+
+__host__ __device__ static inline int64_t cb_off_tail_w(int n_block) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)2 * n_block * (R2L_W * R2L_W + R2L_W);
+}
+
+struct CfBwdArgs {
+    const float* rgb;
+    const float* target;
+    const float* drgb;
+    const float* save_x;
+    const float* save_t;
+    const unsigned char* stream;  // bwd2 stage stream
+    const float* params;
+    int n_block;
+    float grad_scale;
+    float gscale, ginv;
+    const float* scale_dev;  // generic mode: {gscale, 1 / gscale} on the device, or nullptr
+    unsigned* status;        // range guard (r2l_bwd2.hip's word)
+    const unsigned* fmt;     // stash format word of the forward: != 0 -> this step belongs to the bf16x3 kernels
+    float* dpre;
+    float* gx;
+    float* gt;
+    float* sqerr_partial;
+    int64_t N;
+};
+
+// masked u: bit tt*16 + c of the forward's mask word of this wave
+struct CfMask {
+    unsigned w;
+    __device__ __forceinline__ float operator()(float v, int tt, int c) const { return ((w >> (tt * 16 + c)) & 1u) ? v : 0.f; }
+};
+
+__global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][FC_BOP_BYTES];
+    if (__builtin_nontemporal_load(a.fmt) != 0u) {  // the forward's stash is the bf16x3 trio's: so is this step's backward
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
+        return;
+    }
+    const float gscale = a.scale_dev != nullptr ? a.scale_dev[0] : a.gscale;
+    const float ginv = a.scale_dev != nullptr ? a.scale_dev[1] : a.ginv;
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = blockIdx.x;
+    const int64_t ray = tile * R2L_TILE_RAYS + j;
+    const bool valid = ray < a.N;
+    const int64_t rc = valid ? ray : a.N - 1;
+    const int64_t Np = R2L_PAD_ROWS(a.N);
+    const int64_t slot = R2L_TRIO_SLOT(Np);
+
+    // ---- loss gradient through the sigmoid, per-tile squared error (every wave computes it; wave 0 writes) -------------------
+    float dp[3], se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float r = a.rgb[rc * 3 + c];
+        float dl;
+        if (a.target != nullptr) {
+            const float e = r - a.target[rc * 3 + c];
+            se += e * e;
+            dl = a.grad_scale * e;
+        } else {
+            dl = a.drgb[rc * 3 + c];
+        }
+        dp[c] = valid ? dl * (r * (1.0f - r)) : 0.f;
+    }
+    if (!valid) se = 0.f;
+    if (wave == 0) {
+        if (valid && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.dpre[ray * 3 + c] = dp[c];
+        }
+        if (a.sqerr_partial != nullptr) {
+            float s = (h == 0) ? se : 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) a.sqerr_partial[tile] = s;
+        }
+    }
+    // g = dy = Wt^T dpre (tail Linear(256,3)): this wave's 64 features
+    f32x16 g[2], u[2], dy[2];
+    {
+        const float* tw = a.params + cb_off_tail_w(a.n_block);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int T = 2 * wave + tt;
+                f32x4 wv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = wv[0][e] * (dp[0] * gscale);
+                    v = __builtin_fmaf(wv[1][e], dp[1] * gscale, v);
+                    v = __builtin_fmaf(wv[2][e], dp[2] * gscale, v);
+                    g[tt][4 * q + e] = v;
+                    dy[tt][4 * q + e] = v;
+                }
+            }
+    }
+
+    FcRing W;
+    FcStream P;
+    {
+        const unsigned long long sa = (unsigned long long)a.stream;
+        P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        P.voff = (unsigned)lane * 16u + (unsigned)wave * 2048u;
+        P.g = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < FC_RING; ++k) fc_issue(W.a[k], P);
+    f16x8 ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
+    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0];
+    const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;
+    const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;
+    float amax = 0.f;
+
+    // stash bases of this lane / wave (fp16 stage pieces 4w .. 4w+3 of the tile) and the forward's mask word of the wave
+    const int64_t unit0 = tile * R2L_H16_TILE_UNITS + lane + 256 * wave;
+    u32x4* gxh = reinterpret_cast<u32x4*>(a.gx + (int64_t)a.n_block * slot) + unit0;        // slot b + 1 of block b = n_block - 1
+    u32x4* gth = reinterpret_cast<u32x4*>(a.gt + (int64_t)(a.n_block - 1) * slot) + unit0;
+    const unsigned* mwp = reinterpret_cast<const unsigned*>(a.save_t + (int64_t)(a.n_block - 1) * slot + R2L_MASK_OFFSET(Np) +
+                                                            tile * 256 + lane * 4) + wave;
+
+    // g B operands in image 0, masked-u B operands in image 1; a barrier after each production
+    fc_produce<false, true, false>(g, bop_wr, gxh, nullptr, amax);
+    fc_barrier();
+    auto block = [&](auto ph_tag, bool last) {
+        constexpr int PH = decltype(ph_tag)::value;
+        // the forward's mask word: an untracked load like the ring's (a compiler-tracked one would drain vmcnt, i.e. the ring, at
+        // its first use).  It is older than every load of GEMM A, whose last fc_wait leaves only the 12 youngest in flight.
+        unsigned mw;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(mw) : "v"(mwp) : "memory");
+        // GEMM A: u = W2^T g   (zero stage first: u is initialised by C = 0)
+        fc_layer<PH, true>(u, W, P, bop_rd, ones);
+        asm volatile("" : "+v"(mw));  // (uses of mw stay behind GEMM A)
+        fc_produce<false, true, false>(u, bop_wr + FC_BOP_BYTES, gth, nullptr, amax, CfMask{mw});
+        fc_barrier();
+        // GEMM B: g += W1^T (u . mask)
+        fc_layer<(PH + 1) % 4, false>(g, W, P, bop_rd + FC_BOP_BYTES, ones);
+        gxh -= slot / 4;
+        gth -= slot / 4;
+        mwp -= slot;
+        if (!last) {
+            fc_produce<false, true, false>(g, bop_wr, gxh, nullptr, amax);
+            fc_barrier();
+        }
+    };
+#pragma unroll 1
+    for (int b = a.n_block - 1; b >= 0; b -= 2) {
+        block(std::integral_constant<int, 0>{}, b == 0);
+        if (b - 1 >= 0) block(std::integral_constant<int, 2>{}, b - 1 == 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+
+    // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0], row-major fp32 (the head weight gradient reads rows) -----
+    {
+        // x_0's fp16 stage pieces (slot 0 of save_x): stage kb = 2T + r holds fragment registers c = 8r .. 8r+7 of tile T
+        const u32x4* r = reinterpret_cast<const u32x4*>(a.save_x) + tile * R2L_H16_TILE_UNITS + lane;
+        float* o = a.gx + ray * R2L_W + 4 * h;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int T = 2 * wave + tt;
+                const f16x8 xv = __builtin_bit_cast(f16x8, r[64 * (2 * T + rr)]);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    f32x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 8 * rr + 4 * q2 + e;
+                        ov[e] = (float)xv[4 * q2 + e] > 0.f ? (g[tt][c] + dy[tt][c]) * ginv : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(o + 32 * T + 8 * (2 * rr + q2)) = ov;
+                }
+            }
+    }
+}
+
+int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
+                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
+                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
+                       const float* scale_dev) {
+    CfBwdArgs a{};
+    a.status = status;
+    a.scale_dev = scale_dev;
+    a.fmt = reinterpret_cast<const unsigned*>(save_x) + R2L_STASH_FMT_WORD(n_block, R2L_PAD_ROWS(N));
+    a.gscale = gscale; a.ginv = 1.0f / gscale;
+    a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
+    a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;
+    a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
+    const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    hipLaunchKernelGGL(r2l_coopf_bwd_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,249 @@
+// r2l_coopf_fwd.hip — cooperative fp16x2 forward of the R2L student (see r2l_coopf.h): rgb[N,3] =
+// NeRF_v3_2.forward(PositionalEmbedder(10)(PointSampler.sample_train / sample_test(...))), the op sequence of
+// /root/reference/model/nerf_raybased.py:94-126, 198-208, 461-465, 539-544, with ONE 32-ray tile per workgroup (four waves,
+// 64 output features each) instead of one per wave: the kernel of the default fp16 trio for launches of a few thousand
+// rays (BASELINE configs[2] / [3] read literally: 4096 rays per step; the per-GPU share of a strong-scaling step).
+// Numerically it is r2l_fwd2.hip: same packed stream, same three fp16 products per fp32 product, same stash.
+#include "r2l_coopf.h"
+#include <type_traits>
+
+__host__ __device__ static inline int64_t cf_off_tail_w(int n_block) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)2 * n_block * (R2L_W * R2L_W + R2L_W);
+}
+__host__ __device__ static inline int64_t cf_off_tail_b(int n_block) { return cf_off_tail_w(n_block) + 3 * R2L_W; }
+
+struct CfFwdArgs {
+    const float* rays_o;
+    const float* rays_d;
+    const float* t_rand;
+    const float* ztab;
+    float c2w[12];
+    int H, Wimg;
+    float focal;
+    const unsigned char* stream;  // fwd2 stage stream
+    unsigned* status;             // range-guard word behind the stream (r2l_fwd2.hip's)
+    const float* params;
+    int n_block;
+    float* rgb;
+    float* save_x;  // training stash (fp16 stage pieces, r2l_f2.h) or nullptr
+    float* save_t;
+    int64_t N;
+};
+
+template <bool POSE, bool SAVE>
+__global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][FC_BOP_BYTES];
+    __shared__ float pts[32][49];  // the tile's 16 x 3 point coordinates per ray (row stride 49: conflict-free column reads)
+    __shared__ float red[4][32][3];
+
+    if (__builtin_nontemporal_load(a.status) != 0u) return;  // these weights left fp16's range before: the bf16x3 kernel behind
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = blockIdx.x;
+    const int64_t Np = R2L_PAD_ROWS(a.N);
+    const int64_t slot = R2L_TRIO_SLOT(Np);
+
+    // ---- the tile's sample points: thread (ray = tid & 31, group = tid >> 5) evaluates coordinates 6 grp .. 6 grp + 5 ----------
+    {
+        const int pr = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        const int64_t ray = tile * R2L_TILE_RAYS + pr;
+        const int64_t rc = ray < a.N ? ray : a.N - 1;
+        float o[3], d[3];
+        if constexpr (!POSE) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o[k] = a.rays_o[rc * 3 + k];
+                d[k] = a.rays_d[rc * 3 + k];
+            }
+        } else {
+            const int pj = (int)(rc / a.Wimg), pi = (int)(rc % a.Wimg);
+            const float dx = ((float)pi - (float)a.Wimg * 0.5f) / a.focal;
+            const float dy = -(((float)pj - (float)a.H * 0.5f) / a.focal);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = (dx * a.c2w[4 * k + 0] + dy * a.c2w[4 * k + 1]) + (-1.0f) * a.c2w[4 * k + 2];
+                o[k] = a.c2w[4 * k + 3];
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int smp = 2 * grp + s2;
+            float z = a.ztab[smp];
+            if (a.t_rand != nullptr) z = z + a.ztab[16 + smp] * a.t_rand[rc * 16 + smp];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pts[pr][3 * smp + k] = o[k] + d[k] * z;  // fl(o + fl(d*z)): -ffp-contract=off
+        }
+    }
+
+    // ---- weight ring: stages 0 .. 3 requested -------------------------------------------------------------------------------
+    FcRing W;
+    FcStream P;
+    {
+        const unsigned long long sa = (unsigned long long)a.stream;
+        P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
+        P.voff = (unsigned)lane * 16u + (unsigned)wave * 2048u;
+        P.g = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < FC_RING; ++k) fc_issue(W.a[k], P);
+    f16x8 ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
+
+    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0];
+    const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;                            // + buf*32768 + kb*2048 (+1024)
+    const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;    // stage 4w of buffer 0
+    float amax = 0.f;
+    __syncthreads();  // pts complete (nothing of the ring is compiler-tracked, so no vmcnt drain here)
+
+    // ---- head: 63 stages of positional-encoding B values, produced four chunks of 16 stages at a time ---------------------------
+    // stage q + 1 (q = 0..62) = chunk q / 16, position kb = q % 16, produced by wave kb / 4.  Values 8q .. 8q+7 of half h:
+    // v < 480: coordinate ci = v / 20 of the half's 24, frequency (v % 20) / 2, (sin, cos) alternating; else identity 24h + (v - 480)
+    auto produce_pe = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 16 * c + 4 * wave + i;
+            if (q > 62) continue;  // (wave-uniform)
+            float v8[8];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const int v = 8 * q + 2 * p2;
+                if (v < 480) {
+                    const int ci = v / 20, f = (v - 20 * ci) >> 1;
+                    const float x = pts[j][24 * h + ci];
+                    r2l_sincos(x * (float)(1 << f), v8[2 * p2], v8[2 * p2 + 1]);
+                } else {
+                    const int e = v - 480;
+                    v8[2 * p2] = pts[j][24 * h + e];
+                    v8[2 * p2 + 1] = pts[j][24 * h + e + 1];
+                }
+            }
+            u32x4 uh, um;
+            fc_split8(v8, uh, um, amax);
+            const unsigned wa = bop_wr + (unsigned)(c & 1) * FC_BOP_BYTES + (unsigned)i * 2048u;
+            fc_lds_write(wa, uh);
+            fc_lds_write(wa + 1024u, um);
+        }
+    };
+    f32x16 x[2], t[2], x0[2];
+    produce_pe(0);
+    fc_barrier();
+    fc_stage<0, true, true>(x, W, P, ones, ones);  // head bias
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < 3) produce_pe(c + 1);  // into the other image (its last readers passed the barrier that closed chunk c - 1)
+        const unsigned rb = bop_rd + (unsigned)(c & 1) * FC_BOP_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            if (c == 3 && kb == 15) continue;
+            const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)kb * 2048u));
+            const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)kb * 2048u + 1024u));
+            if ((kb + 1) % 4 == 0) fc_stage<0, false, false>(x, W, P, bh, bm);
+            else if ((kb + 1) % 4 == 1) fc_stage<1, false, false>(x, W, P, bh, bm);
+            else if ((kb + 1) % 4 == 2) fc_stage<2, false, false>(x, W, P, bh, bm);
+            else fc_stage<3, false, false>(x, W, P, bh, bm);
+        }
+        if (c < 3) fc_barrier();
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            x[tt][c] = fmaxf(x[tt][c], 0.f);  // X_0 = relu(head)
+            x0[tt][c] = x[tt][c];
+        }
+
+    // ---- body: x B operands live in image 0, relu(t) in image 1; a barrier after each production ------------------------------------
+    u32x4* hx = SAVE ? reinterpret_cast<u32x4*>(a.save_x) + tile * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
+    u32x4* ht = SAVE ? reinterpret_cast<u32x4*>(a.save_t) + tile * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
+    unsigned* mwp = SAVE ? reinterpret_cast<unsigned*>(a.save_t + R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) + wave : nullptr;
+    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
+        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
+    // (image 0 was last read in chunk 2 of the head, two barriers ago)
+    fc_produce<false, SAVE, false>(x, bop_wr, hx, nullptr, amax);
+    fc_barrier();
+    auto block = [&](auto ph_tag, bool last) {
+        constexpr int PH = decltype(ph_tag)::value;
+        // t = W1 x + b1
+        fc_layer<PH, true>(t, W, P, bop_rd, ones);
+        unsigned mw = 0u;
+        fc_produce<true, SAVE, SAVE>(t, bop_wr + FC_BOP_BYTES, ht, &mw, amax);
+        if (SAVE) fc_store_b32(mwp, mw);
+        fc_barrier();
+        // x += W2 relu(t) + b2
+        fc_layer<(PH + 1) % 4, false>(x, W, P, bop_rd + FC_BOP_BYTES, ones);
+        if (SAVE) {
+            hx += slot / 4;
+            ht += slot / 4;
+            mwp += slot;
+        }
+        if (!last) {
+            fc_produce<false, SAVE, false>(x, bop_wr, hx, nullptr, amax);
+            fc_barrier();
+        }
+    };
+#pragma unroll 1
+    for (int b = 0; b < a.n_block; b += 2) {
+        block(std::integral_constant<int, 0>{}, b == a.n_block - 1);
+        if (b + 1 < a.n_block) block(std::integral_constant<int, 2>{}, b + 1 == a.n_block - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead loads (stream padding) and the stash stores
+
+    if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+
+    // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt): per-wave partial dot products over its 64 features, summed through LDS ----------
+    const int64_t ray = tile * R2L_TILE_RAYS + j;
+    const float* tw = a.params + cf_off_tail_w(a.n_block) + 4 * h;
+    float p3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int T = 2 * wave + tt;
+            f32x4 wv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
+            f32x4 yv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yv[e] = x[tt][4 * q + e] + x0[tt][4 * q + e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p3[c] = __builtin_fmaf(wv[c][e], yv[e], p3[c]);
+            }
+            // slot n of save_x: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
+            if (SAVE) *reinterpret_cast<f32x4*>(a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 32 * T + 8 * q + 4 * h) = yv;
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p3[c] += __shfl_xor(p3[c], 32);
+    if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) red[wave][j][c] = p3[c];
+    }
+    __syncthreads();
+    if (wave == 0 && h == 0 && ray < a.N) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = ((red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c])) + a.params[cf_off_tail_b(a.n_block) + c];
+            a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
+        }
+    }
+}
+
+int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* c2w_host12,
+                      int H, int W, float focal, const float* wstream2, const float* params, int n_block, float* rgb,
+                      float* save_x, float* save_t, int64_t N, hipStream_t stream) {
+    CfFwdArgs a{};
+    a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
+    a.stream = reinterpret_cast<const unsigned char*>(wstream2); a.params = params;
+    a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + r2l_fwd2_status_offset(n_block));
+    a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
+    if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
+    const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    const dim3 grid((unsigned)tiles), block(256);
+    if (c2w_host12) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false>), grid, block, 0, stream, a);
+    else if (save_x) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false>), grid, block, 0, stream, a);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}

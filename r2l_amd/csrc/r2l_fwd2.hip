@@ -3,6 +3,7 @@
 // 16 KiB ([split 2][tile 8][lane 64][8 fp16]).  Default of every one-wave-per-tile forward launch (render / evaluation and the training forward with its stash);
 // R2L_NO_FWD2=1: bf16x3 only.
 #include "r2l_f2.h"
+#include "r2l_coopf.h"
 
 __host__ __device__ static inline int64_t f2_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
 __host__ __device__ static inline int64_t f2_off_body_w(int layer) {
@@ -335,6 +336,10 @@ int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t
 int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
                      int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream) {
+    // small launches: one 32-ray tile per workgroup instead of per wave (r2l_coopf_fwd.hip), same stream / stash / status word
+    if (r2l_use_coopf(N, n_block))
+        return r2l_coopf_forward(rays_o, rays_d, t_rand, ztab, c2w_host12, H, W, focal, wstream2, params, n_block, rgb, save_x,
+                                 save_t, N, stream);
     F2Args a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.stream = reinterpret_cast<const unsigned char*>(wstream2); a.params = params;

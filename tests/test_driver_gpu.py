@@ -120,7 +120,7 @@ def test_distillation_converges_on_teacher_data(trained_student):
     assert p150 > p0 + 3 and p1000 >= p150 - 0.5
 
 
-VARIANTS = {"main-fp16x2": {"R2L_FORCE_VARIANT": "main"},
+VARIANTS = {"main-fp16x2": {"R2L_FORCE_VARIANT": "main"}, "coopf-fp16x2": {"R2L_FORCE_VARIANT": "coopf"},
             "main-bf16x3": {"R2L_FORCE_VARIANT": "main", "R2L_NO_FWD2": "1"},
             "main-f32mfma": {"R2L_FORCE_VARIANT": "main", "R2L_NO_FWD3": "1"},
             "coop": {"R2L_FORCE_VARIANT": "coop"}, "coop16": {"R2L_FORCE_VARIANT": "coop16"}}

@@ -33,11 +33,15 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     lib = _lib.load()
     for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
         monkeypatch.delenv(k, raising=False)
-    # defaults: 16-ray cooperative kernels up to 4096 rays, one wave per tile (fp16x2, with the bf16x3 stream behind it) above
-    assert lib.r2l_variant_for(4096) == 2 and lib.r2l_variant_for(4097) == 0 and lib.r2l_variant_for(160000) == 0
-    assert lib.r2l_forward_layout_for(4096, 1) == 16
+    # defaults: the fp16 trio everywhere (layout 2 = fp16x2 stages with the bf16x3 stream behind them): its cooperative
+    # kernels (one 32-ray tile per workgroup) up to 16 384 rays, one wave per tile above — both are the MAIN family (0)
+    assert lib.r2l_variant_for(4096) == 0 and lib.r2l_variant_for(16385) == 0 and lib.r2l_variant_for(160000) == 0
+    assert lib.r2l_forward_layout_for(4096, 1) == 2 and lib.r2l_backward_layout_for(4096) == 2
     assert lib.r2l_forward_layout_for(98304, 1) == 2 and lib.r2l_forward_layout_for(160000, 0) == 2
-    assert lib.r2l_backward_layout_for(98304) == 2 and lib.r2l_backward_layout_for(4096) == 16
+    assert lib.r2l_backward_layout_for(98304) == 2
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "coopf")
+    assert lib.r2l_variant_for(98304) == 0 and lib.r2l_forward_layout_for(98304, 1) == 2
+    monkeypatch.delenv("R2L_FORCE_VARIANT")
     # any switch of the fp16 training trio puts the WHOLE step on the bf16x3 trio (one stash format per step); forward-only
     # launches look at R2L_NO_FWD2 alone
     for k in ("R2L_NO_BWD2", "R2L_NO_DW2"):
@@ -48,6 +52,9 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     monkeypatch.setenv("R2L_NO_FWD2", "1")
     assert lib.r2l_forward_layout_for(98304, 1) == 3 and lib.r2l_backward_layout_for(98304) == 3
     assert lib.r2l_forward_layout_for(160000, 0) == 3
+    # without the fp16 trio small launches go to the 16-ray cooperative fp32-MFMA kernels again
+    assert lib.r2l_variant_for(4096) == 2 and lib.r2l_forward_layout_for(4096, 1) == 16 and lib.r2l_backward_layout_for(4096) == 16
+    assert lib.r2l_variant_for(4097) == 0
     monkeypatch.setenv("R2L_NO_FWD3", "1")  # everything on the fp32 MFMA: the small-batch kernels win up to 20 480 rays again
     assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_backward_layout_for(98304) == 32
     assert lib.r2l_variant_for(20480) == 2 and lib.r2l_variant_for(24576) == 0

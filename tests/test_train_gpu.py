@@ -12,12 +12,14 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "main-bf16x3-trio", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "coopf", "main-bf16x3-trio", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
     """Every test runs under each kernel family of the training step:
       main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip) and dX chain (r2l_bwd2.hip) stashing
                        fp16 stage pieces, fp16 weight-gradient GEMMs on them (r2l_dw16.hip); range-guarded, with the bf16x3
                        kernels launched behind them
+      coopf            the same trio with the cooperative chains (r2l_coopf_fwd / _bwd.hip: one 32-ray tile per workgroup; the
+                       default of steps up to 16 384 rays), same stash, same weight-gradient kernels
       main-bf16x3-trio R2L_NO_FWD2 = R2L_NO_BWD2 = R2L_NO_DW2 = 1 (any one of them would do): the whole step on six bf16
                        products per fp32 product and the chunked fp32 stash — exactly the kernels the guards fall back to
       main-f32mfma     R2L_NO_FWD3=1: everything on the exact-fp32 MFMA
@@ -129,7 +131,7 @@ def test_three_adam_steps_vs_oracle(chain_variant):
     for k in ref:
         # Adam's first steps move every weight by ~lr regardless of gradient size; compare on that scale
         diff = (new[k].cpu() - ref[k]).abs()
-        if chain_variant == "main" and not k.startswith("tail"):
+        if chain_variant in ("main", "coopf") and not k.startswith("tail"):
             # default trio: the weight-gradient GEMMs of head and body take fp16-rounded operands (r2l_dw16.hip,
             # r2l_dw_head16.hip).  Each gradient entry is a sum over the rays whose rounding errors average out (per-tensor
             # error ~1e-4 of its max here, 512 rays), but Adam normalises every entry by its own magnitude: the entries whose
