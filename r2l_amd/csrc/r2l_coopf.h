@@ -56,12 +56,13 @@ __device__ __forceinline__ void fc_wait(u32x4 (&a)[4]) {
 __device__ __forceinline__ void fc_barrier() {  // LDS writes of this wave done, then the workgroup barrier (no vmcnt drain)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// stash / ride-along global store the compiler does not track either
+// stash / ride-along global stores the compiler does not track either.  (The hazard recognizer does not look into inline
+// asm: a VALU write to the data registers of a > 64-bit store needs wait states behind it, hence the s_nop.)
 __device__ __forceinline__ void fc_store_nt(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void fc_store_b32(void* p, unsigned v) {
-    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
 }
 
 // acc[2 tiles] (+)= stage: BIAS: one MFMA per tile (bias hi / mid in k slots 0, 1 against ones), else the three products,

@@ -1,5 +1,6 @@
-"""Step / forward time of the chain variants over N (GPU box): which N should switch from the cooperative small-batch
-kernels to the one-wave-per-tile fp16x2 kernels (cost model in r2l_chain_variant, csrc/r2l_common.h)."""
+"""Step / forward time of the chain variants over N (GPU box): which N should switch from the cooperative fp16x2 kernels
+(one tile per workgroup, r2l_coopf) to the one-wave-per-tile ones (R2L_COOPF_MAX_RAYS, csrc/r2l_common.h); the 16-ray
+fp32-MFMA cooperative family for comparison."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,11 +11,11 @@ from r2l_amd.train_step import R2LTrainer, lr_schedule
 
 sd = O.make_state_dict(43, seed=0)
 ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
-for n in (4096, 6144, 8192, 12288, 16384, 20480, 24576, 32768):
+for n in (1024, 4096, 8192, 12288, 16384, 24576, 32768, 49152, 65536):
     g = torch.Generator().manual_seed(1)
     o = (torch.randn(n, 3, generator=g) * 1.5).cuda(); d = torch.randn(n, 3, generator=g).cuda(); t = torch.rand(n, 3, generator=g).cuda()
     line = "N %6d:" % n
-    for var in ("coop16", "coop", "main", None):
+    for var in ("coop16", "coopf", "main", None):
         if var is None:
             os.environ.pop("R2L_FORCE_VARIANT", None)
         else:
