@@ -29,9 +29,10 @@ int r2l_pack_forward(const float* params, int n_block, float* wstream, void* str
 int r2l_pack_backward(const float* params, int n_block, float* wstream_bwd, void* stream);
 /* Per-layout form: layout = 32 (fp32-MFMA one-wave-per-tile and 32-ray cooperative kernels), 16 (16-ray cooperative
  * kernels), 3 (bf16 (hi, mid, lo) stages: r2l_fwd3.hip / r2l_bwd3.hip), 2 (fp16 (hi, mid) stages: r2l_fwd2.hip /
- * r2l_bwd2.hip; fills layout 3 as well, their fallback) or 0 (all parts, =
- * r2l_pack_forward/backward).  r2l_variant_for(N) tells which chain variant a call with N rays will take
- * (0 main, 1 coop: layout 32; 2 coop16: layout 16), honouring R2L_FORCE_VARIANT. */
+ * r2l_bwd2.hip and their cooperative forms r2l_coopf_*.hip; the bf16 stream behind them is their range-guard fallback and
+ * is packed by the fallback launch itself when — and only when — it runs) or 0 (all parts, = r2l_pack_forward/backward).
+ * r2l_variant_for(N) tells which chain variant a call with N rays will take (0 main — incl. the cooperative fp16x2 kernels
+ * of small launches —, 1 coop: layout 32; 2 coop16: layout 16), honouring R2L_FORCE_VARIANT (main | coopf | coop | coop16). */
 int r2l_variant_for(int64_t N);
 int r2l_forward_layout_for(int64_t N, int with_stash); /* 16, 32, 3 = bf16x3 stage stream, 2 = fp16x2 stage stream (+ the
                                                          * bf16x3 one behind it as range-guard fallback) */

@@ -1202,6 +1202,9 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
             const int rc2 = r2l_bwd2_backward(rgb, target, drgb, save_x, save_t, w2, params, n_block, grad_scale, dpre, gx, gt,
                                               sqerr_partial, N, stream, gscale, bwd_status, scale_dev);
             if (rc2) return rc2;
+            // the fallback's stream is packed in front of it, and only when it will run
+            const int rp = r2l_bwd3_pack(params, n_block, const_cast<float*>(w3), stream, bwd_status);
+            if (rp) return rp;
         }
         const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t, w3, params, n_block, grad_scale, dpre, gx, gt,
                                          sqerr_partial, N, stream, gscale, trio16 ? bwd_status : nullptr, scale_dev);
@@ -1258,6 +1261,7 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
         R2LDwHeadArgs a{};
         a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab; a.emb = emb; a.gh = gx; a.grads = grads; a.N = N;
         int64_t slices = n_cu / 4;
+        if (slices > (N + 255) / 256) slices = (N + 255) / 256;  // small launches: >= 256 rays per slice (each slice costs a 1 MB partial)
         if (slices < 1) slices = 1;
         int64_t per = (N + slices - 1) / slices;
         per = (per + 1) & ~(int64_t)1;  // even: a k-step pairs rays 2s, 2s+1

@@ -24,7 +24,9 @@ __host__ __device__ static inline int64_t b3_off_tail_w(int n_block) { return b3
 // pack: stage g = 34 * slot + r, slot = n_block-1-b;  r = 0 / 17: zero stages;  r = 1..16: k-block r-1 of W2^T (layer 2b+1);
 // r = 18..33: k-block r-18 of W1^T (layer 2b).  Element (split, tile t, lane (i,h), slot s): (W^T)[32t+i][feature(kb,h,s)]
 // =================================================================================================================
-__global__ void r2l_pack_bwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
+__global__ void r2l_pack_bwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                     const unsigned* __restrict__ run_if) {
+    if (run_if != nullptr && __builtin_nontemporal_load(run_if) == 0u) return;  // fallback stream: only packed when needed
     const int64_t stages = r2l_bwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -259,9 +261,9 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream) {
+int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if) {
     hipLaunchKernelGGL(r2l_pack_bwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
-                       reinterpret_cast<unsigned short*>(wstream3), n_block);
+                       reinterpret_cast<unsigned short*>(wstream3), n_block, run_if);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

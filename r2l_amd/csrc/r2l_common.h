@@ -391,7 +391,9 @@ __host__ __device__ static inline int64_t r2l_bwd2_status_offset(int n_block) {
     return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (16384 / 4);
 }
 __host__ __device__ static inline int64_t r2l_bwd2_stream_floats(int n_block) { return r2l_bwd2_status_offset(n_block) + 16; }
-int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
+// run_if: nullptr, or a device word — the pack returns at once while it is 0 (the bf16x3 stream as range-guard fallback of the
+// fp16 kernels is packed right in front of the fallback launch, and only when that launch will really run)
+int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if = nullptr);
 int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale = 1.0f,
@@ -419,7 +421,7 @@ int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t
 int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
                      int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
-int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream);
+int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if = nullptr);
 // run_if: nullptr, or a device word — the launch returns at once while it is 0 (fallback behind r2l_fwd2_forward)
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,

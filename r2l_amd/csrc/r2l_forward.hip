@@ -272,9 +272,12 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
         const int rc = r2l_fwd2_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w2, params, n_block, rgb, save_x,
                                         save_t, N, (hipStream_t)stream);
         if (rc) return rc;
-        // range-guard fallback: returns at once unless the fp16x2 launch raised its status word
+        // range-guard fallback: stream pack + launch, both returning at once unless the fp16x2 launch raised its status word
+        const unsigned* st = reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block));
+        const int rp = r2l_fwd3_pack(params, n_block, const_cast<float*>(w3), (hipStream_t)stream, st);
+        if (rp) return rp;
         return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w3, params, n_block, rgb, save_x, save_t, N,
-                                (hipStream_t)stream, reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block)));
+                                (hipStream_t)stream, st);
     }
     if (N > 0 && r2l_use_fwd3())
         return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f,
@@ -304,9 +307,11 @@ extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float foc
         const int rc = r2l_fwd2_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, w2, params, n_block, rgb,
                                         nullptr, nullptr, a.N, (hipStream_t)stream);
         if (rc) return rc;
+        const unsigned* st = reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block));
+        const int rp = r2l_fwd3_pack(params, n_block, const_cast<float*>(w3), (hipStream_t)stream, st);
+        if (rp) return rp;
         return r2l_fwd3_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, w3, params, n_block, rgb, nullptr,
-                                nullptr, a.N, (hipStream_t)stream,
-                                reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block)));
+                                nullptr, a.N, (hipStream_t)stream, st);
     }
     if (a.N > 0 && r2l_use_fwd3())
         return r2l_fwd3_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal,

@@ -38,7 +38,9 @@ __host__ __device__ static inline int64_t f3_off_tail_b(int n_block) { return f3
 //   body k-block kb = 2T + r: feature 32T + 8(2r + (s>>2)) + 4h + (s&3)  — fragment registers 8r .. 8r+7 of tile T.
 //   bias stage: split region 0 only: slots 0,1,2 of half 0 = hi, mid, lo of bias[32t + i]; everything else 0.
 // =================================================================================================================
-__global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
+__global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                     const unsigned* __restrict__ run_if) {
+    if (run_if != nullptr && __builtin_nontemporal_load(run_if) == 0u) return;  // fallback stream: only packed when needed
     const int64_t stages = r2l_fwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -331,9 +333,9 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream) {
+int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if) {
     hipLaunchKernelGGL(r2l_pack_fwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
-                       reinterpret_cast<unsigned short*>(wstream3), n_block);
+                       reinterpret_cast<unsigned short*>(wstream3), n_block, run_if);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -163,7 +163,7 @@ extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* 
                            wstream + r2l_fwd32_stream_floats(n_block), n_block);
         R2L_CHECK(hipGetLastError());
     }
-    if (layout == 0 || layout == 3 || layout == 2) {  // (2: the bf16x3 stream is the range-guard fallback of the fp16x2 one)
+    if (layout == 0 || layout == 3) {  // (layout 2's bf16x3 fallback stream is packed by the fallback launch itself, when it runs)
         const int rc = r2l_fwd3_pack(params, n_block, wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block),
                                      (hipStream_t)stream);
         if (rc) return rc;
@@ -187,7 +187,7 @@ extern "C" int r2l_pack_backward_layout(const float* params, int n_block, float*
                            wstream + r2l_bwd32_stream_floats(n_block), n_block);
         R2L_CHECK(hipGetLastError());
     }
-    if (layout == 0 || layout == 3 || layout == 2) {  // (2: the bf16x3 stream is the range-guard fallback of the fp16x2 one)
+    if (layout == 0 || layout == 3) {  // (layout 2's bf16x3 fallback stream is packed by the fallback launch itself, when it runs)
         const int rc = r2l_bwd3_pack(params, n_block, wstream + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block),
                                      (hipStream_t)stream);
         if (rc) return rc;

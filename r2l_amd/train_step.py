@@ -86,7 +86,7 @@ class R2LTrainer:
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
         ver, layout = eng.version(), self.lib.r2l_backward_layout_for(int(n))  # 16 / 32 / 3 / 2: what r2l_backward will read
-        if self._bwd_packed is None:  # (layout 2 = the fp16x2 stream plus the bf16x3 one behind it)
+        if self._bwd_packed is None:  # (layout 2 = the fp16x2 stream; its bf16x3 fallback stream packs itself when it runs)
             self._bwd_packed = {16: None, 32: None, 3: None, 2: None}
         if self._bwd_packed[layout] != ver:
             _lib.check(self.lib.r2l_pack_backward_layout(_ptr(eng.flat), eng.n_block, _ptr(self.wstream_bwd), layout,
