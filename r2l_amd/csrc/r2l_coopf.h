@@ -12,25 +12,22 @@
 //     2w, 2w+1 ARE, lane for lane, the B operands of stages 4w .. 4w+3 of the next layer (fragment registers c = 8r .. 8r+7 of
 //     tile T = stage 2T + r), so each wave converts its own 32 values per lane to (hi, mid), writes them to the image
 //     [stage][split][lane][16 B] and — training — stores the hi quad as the stash piece; ONE barrier per layer.
-//   * A operands come straight from L2 into a register ring of D = 4 or 8 stages (16 / 32 loads in flight per wave), no LDS:
-//     a wave reads only its own quarter of a stage.  The ring slot of every stage is a compile-time constant: a layer has 17
-//     stages, so the phase advances by one per layer and the body is unrolled over D / 2 blocks (68 / 136 stages).
+//   * A operands come straight from L2 into a four-stage register ring (16 loads in flight per wave), no LDS: a wave reads
+//     only its own quarter of a stage.  The ring slot of every stage is a compile-time constant: a layer has 17 stages, so
+//     the phase advances by one per layer and the body is unrolled over two blocks (68 stages).
 //   * The kernel is bound by that weight stream (256 KiB per layer and workgroup from L2), not by the matrix pipe.
 #pragma once
 #include "r2l_f2.h"
-#include <type_traits>
 
+#define FC_RING 4
 #define FC_BOP_BYTES 32768   // one B-operand image: 16 stages x (hi, mid) x 1 KiB
 
 typedef __attribute__((address_space(3))) u32x4 fc_lds_u32x4;
 __device__ __forceinline__ u32x4 fc_lds_read(unsigned addr) { return *(fc_lds_u32x4*)(size_t)addr; }
 __device__ __forceinline__ void fc_lds_write(unsigned addr, u32x4 v) { *(fc_lds_u32x4*)(size_t)addr = v; }
 
-// D stages x (hi tile 0, hi tile 1, mid tile 0, mid tile 1) of this wave.  D = 4 when two workgroups share a CU (the other
-// one's MFMAs cover the L2 latency), D = 8 for launches of at most one workgroup per CU (nothing else covers it)
-template <int D>
-struct FcRing {
-    u32x4 a[D][4];
+struct FcRing {  // four stages x (hi tile 0, hi tile 1, mid tile 0, mid tile 1) of this wave
+    u32x4 a[FC_RING][4];
 };
 struct FcStream {
     u32x4 rs;       // descriptor of the stage stream
@@ -51,13 +48,10 @@ __device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
     fc_load<1024>(a[3], p.rs, p.voff + 8192u, so);
     ++p.g;
 }
-// the four loads of the oldest stage in flight have landed: D - 1 younger stages (4 loads each) may still fly; vmcnt retires
-// in order, and anything else in the queue (stash stores) only makes the wait stricter
-template <int D>
+// the four loads of the oldest stage in flight have landed: three younger stages (12 loads) may still fly; vmcnt retires in
+// order, and anything else in the queue (stash stores) only makes the wait stricter
 __device__ __forceinline__ void fc_wait(u32x4 (&a)[4]) {
-    static_assert(D == 4 || D == 8, "ring depth");
-    if (D == 4) asm volatile("s_waitcnt vmcnt(12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
-    else asm volatile("s_waitcnt vmcnt(28)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
 }
 __device__ __forceinline__ void fc_barrier() {  // LDS writes of this wave done, then the workgroup barrier (no vmcnt drain)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -73,11 +67,10 @@ __device__ __forceinline__ void fc_store_b32(void* p, unsigned v) {
 
 // acc[2 tiles] (+)= stage: BIAS: one MFMA per tile (bias hi / mid in k slots 0, 1 against ones), else the three products,
 // small terms first.  Then the slot is refilled with the stage four positions ahead.
-template <int SLOT, bool BIAS, bool ZERO, int D>
-__device__ __forceinline__ void fc_stage(f32x16 (&acc)[2], FcRing<D>& W, FcStream& p, const f16x8& bh, const f16x8& bm) {
-    static_assert(SLOT >= 0 && SLOT < D, "ring slot");
+template <int SLOT, bool BIAS, bool ZERO>
+__device__ __forceinline__ void fc_stage(f32x16 (&acc)[2], FcRing& W, FcStream& p, const f16x8& bh, const f16x8& bm) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    fc_wait<D>(W.a[SLOT]);
+    fc_wait(W.a[SLOT]);
     const f16x8 h0 = __builtin_bit_cast(f16x8, W.a[SLOT][0]), h1 = __builtin_bit_cast(f16x8, W.a[SLOT][1]);
     const f16x8 m0 = __builtin_bit_cast(f16x8, W.a[SLOT][2]), m1 = __builtin_bit_cast(f16x8, W.a[SLOT][3]);
     if (BIAS) {
@@ -94,34 +87,19 @@ __device__ __forceinline__ void fc_stage(f32x16 (&acc)[2], FcRing<D>& W, FcStrea
     fc_issue(W.a[SLOT], p);
 }
 
-// stage in the ring slot S % D (S a compile-time stage count)
-template <int S, bool BIAS, bool ZERO, int D>
-__device__ __forceinline__ void fc_stage_at(f32x16 (&acc)[2], FcRing<D>& W, FcStream& p, const f16x8& bh, const f16x8& bm) {
-    fc_stage<S % D, BIAS, ZERO>(acc, W, p, bh, bm);
-}
-template <int PH, int KB, int D>
-__device__ __forceinline__ void fc_kstages(f32x16 (&acc)[2], FcRing<D>& W, FcStream& p, unsigned bop) {
-    if constexpr (KB < 16) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)KB * 2048u));
-        const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)KB * 2048u + 1024u));
-        fc_stage_at<PH + 1 + KB, false, false>(acc, W, p, bh, bm);
-        fc_kstages<PH, KB + 1>(acc, W, p, bop);
-    }
-}
 // One layer: its bias (or zero) stage in ring slot PH, then the 16 k-stages against the B-operand image at `bop`
 // (LDS byte address of this lane's 16 bytes of stage 0, split 0).  ZERO_FIRST: the bias stage initialises acc (C = 0).
-template <int PH, bool ZERO_FIRST, int D>
-__device__ __forceinline__ void fc_layer(f32x16 (&acc)[2], FcRing<D>& W, FcStream& p, unsigned bop, const f16x8& ones) {
-    fc_stage_at<PH, true, ZERO_FIRST>(acc, W, p, ones, ones);
-    fc_kstages<PH, 0>(acc, W, p, bop);
-}
-// the blocks of one trip of the body loop: a layer has 17 stages, so the ring phase advances by 2 per block and returns to 0
-// after D / 2 blocks.  f(phase tag, block index) is called for the blocks b0 .. b0 + D/2 - 1 that exist.
-template <int D, int K = 0, class F>
-__device__ __forceinline__ void fc_block_trip(F& f, int b0, int n_block) {
-    if constexpr (K < D / 2) {
-        if (b0 + K < n_block) f(std::integral_constant<int, (2 * K) % D>{}, b0 + K);
-        fc_block_trip<D, K + 1>(f, b0, n_block);
+template <int PH, bool ZERO_FIRST>
+__device__ __forceinline__ void fc_layer(f32x16 (&acc)[2], FcRing& W, FcStream& p, unsigned bop, const f16x8& ones) {
+    fc_stage<PH, true, ZERO_FIRST>(acc, W, p, ones, ones);
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)kb * 2048u));
+        const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)kb * 2048u + 1024u));
+        if ((PH + 1 + kb) % 4 == 0) fc_stage<0, false, false>(acc, W, p, bh, bm);
+        else if ((PH + 1 + kb) % 4 == 1) fc_stage<1, false, false>(acc, W, p, bh, bm);
+        else if ((PH + 1 + kb) % 4 == 2) fc_stage<2, false, false>(acc, W, p, bh, bm);
+        else fc_stage<3, false, false>(acc, W, p, bh, bm);
     }
 }
 
@@ -165,16 +143,6 @@ __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bop
             if (SAVE) fc_store_nt(hst + 64 * (2 * tt + r), uh);
         }
     if (MASK) *mword = mw;
-}
-
-// CUs of the device (one device type per process)
-static inline int64_t r2l_coopf_cus() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return n_cu;
 }
 
 // launchers (called from r2l_fwd2_forward / r2l_bwd2_backward when the launch is small: r2l_use_coopf)

@@ -38,8 +38,7 @@ struct CfMask {
     __device__ __forceinline__ float operator()(float v, int tt, int c) const { return ((w >> (tt * 16 + c)) & 1u) ? v : 0.f; }
 };
 
-template <int D>
-__global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char bop[2][FC_BOP_BYTES];
     if (__builtin_nontemporal_load(a.fmt) != 0u) {  // the forward's stash is the bf16x3 trio's: so is this step's backward
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_bwd_kernel(cons
             }
     }
 
-    FcRing<D> W;
+    FcRing W;
     FcStream P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_bwd_kernel(cons
         P.g = 0u;
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) fc_issue(W.a[k], P);
+    for (int k = 0; k < FC_RING; ++k) fc_issue(W.a[k], P);
     f16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
@@ -136,11 +135,10 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_bwd_kernel(cons
     // g B operands in image 0, masked-u B operands in image 1; a barrier after each production
     fc_produce<false, true, false>(g, bop_wr, gxh, nullptr, amax);
     fc_barrier();
-    auto block = [&](auto ph_tag, int k) {  // k-th block of the chain = block n_block - 1 - k of the network
+    auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
-        const bool last = k == a.n_block - 1;
         // the forward's mask word: an untracked load like the ring's (a compiler-tracked one would drain vmcnt, i.e. the ring, at
-        // its first use).  It is older than every load of GEMM A, whose last fc_wait leaves only the youngest stages in flight.
+        // its first use).  It is older than every load of GEMM A, whose last fc_wait leaves only the 12 youngest in flight.
         unsigned mw;
         asm volatile("global_load_dword %0, %1, off" : "=&v"(mw) : "v"(mwp) : "memory");
         // GEMM A: u = W2^T g   (zero stage first: u is initialised by C = 0)
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_bwd_kernel(cons
         fc_produce<false, true, false>(u, bop_wr + FC_BOP_BYTES, gth, nullptr, amax, CfMask{mw});
         fc_barrier();
         // GEMM B: g += W1^T (u . mask)
-        fc_layer<PH + 1, false>(g, W, P, bop_rd + FC_BOP_BYTES, ones);
+        fc_layer<(PH + 1) % 4, false>(g, W, P, bop_rd + FC_BOP_BYTES, ones);
         gxh -= slot / 4;
         gth -= slot / 4;
         mwp -= slot;
@@ -159,7 +157,10 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_bwd_kernel(cons
         }
     };
 #pragma unroll 1
-    for (int k = 0; k < a.n_block; k += D / 2) fc_block_trip<D>(block, k, a.n_block);
+    for (int b = a.n_block - 1; b >= 0; b -= 2) {
+        block(std::integral_constant<int, 0>{}, b == 0);
+        if (b - 1 >= 0) block(std::integral_constant<int, 2>{}, b - 1 == 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
@@ -202,8 +203,7 @@ int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb,
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    if (tiles <= r2l_coopf_cus()) hipLaunchKernelGGL(r2l_coopf_bwd_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(r2l_coopf_bwd_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(r2l_coopf_bwd_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -30,19 +30,8 @@ struct CfFwdArgs {
     int64_t N;
 };
 
-// the 15 k-stages of the head's last chunk (ring slots 1 .. 15 mod D)
-template <int KB = 0, int D>
-__device__ __forceinline__ void fc_kstages15(f32x16 (&acc)[2], FcRing<D>& W, FcStream& p, unsigned bop) {
-    if constexpr (KB < 15) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)KB * 2048u));
-        const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)KB * 2048u + 1024u));
-        fc_stage_at<1 + KB, false, false>(acc, W, p, bh, bm);
-        fc_kstages15<KB + 1>(acc, W, p, bop);
-    }
-}
-
-template <bool POSE, bool SAVE, int D>
-__global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
+template <bool POSE, bool SAVE>
+__global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char bop[2][FC_BOP_BYTES];
     __shared__ float pts[32][49];  // the tile's 16 x 3 point coordinates per ray (row stride 49: conflict-free column reads)
     __shared__ float red[4][32][3];
@@ -86,8 +75,8 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(cons
         }
     }
 
-    // ---- weight ring: stages 0 .. D-1 requested -------------------------------------------------------------------------------
-    FcRing<D> W;
+    // ---- weight ring: stages 0 .. 3 requested -------------------------------------------------------------------------------
+    FcRing W;
     FcStream P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
@@ -97,7 +86,7 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(cons
         P.g = 0u;
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) fc_issue(W.a[k], P);
+    for (int k = 0; k < FC_RING; ++k) fc_issue(W.a[k], P);
     f16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
@@ -141,22 +130,22 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(cons
     produce_pe(0);
     fc_barrier();
     fc_stage<0, true, true>(x, W, P, ones, ones);  // head bias
-    auto head_chunk = [&](auto c_tag) {
-        constexpr int c = decltype(c_tag)::value;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
         if (c < 3) produce_pe(c + 1);  // into the other image (its last readers passed the barrier that closed chunk c - 1)
         const unsigned rb = bop_rd + (unsigned)(c & 1) * FC_BOP_BYTES;
-        // stage 16 c + kb + 1 of the stream: ring slot (kb + 1) % D (16 c is a multiple of D)
-        if constexpr (c < 3) {
-            fc_kstages<0, 0>(x, W, P, rb);
-        } else {  // the last chunk has 15 stages (63 in all)
-            fc_kstages15(x, W, P, rb);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            if (c == 3 && kb == 15) continue;
+            const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)kb * 2048u));
+            const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)kb * 2048u + 1024u));
+            if ((kb + 1) % 4 == 0) fc_stage<0, false, false>(x, W, P, bh, bm);
+            else if ((kb + 1) % 4 == 1) fc_stage<1, false, false>(x, W, P, bh, bm);
+            else if ((kb + 1) % 4 == 2) fc_stage<2, false, false>(x, W, P, bh, bm);
+            else fc_stage<3, false, false>(x, W, P, bh, bm);
         }
         if (c < 3) fc_barrier();
-    };
-    head_chunk(std::integral_constant<int, 0>{});
-    head_chunk(std::integral_constant<int, 1>{});
-    head_chunk(std::integral_constant<int, 2>{});
-    head_chunk(std::integral_constant<int, 3>{});
+    }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -174,9 +163,8 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(cons
     // (image 0 was last read in chunk 2 of the head, two barriers ago)
     fc_produce<false, SAVE, false>(x, bop_wr, hx, nullptr, amax);
     fc_barrier();
-    auto block = [&](auto ph_tag, int b) {
+    auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
-        const bool last = b == a.n_block - 1;
         // t = W1 x + b1
         fc_layer<PH, true>(t, W, P, bop_rd, ones);
         unsigned mw = 0u;
@@ -184,7 +172,7 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(cons
         if (SAVE) fc_store_b32(mwp, mw);
         fc_barrier();
         // x += W2 relu(t) + b2
-        fc_layer<PH + 1, false>(x, W, P, bop_rd + FC_BOP_BYTES, ones);
+        fc_layer<(PH + 1) % 4, false>(x, W, P, bop_rd + FC_BOP_BYTES, ones);
         if (SAVE) {
             hx += slot / 4;
             ht += slot / 4;
@@ -196,7 +184,10 @@ __global__ __launch_bounds__(256, D == 4 ? 2 : 1) void r2l_coopf_fwd_kernel(cons
         }
     };
 #pragma unroll 1
-    for (int b = 0; b < a.n_block; b += D / 2) fc_block_trip<D>(block, b, a.n_block);
+    for (int b = 0; b < a.n_block; b += 2) {
+        block(std::integral_constant<int, 0>{}, b == a.n_block - 1);
+        if (b + 1 < a.n_block) block(std::integral_constant<int, 2>{}, b + 1 == a.n_block - 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead loads (stream padding) and the stash stores
 
     if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
@@ -250,18 +241,9 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)tiles), block(256);
-    // at most one workgroup per CU: the deep weight ring (nothing else on the CU covers the L2 latency); else two per CU
-    const bool deep = tiles <= r2l_coopf_cus();
-    if (c2w_host12) {
-        if (deep) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 8>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 4>), grid, block, 0, stream, a);
-    } else if (save_x) {
-        if (deep) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 8>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 4>), grid, block, 0, stream, a);
-    } else {
-        if (deep) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 8>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 4>), grid, block, 0, stream, a);
-    }
+    if (c2w_host12) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false>), grid, block, 0, stream, a);
+    else if (save_x) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false>), grid, block, 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }
