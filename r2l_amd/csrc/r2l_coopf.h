@@ -38,7 +38,8 @@ struct FcStream {
 template <int IMM>
 __device__ __forceinline__ void fc_load(u32x4& dst, u32x4 rs, unsigned voff, unsigned soff) {
     // untracked by the compiler (it would drain vmcnt at every barrier and loop header): consumers wait with fc_wait
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM) : "memory");
+    // (no "memory" clobber: the stream is read-only, and LDS reads of the B operands may be scheduled across it)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM));
 }
 __device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
     const unsigned so = p.g * (unsigned)F2_STAGE_BYTES;
@@ -51,7 +52,7 @@ __device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
 // the four loads of the oldest stage in flight have landed: three younger stages (12 loads) may still fly; vmcnt retires in
 // order, and anything else in the queue (stash stores) only makes the wait stricter
 __device__ __forceinline__ void fc_wait(u32x4 (&a)[4]) {
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 }
 __device__ __forceinline__ void fc_barrier() {  // LDS writes of this wave done, then the workgroup barrier (no vmcnt drain)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -91,11 +92,16 @@ __device__ __forceinline__ void fc_stage(f32x16 (&acc)[2], FcRing& W, FcStream& 
 // (LDS byte address of this lane's 16 bytes of stage 0, split 0).  ZERO_FIRST: the bias stage initialises acc (C = 0).
 template <int PH, bool ZERO_FIRST>
 __device__ __forceinline__ void fc_layer(f32x16 (&acc)[2], FcRing& W, FcStream& p, unsigned bop, const f16x8& ones) {
+    // B operands one stage ahead: the LDS read of stage kb + 1 is in flight under the MFMAs of stage kb
+    u32x4 nh = fc_lds_read(bop), nm = fc_lds_read(bop + 1024u);
     fc_stage<PH, true, ZERO_FIRST>(acc, W, p, ones, ones);
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)kb * 2048u));
-        const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(bop + (unsigned)kb * 2048u + 1024u));
+        const f16x8 bh = __builtin_bit_cast(f16x8, nh), bm = __builtin_bit_cast(f16x8, nm);
+        if (kb < 15) {
+            nh = fc_lds_read(bop + (unsigned)(kb + 1) * 2048u);
+            nm = fc_lds_read(bop + (unsigned)(kb + 1) * 2048u + 1024u);
+        }
         if ((PH + 1 + kb) % 4 == 0) fc_stage<0, false, false>(acc, W, p, bh, bm);
         else if ((PH + 1 + kb) % 4 == 1) fc_stage<1, false, false>(acc, W, p, bh, bm);
         else if ((PH + 1 + kb) % 4 == 2) fc_stage<2, false, false>(acc, W, p, bh, bm);
