@@ -239,6 +239,13 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
         path = ("fp16 trio: forward and dX chain with 3 fp16 MFMA products per fp32 product (two-way operand splits), dW body "
                 "with 1 (fp16 hi operands from the fp16 stash); range-guarded, bf16x3 trio behind it")
         extra = {"peak_if_every_gemm_took_3_products": 2500.0 / 3., "frac_of_3_product_peak": achieved / (2500.0 / 3.)}
+        if n <= 16384:
+            # cooperative chains (r2l_coopf: one 32-ray tile per workgroup): N / 32 workgroups, each streaming the 25 MB of
+            # packed weights per chain from L2 — measured ~45 B/clk per CU, which is what bounds them, not the matrix pipe
+            path += "; chains: cooperative kernels (one tile per workgroup), bound by the L2 weight stream: %d workgroups x " \
+                    "25.1 MB per chain" % ((n + 31) // 32)
+            extra["weight_stream_bytes_per_step"] = 2 * ((n + 31) // 32) * 25.1e6
+
     elif fwd3 and big:
         peak = 2500.0 / 6.
         path = "bf16x3 trio: forward, dX chain and dW body with 6 bf16 products per fp32 product (%s)" % ", ".join(off)
