@@ -12,8 +12,7 @@
 // A pair is (sin, cos) of one frequency of one point coordinate — one r2l_sincos evaluation feeds both of the lane's B
 // operands — or two identity columns (pairs 480 .. 503), or padding (504 .. 511): pair P = 128 kq + 32 w + m, tile 0 holds
 // the pair's first column, tile 1 its second.  One k-step = 16 rays: lane (m, kg) supplies, for rays 8 kg .. 8 kg + 7 of the
-// step, Gh[ray][8 m + e] (A operands of the eight tiles e = 0..7: output row 8 m + e, i.e. two 16-byte loads per ray and a full
-// 1 KiB row per half-wave) and its pair's two encoding values (B operands).
+// step, Gh[ray][32 e + m] (A operands, e = 0..7: coalesced 128-byte rows) and its pair's two encoding values (B operands).
 // The kernel is VALU-bound (the encoding), not matrix-bound.  Rows past the end of a slice are out-of-range buffer loads
 // (zero fill): no tails, no predicates.  Per-slice partials go to the slab and are added in slice order by
 // r2l_head_reduce_kernel, like the fp32 kernel's.
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
         for (int ei = 0; ei < 2; ++ei)
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[e][ei][c] = 0.f;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dbh partials (kq == 0, wave 0): row 8 m + e, this lane's rays
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dbh partials (kq == 0, wave 0): row 32 e + m, this lane's rays
 
     // raw buffers over the slice's rows: loads past its last ray return zero (the range check sees voffset + immediate, which
     // is why the k-step advance is added to the VGPR offsets, not passed as a scalar offset)
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     const h16_rsrc_t ors = h16_rsrc(a.rays_o + r0 * 3, (unsigned)nrays * 12u);
     const h16_rsrc_t drs = h16_rsrc(a.rays_d + r0 * 3, (unsigned)nrays * 12u);
     const h16_rsrc_t urs = h16_rsrc(JITTER ? a.t_rand + r0 * 16 : a.rays_o, JITTER ? (unsigned)nrays * 64u : 0u);
-    unsigned vg = (unsigned)((8 * kg * R2L_W + 8 * m) * 4);      // Gh[8kg + i][8 m + e], e = 0..7: + i*1024 (+16)
+    unsigned vg = (unsigned)((8 * kg * R2L_W + m) * 4);          // Gh[8kg + i][32 e + m]: + i*1024 + e*128
     unsigned vp0 = (unsigned)((8 * kg * 3 + pc.ax_a) * 4), vp1 = (unsigned)((8 * kg * 3 + pc.ax_b) * 4);     // + i*12
     unsigned vu0 = (unsigned)((8 * kg * 16 + pc.smp_a) * 4), vu1 = (unsigned)((8 * kg * 16 + pc.smp_b) * 4);  // + i*64
     const int nsteps = (nrays + 15) / 16;
@@ -104,15 +103,11 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     // the k-step the offsets point at, then advance them by 16 rays
     auto ld_g = [&](Head16G& v) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {  // two 16-byte loads per ray: the lane's 8 consecutive features (tile e = feature 8 m + e)
-            const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(grs, vg + (unsigned)(i * 1024), 0, 0);
-            const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(grs, vg + (unsigned)(i * 1024 + 16), 0, 0);
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v.g[e][i] = __builtin_bit_cast(float, lo[e]);
-                v.g[4 + e][i] = __builtin_bit_cast(float, hi[e]);
-            }
-        }
+            for (int e = 0; e < 8; ++e)
+                v.g[e][i] = (i < 4) ? h16_load(grs, vg, (unsigned)(i * 1024 + e * 128))
+                                    : h16_load(grs, vg + 4096u, (unsigned)((i - 4) * 1024 + e * 128));
         vg += 16u * R2L_W * 4u;
     };
     auto ld_rays = [&](Head16Rays& v) {
@@ -179,24 +174,24 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
             acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[e], b1, acc[e][1], 0, 0, 0);
         }
     }
-    // flush: D row rr = 8 (c>>2) + 4 kg + (c&3) of tile e -> output row o = 8 rr + e; column = the pair's ka (tile 0) / kb (tile 1)
+    // flush: D row 8 (c>>2) + 4 kg + (c&3) of tile e -> output row o = 32 e + that; column = the pair's ka (tile 0) / kb (tile 1)
     float* sl = a.slab ? a.slab + slice * (int64_t)(R2L_W * 1024) : nullptr;
 #pragma unroll
     for (int ei = 0; ei < 2; ++ei) {
         const int k = ei == 0 ? pc.ka : pc.kb;  // the real column of this lane's tile-ei values
         if (k < 0) continue;                    // padding pairs
         if (sl) {
-            float* p = sl + (8 * 4 * kg) * 1024 + k;
+            float* p = sl + (4 * kg) * 1024 + k;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) p[(8 * (8 * (c >> 2) + (c & 3)) + e) * 1024] = acc[e][ei][c] * unscale;
+                for (int c = 0; c < 16; ++c) p[(32 * e + 8 * (c >> 2) + (c & 3)) * 1024] = acc[e][ei][c] * unscale;
         } else {
-            float* p = a.grads + (int64_t)(8 * 4 * kg) * R2L_IN + k;
+            float* p = a.grads + (int64_t)(4 * kg) * R2L_IN + k;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) atomicAdd(p + (8 * (8 * (c >> 2) + (c & 3)) + e) * R2L_IN, acc[e][ei][c] * unscale);
+                for (int c = 0; c < 16; ++c) atomicAdd(p + (32 * e + 8 * (c >> 2) + (c & 3)) * R2L_IN, acc[e][ei][c] * unscale);
         }
     }
     if (kq == 0 && wave == 0) {
@@ -204,8 +199,8 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
         for (int e = 0; e < 8; ++e) {
             const float s = bsum[e] + __shfl_xor(bsum[e], 32);
             if (kg == 0) {
-                if (sl) sl[(8 * m + e) * 1024 + R2L_IN] = s;  // the slab row's padding column 1008 carries the bias partial
-                else atomicAdd(a.grads + b_off_head_b() + 8 * m + e, s);
+                if (sl) sl[(32 * e + m) * 1024 + R2L_IN] = s;  // the slab row's padding column 1008 carries the bias partial
+                else atomicAdd(a.grads + b_off_head_b() + 32 * e + m, s);
             }
         }
     }
