@@ -4,7 +4,8 @@
 // The one-wave-per-tile kernels (r2l_fwd2 / r2l_bwd2) need 32 768 rays to occupy the 1024 SIMDs, and every workgroup streams
 // the whole 25 MB of packed weights for its 128 rays.  Here the FOUR waves of a workgroup share ONE 32-ray tile: wave w owns
 // output tiles 2w, 2w+1 (64 of the 256 features) of every layer, so 4096 rays already give 128 workgroups x 4 waves and a
-// step of <= 8192 rays is one round.  Everything else is the fp16 trio's: the same packed stage streams (16 KiB stages,
+// step of <= 8192 rays is one round.  From 8192 rays on a workgroup takes NT = 2 ray tiles (64 rays) that share every
+// weight load: half the L2 stream per ray.  Everything else is the fp16 trio's: the same packed stage streams (16 KiB stages,
 // [split][tile][lane][8 fp16]; a wave reads the four 1 KiB pieces of its two tiles), the same 32x32x16 MFMA fragments, three
 // fp16 products per fp32 product, the same fp16 stage-piece stash, mask words and range-guard protocol — so r2l_dw16 /
 // r2l_dw_head16 and the bf16x3 fallbacks serve these launches unchanged.
@@ -21,6 +22,16 @@
 
 #define FC_RING 4
 #define FC_BOP_BYTES 32768   // one B-operand image: 16 stages x (hi, mid) x 1 KiB
+// Dynamic LDS added to every one-tile launch (64 - 72 KiB static) so that a CU never holds TWO of these workgroups.  Measured
+// (round 2, tools/coopf_coresidency.py): with two workgroups of the training forward (236 - 252 VGPRs: the two waves of a SIMD
+// own 480 - 512 of its 512 registers) on one CU, the tail's packed-FMA chain returned wrong red partial sums in lanes 48 - 63
+// of the older workgroup (rays 16 - 31 of its tile, 1 - 60 tiles per launch, every launch of 16 384 rays) although its inputs
+// (stash, weights) were bit-exact and a recomputation in the same kernel was right; the render forward (206 VGPRs) and the
+// dX chain (184) were exact under the same co-residency.  Not understood; avoided: one workgroup per CU (what these launches
+// are anyway: <= one tile per CU, see r2l_coopf_two_tiles), two-tile workgroups (143 KiB) cannot share a CU at all.
+// (R2L_COOPF_SHARE_CU=1 drops the padding: the reproducer's switch, nothing else uses it.)
+#define FC_SOLO_LDS_BYTES 24576
+static inline unsigned r2l_coopf_solo_lds() { return r2l_env_on("R2L_COOPF_SHARE_CU") ? 0u : (unsigned)FC_SOLO_LDS_BYTES; }
 
 typedef __attribute__((address_space(3))) u32x4 fc_lds_u32x4;
 __device__ __forceinline__ u32x4 fc_lds_read(unsigned addr) { return *(fc_lds_u32x4*)(size_t)addr; }
@@ -66,41 +77,66 @@ __device__ __forceinline__ void fc_store_b32(void* p, unsigned v) {
     asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
 }
 
-// acc[2 tiles] (+)= stage: BIAS: one MFMA per tile (bias hi / mid in k slots 0, 1 against ones), else the three products,
-// small terms first.  Then the slot is refilled with the stage four positions ahead.
-template <int SLOT, bool BIAS, bool ZERO>
-__device__ __forceinline__ void fc_stage(f32x16 (&acc)[2], FcRing& W, FcStream& p, const f16x8& bh, const f16x8& bm) {
+// acc[ray tile][2 feature tiles] (+)= stage: BIAS: one MFMA per tile (bias hi / mid in k slots 0, 1 against ones), else the three
+// products, small terms first; the NT ray tiles of the workgroup share the A operands.  Then the slot is refilled with the
+// stage four positions ahead.
+template <int SLOT, bool BIAS, bool ZERO, int NT>
+__device__ __forceinline__ void fc_stage(f32x16 (&acc)[NT][2], FcRing& W, FcStream& p, const f16x8 (&bh)[NT], const f16x8 (&bm)[NT]) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     fc_wait(W.a[SLOT]);
     const f16x8 h0 = __builtin_bit_cast(f16x8, W.a[SLOT][0]), h1 = __builtin_bit_cast(f16x8, W.a[SLOT][1]);
     const f16x8 m0 = __builtin_bit_cast(f16x8, W.a[SLOT][2]), m1 = __builtin_bit_cast(f16x8, W.a[SLOT][3]);
     if (BIAS) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh, ZERO ? zero : acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh, ZERO ? zero : acc[1], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh[rt], ZERO ? zero : acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh[rt], ZERO ? zero : acc[rt][1], 0, 0, 0);
+        }
     } else {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m0, bh, ZERO ? zero : acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m1, bh, ZERO ? zero : acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bm, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bm, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh, acc[1], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m0, bh[rt], ZERO ? zero : acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(m1, bh[rt], ZERO ? zero : acc[rt][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bm[rt], acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bm[rt], acc[rt][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, bh[rt], acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, bh[rt], acc[rt][1], 0, 0, 0);
+        }
     }
     fc_issue(W.a[SLOT], p);
 }
 
-// One layer: its bias (or zero) stage in ring slot PH, then the 16 k-stages against the B-operand image at `bop`
-// (LDS byte address of this lane's 16 bytes of stage 0, split 0).  ZERO_FIRST: the bias stage initialises acc (C = 0).
-template <int PH, bool ZERO_FIRST>
-__device__ __forceinline__ void fc_layer(f32x16 (&acc)[2], FcRing& W, FcStream& p, unsigned bop, const f16x8& ones) {
-    // B operands one stage ahead: the LDS read of stage kb + 1 is in flight under the MFMAs of stage kb
-    u32x4 nh = fc_lds_read(bop), nm = fc_lds_read(bop + 1024u);
-    fc_stage<PH, true, ZERO_FIRST>(acc, W, p, ones, ones);
+// One layer: its bias (or zero) stage in ring slot PH, then the 16 k-stages against the B-operand images at `bop` + rt *
+// FC_BOP_BYTES (LDS byte address of this lane's 16 bytes of stage 0, split 0, ray tile 0).  ZERO_FIRST: the bias stage
+// initialises acc (C = 0).  B operands are read one stage ahead.
+template <int PH, bool ZERO_FIRST, int NT>
+__device__ __forceinline__ void fc_layer(f32x16 (&acc)[NT][2], FcRing& W, FcStream& p, unsigned bop, const f16x8& ones) {
+    u32x4 nh[NT], nm[NT];
+    f16x8 o1[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        nh[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES);
+        nm[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + 1024u);
+        o1[rt] = ones;
+    }
+    fc_stage<PH, true, ZERO_FIRST>(acc, W, p, o1, o1);
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb) {
-        const f16x8 bh = __builtin_bit_cast(f16x8, nh), bm = __builtin_bit_cast(f16x8, nm);
-        if (kb < 15) {
-            nh = fc_lds_read(bop + (unsigned)(kb + 1) * 2048u);
-            nm = fc_lds_read(bop + (unsigned)(kb + 1) * 2048u + 1024u);
+        f16x8 bh[NT], bm[NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            bh[rt] = __builtin_bit_cast(f16x8, nh[rt]);
+            bm[rt] = __builtin_bit_cast(f16x8, nm[rt]);
+            if (kb < 15) {
+                nh[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + (unsigned)(kb + 1) * 2048u);
+                nm[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + (unsigned)(kb + 1) * 2048u + 1024u);
+            }
         }
         if ((PH + 1 + kb) % 4 == 0) fc_stage<0, false, false>(acc, W, p, bh, bm);
         else if ((PH + 1 + kb) % 4 == 1) fc_stage<1, false, false>(acc, W, p, bh, bm);
@@ -149,6 +185,20 @@ __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bop
             if (SAVE) fc_store_nt(hst + 64 * (2 * tt + r), uh);
         }
     if (MASK) *mword = mw;
+}
+
+// ray tiles per workgroup: 1 while that keeps the launch within one workgroup per CU, else 2 (R2L_COOPF_TILES=1|2 overrides)
+static inline bool r2l_coopf_two_tiles(int64_t tiles) {
+    if (const char* e = getenv("R2L_COOPF_TILES")) {
+        if (e[0] == '1') return false;
+        if (e[0] == '2') return true;
+    }
+    static int n_cu = 0;  // one device type per process
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return tiles > n_cu;
 }
 
 // launchers (called from r2l_fwd2_forward / r2l_bwd2_backward when the launch is small: r2l_use_coopf)

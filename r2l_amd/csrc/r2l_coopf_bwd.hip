@@ -38,8 +38,10 @@ struct CfMask {
     __device__ __forceinline__ float operator()(float v, int tt, int c) const { return ((w >> (tt * 16 + c)) & 1u) ? v : 0.f; }
 };
 
-__global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][FC_BOP_BYTES];
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
+    // B-operand images: [g | masked u][ray tile][16 stages x (hi, mid) x 1 KiB]
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
     if (__builtin_nontemporal_load(a.fmt) != 0u) {  // the forward's stash is the bf16x3 trio's: so is this step's backward
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
         return;
@@ -48,63 +50,80 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a
     const float ginv = a.scale_dev != nullptr ? a.scale_dev[1] : a.ginv;
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t tile = blockIdx.x;
-    const int64_t ray = tile * R2L_TILE_RAYS + j;
-    const bool valid = ray < a.N;
-    const int64_t rc = valid ? ray : a.N - 1;
+    const int64_t n_tiles = (a.N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    // ray tiles of this workgroup; one past the end (odd tile count, NT = 2) recomputes the last live tile (same values to the
+    // same addresses)
+    int64_t tile[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        tile[rt] = (int64_t)blockIdx.x * NT + rt;
+        if (tile[rt] > n_tiles - 1) tile[rt] = n_tiles - 1;
+    }
     const int64_t Np = R2L_PAD_ROWS(a.N);
     const int64_t slot = R2L_TRIO_SLOT(Np);
+    const float* tw = a.params + cb_off_tail_w(a.n_block);
 
     // ---- loss gradient through the sigmoid, per-tile squared error (every wave computes it; wave 0 writes) -------------------
-    float dp[3], se = 0.f;
+    float dp[NT][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float r = a.rgb[rc * 3 + c];
-        float dl;
-        if (a.target != nullptr) {
-            const float e = r - a.target[rc * 3 + c];
-            se += e * e;
-            dl = a.grad_scale * e;
-        } else {
-            dl = a.drgb[rc * 3 + c];
+    for (int rt = 0; rt < NT; ++rt) {
+        const int64_t ray = tile[rt] * R2L_TILE_RAYS + j;
+        const bool valid = ray < a.N;
+        const int64_t rc = valid ? ray : a.N - 1;
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float r = a.rgb[rc * 3 + c];
+            float dl;
+            if (a.target != nullptr) {
+                const float e = r - a.target[rc * 3 + c];
+                se += e * e;
+                dl = a.grad_scale * e;
+            } else {
+                dl = a.drgb[rc * 3 + c];
+            }
+            dp[rt][c] = valid ? dl * (r * (1.0f - r)) : 0.f;
         }
-        dp[c] = valid ? dl * (r * (1.0f - r)) : 0.f;
+        if (!valid) se = 0.f;
+        if (wave == 0) {
+            if (valid && h == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.dpre[ray * 3 + c] = dp[rt][c];
+            }
+            if (a.sqerr_partial != nullptr) {
+                float s = (h == 0) ? se : 0.f;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+                if (lane == 0) a.sqerr_partial[tile[rt]] = s;
+            }
+        }
     }
-    if (!valid) se = 0.f;
-    if (wave == 0) {
-        if (valid && h == 0) {
+    // dy = Wt^T dpre (tail Linear(256,3)): register c = 4q + e of this wave's output tile tt
+    auto tail_t = [&](int rt, int tt, int q, f32x4& out) {
+        const int T = 2 * wave + tt;
+        f32x4 wv[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) a.dpre[ray * 3 + c] = dp[c];
-        }
-        if (a.sqerr_partial != nullptr) {
-            float s = (h == 0) ? se : 0.f;
+        for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0) a.sqerr_partial[tile] = s;
+        for (int e = 0; e < 4; ++e) {
+            float v = wv[0][e] * (dp[rt][0] * gscale);
+            v = __builtin_fmaf(wv[1][e], dp[rt][1] * gscale, v);
+            v = __builtin_fmaf(wv[2][e], dp[rt][2] * gscale, v);
+            out[e] = v;
         }
-    }
-    // g = dy = Wt^T dpre (tail Linear(256,3)): this wave's 64 features
-    f32x16 g[2], u[2], dy[2];
-    {
-        const float* tw = a.params + cb_off_tail_w(a.n_block);
+    };
+    f32x16 g[NT][2], u[NT][2];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int T = 2 * wave + tt;
-                f32x4 wv[3];
+                f32x4 v;
+                tail_t(rt, tt, q, v);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = wv[0][e] * (dp[0] * gscale);
-                    v = __builtin_fmaf(wv[1][e], dp[1] * gscale, v);
-                    v = __builtin_fmaf(wv[2][e], dp[2] * gscale, v);
-                    g[tt][4 * q + e] = v;
-                    dy[tt][4 * q + e] = v;
-                }
+                for (int e = 0; e < 4; ++e) g[rt][tt][4 * q + e] = v[e];
             }
-    }
 
     FcRing W;
     FcStream P;
@@ -120,39 +139,56 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a
     f16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
-    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0];
+    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
+    constexpr unsigned KIND = NT * FC_BOP_BYTES;
     const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;
     const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;
     float amax = 0.f;
 
     // stash bases of this lane / wave (fp16 stage pieces 4w .. 4w+3 of the tile) and the forward's mask word of the wave
-    const int64_t unit0 = tile * R2L_H16_TILE_UNITS + lane + 256 * wave;
-    u32x4* gxh = reinterpret_cast<u32x4*>(a.gx + (int64_t)a.n_block * slot) + unit0;        // slot b + 1 of block b = n_block - 1
-    u32x4* gth = reinterpret_cast<u32x4*>(a.gt + (int64_t)(a.n_block - 1) * slot) + unit0;
-    const unsigned* mwp = reinterpret_cast<const unsigned*>(a.save_t + (int64_t)(a.n_block - 1) * slot + R2L_MASK_OFFSET(Np) +
-                                                            tile * 256 + lane * 4) + wave;
+    u32x4* gxh[NT];
+    u32x4* gth[NT];
+    const unsigned* mwp[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        const int64_t unit0 = tile[rt] * R2L_H16_TILE_UNITS + lane + 256 * wave;
+        gxh[rt] = reinterpret_cast<u32x4*>(a.gx + (int64_t)a.n_block * slot) + unit0;  // slot b + 1 of block b = n_block - 1
+        gth[rt] = reinterpret_cast<u32x4*>(a.gt + (int64_t)(a.n_block - 1) * slot) + unit0;
+        mwp[rt] = reinterpret_cast<const unsigned*>(a.save_t + (int64_t)(a.n_block - 1) * slot + R2L_MASK_OFFSET(Np) +
+                                                    tile[rt] * 256 + lane * 4) + wave;
+    }
 
-    // g B operands in image 0, masked-u B operands in image 1; a barrier after each production
-    fc_produce<false, true, false>(g, bop_wr, gxh, nullptr, amax);
+    // g B operands in the kind-0 images, masked-u B operands in the kind-1 images; a barrier after each production
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) fc_produce<false, true, false>(g[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, gxh[rt], nullptr, amax);
     fc_barrier();
     auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
-        // the forward's mask word: an untracked load like the ring's (a compiler-tracked one would drain vmcnt, i.e. the ring, at
-        // its first use).  It is older than every load of GEMM A, whose last fc_wait leaves only the 12 youngest in flight.
-        unsigned mw;
-        asm volatile("global_load_dword %0, %1, off" : "=&v"(mw) : "v"(mwp) : "memory");
+        // the forward's mask words: untracked loads like the ring's (a compiler-tracked one would drain vmcnt, i.e. the ring, at
+        // its first use).  They are older than every load of GEMM A, whose last fc_wait leaves only the 12 youngest in flight.
+        unsigned mw[NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) asm volatile("global_load_dword %0, %1, off" : "=&v"(mw[rt]) : "v"(mwp[rt]) : "memory");
         // GEMM A: u = W2^T g   (zero stage first: u is initialised by C = 0)
         fc_layer<PH, true>(u, W, P, bop_rd, ones);
-        asm volatile("" : "+v"(mw));  // (uses of mw stay behind GEMM A)
-        fc_produce<false, true, false>(u, bop_wr + FC_BOP_BYTES, gth, nullptr, amax, CfMask{mw});
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            asm volatile("" : "+v"(mw[rt]));  // (uses of mw stay behind GEMM A)
+            fc_produce<false, true, false>(u[rt], bop_wr + KIND + (unsigned)rt * FC_BOP_BYTES, gth[rt], nullptr, amax, CfMask{mw[rt]});
+        }
         fc_barrier();
         // GEMM B: g += W1^T (u . mask)
-        fc_layer<(PH + 1) % 4, false>(g, W, P, bop_rd + FC_BOP_BYTES, ones);
-        gxh -= slot / 4;
-        gth -= slot / 4;
-        mwp -= slot;
+        fc_layer<(PH + 1) % 4, false>(g, W, P, bop_rd + KIND, ones);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            gxh[rt] -= slot / 4;
+            gth[rt] -= slot / 4;
+            mwp[rt] -= slot;
+        }
         if (!last) {
-            fc_produce<false, true, false>(g, bop_wr, gxh, nullptr, amax);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+                fc_produce<false, true, false>(g[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, gxh[rt], nullptr, amax);
             fc_barrier();
         }
     };
@@ -166,10 +202,12 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a
     if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
 
     // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0], row-major fp32 (the head weight gradient reads rows) -----
-    {
+    // (dy recomputed: the same operations on the same values as the chain's seed)
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
         // x_0's fp16 stage pieces (slot 0 of save_x): stage kb = 2T + r holds fragment registers c = 8r .. 8r+7 of tile T
-        const u32x4* r = reinterpret_cast<const u32x4*>(a.save_x) + tile * R2L_H16_TILE_UNITS + lane;
-        float* o = a.gx + ray * R2L_W + 4 * h;
+        const u32x4* r = reinterpret_cast<const u32x4*>(a.save_x) + tile[rt] * R2L_H16_TILE_UNITS + lane;
+        float* o = a.gx + (tile[rt] * R2L_TILE_RAYS + j) * R2L_W + 4 * h;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -178,11 +216,12 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_bwd_kernel(const CfBwdArgs a
                 const f16x8 xv = __builtin_bit_cast(f16x8, r[64 * (2 * T + rr)]);
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
-                    f32x4 ov;
+                    f32x4 dyv, ov;
+                    tail_t(rt, tt, 2 * rr + q2, dyv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int c = 8 * rr + 4 * q2 + e;
-                        ov[e] = (float)xv[4 * q2 + e] > 0.f ? (g[tt][c] + dy[tt][c]) * ginv : 0.f;
+                        ov[e] = (float)xv[4 * q2 + e] > 0.f ? (g[rt][tt][c] + dyv[e]) * ginv : 0.f;
                     }
                     *reinterpret_cast<f32x4*>(o + 32 * T + 8 * (2 * rr + q2)) = ov;
                 }
@@ -203,7 +242,8 @@ int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb,
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    hipLaunchKernelGGL(r2l_coopf_bwd_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    if (r2l_coopf_two_tiles(tiles)) hipLaunchKernelGGL(r2l_coopf_bwd_kernel<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(r2l_coopf_bwd_kernel<1>, dim3((unsigned)tiles), dim3(256), r2l_coopf_solo_lds(), stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -30,23 +30,33 @@ struct CfFwdArgs {
     int64_t N;
 };
 
-template <bool POSE, bool SAVE>
-__global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][FC_BOP_BYTES];
-    __shared__ float pts[32][49];  // the tile's 16 x 3 point coordinates per ray (row stride 49: conflict-free column reads)
-    __shared__ float red[4][32][3];
+template <bool POSE, bool SAVE, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
+    // B-operand images: [x | relu(t)][ray tile][16 stages x (hi, mid) x 1 KiB]
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
+    __shared__ float pts[NT * 32][49];  // the tiles' 16 x 3 point coordinates per ray (row stride 49: conflict-free column reads)
+    __shared__ float red[4][NT * 32][3];
 
     if (__builtin_nontemporal_load(a.status) != 0u) return;  // these weights left fp16's range before: the bf16x3 kernel behind
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t tile = blockIdx.x;
+    const int64_t n_tiles = (a.N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
+    // ray tiles of this workgroup; one past the end (odd tile count, NT = 2) recomputes the last live tile: identical values
+    // to identical addresses, nothing in the chain is conditional
+    int64_t tile[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        tile[rt] = (int64_t)blockIdx.x * NT + rt;
+        if (tile[rt] > n_tiles - 1) tile[rt] = n_tiles - 1;
+    }
     const int64_t Np = R2L_PAD_ROWS(a.N);
     const int64_t slot = R2L_TRIO_SLOT(Np);
 
-    // ---- the tile's sample points: thread (ray = tid & 31, group = tid >> 5) evaluates coordinates 6 grp .. 6 grp + 5 ----------
-    {
+    // ---- the tiles' sample points: thread (ray = tid & 31, group = tid >> 5) evaluates coordinates 6 grp .. 6 grp + 5 ----------
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
         const int pr = threadIdx.x & 31, grp = threadIdx.x >> 5;
-        const int64_t ray = tile * R2L_TILE_RAYS + pr;
+        const int64_t ray = tile[rt] * R2L_TILE_RAYS + pr;
         const int64_t rc = ray < a.N ? ray : a.N - 1;
         float o[3], d[3];
         if constexpr (!POSE) {
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a
             float z = a.ztab[smp];
             if (a.t_rand != nullptr) z = z + a.ztab[16 + smp] * a.t_rand[rc * 16 + smp];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pts[pr][3 * smp + k] = o[k] + d[k] * z;  // fl(o + fl(d*z)): -ffp-contract=off
+            for (int k = 0; k < 3; ++k) pts[rt * 32 + pr][3 * smp + k] = o[k] + d[k] * z;  // fl(o + fl(d*z)): -ffp-contract=off
         }
     }
 
@@ -91,9 +101,10 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
 
-    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0];
-    const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;                            // + buf*32768 + kb*2048 (+1024)
-    const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;    // stage 4w of buffer 0
+    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
+    constexpr unsigned KIND = NT * FC_BOP_BYTES;                                        // x images -> relu(t) images
+    const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;                            // + kind*KIND + rt*32768 + kb*2048 (+1024)
+    const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;    // stage 4w of x image 0
     float amax = 0.f;
     __syncthreads();  // pts complete (nothing of the ring is compiler-tracked, so no vmcnt drain here)
 
@@ -102,43 +113,54 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a
     // v < 480: coordinate ci = v / 20 of the half's 24, frequency (v % 20) / 2, (sin, cos) alternating; else identity 24h + (v - 480)
     auto produce_pe = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = 16 * c + 4 * wave + i;
-            if (q > 62) continue;  // (wave-uniform)
-            float v8[8];
+        for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-            for (int p2 = 0; p2 < 4; ++p2) {
-                const int v = 8 * q + 2 * p2;
-                if (v < 480) {
-                    const int ci = v / 20, f = (v - 20 * ci) >> 1;
-                    const float x = pts[j][24 * h + ci];
-                    r2l_sincos(x * (float)(1 << f), v8[2 * p2], v8[2 * p2 + 1]);
-                } else {
-                    const int e = v - 480;
-                    v8[2 * p2] = pts[j][24 * h + e];
-                    v8[2 * p2 + 1] = pts[j][24 * h + e + 1];
+            for (int i = 0; i < 4; ++i) {
+                const int q = 16 * c + 4 * wave + i;
+                if (q > 62) continue;  // (wave-uniform)
+                float v8[8];
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const int v = 8 * q + 2 * p2;
+                    if (v < 480) {
+                        const int ci = v / 20, f = (v - 20 * ci) >> 1;
+                        const float x = pts[rt * 32 + j][24 * h + ci];
+                        r2l_sincos(x * (float)(1 << f), v8[2 * p2], v8[2 * p2 + 1]);
+                    } else {
+                        const int e = v - 480;
+                        v8[2 * p2] = pts[rt * 32 + j][24 * h + e];
+                        v8[2 * p2 + 1] = pts[rt * 32 + j][24 * h + e + 1];
+                    }
                 }
+                u32x4 uh, um;
+                fc_split8(v8, uh, um, amax);
+                const unsigned wa = bop_wr + (unsigned)(c & 1) * KIND + (unsigned)rt * FC_BOP_BYTES + (unsigned)i * 2048u;
+                fc_lds_write(wa, uh);
+                fc_lds_write(wa + 1024u, um);
             }
-            u32x4 uh, um;
-            fc_split8(v8, uh, um, amax);
-            const unsigned wa = bop_wr + (unsigned)(c & 1) * FC_BOP_BYTES + (unsigned)i * 2048u;
-            fc_lds_write(wa, uh);
-            fc_lds_write(wa + 1024u, um);
-        }
     };
-    f32x16 x[2], t[2], x0[2];
+    f32x16 x[NT][2], t[NT][2], x0[NT][2];
     produce_pe(0);
     fc_barrier();
-    fc_stage<0, true, true>(x, W, P, ones, ones);  // head bias
+    {
+        f16x8 o1[NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) o1[rt] = ones;
+        fc_stage<0, true, true>(x, W, P, o1, o1);  // head bias
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (c < 3) produce_pe(c + 1);  // into the other image (its last readers passed the barrier that closed chunk c - 1)
-        const unsigned rb = bop_rd + (unsigned)(c & 1) * FC_BOP_BYTES;
+        if (c < 3) produce_pe(c + 1);  // into the other images (their last readers passed the barrier that closed chunk c - 1)
+        const unsigned rb = bop_rd + (unsigned)(c & 1) * KIND;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
             if (c == 3 && kb == 15) continue;
-            const f16x8 bh = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)kb * 2048u));
-            const f16x8 bm = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)kb * 2048u + 1024u));
+            f16x8 bh[NT], bm[NT];
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) {
+                bh[rt] = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)rt * FC_BOP_BYTES + (unsigned)kb * 2048u));
+                bm[rt] = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)rt * FC_BOP_BYTES + (unsigned)kb * 2048u + 1024u));
+            }
             if ((kb + 1) % 4 == 0) fc_stage<0, false, false>(x, W, P, bh, bm);
             else if ((kb + 1) % 4 == 1) fc_stage<1, false, false>(x, W, P, bh, bm);
             else if ((kb + 1) % 4 == 2) fc_stage<2, false, false>(x, W, P, bh, bm);
@@ -147,39 +169,55 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a
         if (c < 3) fc_barrier();
     }
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            x[tt][c] = fmaxf(x[tt][c], 0.f);  // X_0 = relu(head)
-            x0[tt][c] = x[tt][c];
-        }
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                x[rt][tt][c] = fmaxf(x[rt][tt][c], 0.f);  // X_0 = relu(head)
+                x0[rt][tt][c] = x[rt][tt][c];
+            }
 
-    // ---- body: x B operands live in image 0, relu(t) in image 1; a barrier after each production ------------------------------------
-    u32x4* hx = SAVE ? reinterpret_cast<u32x4*>(a.save_x) + tile * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
-    u32x4* ht = SAVE ? reinterpret_cast<u32x4*>(a.save_t) + tile * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
-    unsigned* mwp = SAVE ? reinterpret_cast<unsigned*>(a.save_t + R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) + wave : nullptr;
+    // ---- body: x B operands live in the kind-0 images, relu(t) in the kind-1 images; a barrier after each production ----------------
+    u32x4* hx[NT];
+    u32x4* ht[NT];
+    unsigned* mwp[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        hx[rt] = SAVE ? reinterpret_cast<u32x4*>(a.save_x) + tile[rt] * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
+        ht[rt] = SAVE ? reinterpret_cast<u32x4*>(a.save_t) + tile[rt] * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
+        mwp[rt] = SAVE ? reinterpret_cast<unsigned*>(a.save_t + R2L_MASK_OFFSET(Np) + tile[rt] * 256 + lane * 4) + wave : nullptr;
+    }
     if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
         reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
-    // (image 0 was last read in chunk 2 of the head, two barriers ago)
-    fc_produce<false, SAVE, false>(x, bop_wr, hx, nullptr, amax);
+    // (the kind-0 images were last read in chunk 2 of the head, two barriers ago)
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax);
     fc_barrier();
     auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
         // t = W1 x + b1
         fc_layer<PH, true>(t, W, P, bop_rd, ones);
-        unsigned mw = 0u;
-        fc_produce<true, SAVE, SAVE>(t, bop_wr + FC_BOP_BYTES, ht, &mw, amax);
-        if (SAVE) fc_store_b32(mwp, mw);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            unsigned mw = 0u;
+            fc_produce<true, SAVE, SAVE>(t[rt], bop_wr + KIND + (unsigned)rt * FC_BOP_BYTES, ht[rt], &mw, amax);
+            if (SAVE) fc_store_b32(mwp[rt], mw);
+        }
         fc_barrier();
         // x += W2 relu(t) + b2
-        fc_layer<(PH + 1) % 4, false>(x, W, P, bop_rd + FC_BOP_BYTES, ones);
+        fc_layer<(PH + 1) % 4, false>(x, W, P, bop_rd + KIND, ones);
         if (SAVE) {
-            hx += slot / 4;
-            ht += slot / 4;
-            mwp += slot;
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) {
+                hx[rt] += slot / 4;
+                ht[rt] += slot / 4;
+                mwp[rt] += slot;
+            }
         }
         if (!last) {
-            fc_produce<false, SAVE, false>(x, bop_wr, hx, nullptr, amax);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax);
             fc_barrier();
         }
     };
@@ -193,39 +231,47 @@ __global__ __launch_bounds__(256, 2) void r2l_coopf_fwd_kernel(const CfFwdArgs a
     if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt): per-wave partial dot products over its 64 features, summed through LDS ----------
-    const int64_t ray = tile * R2L_TILE_RAYS + j;
     const float* tw = a.params + cf_off_tail_w(a.n_block) + 4 * h;
-    float p3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int rt = 0; rt < NT; ++rt) {
+        const int64_t ray = tile[rt] * R2L_TILE_RAYS + j;
+        float p3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int T = 2 * wave + tt;
-            f32x4 wv[3];
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
-            f32x4 yv;
+            for (int q = 0; q < 4; ++q) {
+                const int T = 2 * wave + tt;
+                f32x4 wv[3];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                yv[e] = x[tt][4 * q + e] + x0[tt][4 * q + e];
+                for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
+                f32x4 yv;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) p3[c] = __builtin_fmaf(wv[c][e], yv[e], p3[c]);
+                for (int e = 0; e < 4; ++e) {
+                    yv[e] = x[rt][tt][4 * q + e] + x0[rt][tt][4 * q + e];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p3[c] = __builtin_fmaf(wv[c][e], yv[e], p3[c]);
+                }
+                // slot n of save_x: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
+                if (SAVE) *reinterpret_cast<f32x4*>(a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 32 * T + 8 * q + 4 * h) = yv;
             }
-            // slot n of save_x: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
-            if (SAVE) *reinterpret_cast<f32x4*>(a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 32 * T + 8 * q + 4 * h) = yv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p3[c] += __shfl_xor(p3[c], 32);
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[wave][rt * 32 + j][c] = p3[c];
         }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) p3[c] += __shfl_xor(p3[c], 32);
-    if (h == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) red[wave][j][c] = p3[c];
     }
     __syncthreads();
-    if (wave == 0 && h == 0 && ray < a.N) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = ((red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c])) + a.params[cf_off_tail_b(a.n_block) + c];
-            a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
+    for (int rt = 0; rt < NT; ++rt) {
+        const int64_t ray = tile[rt] * R2L_TILE_RAYS + j;
+        if (wave == 0 && h == 0 && ray < a.N) {
+            const int rj = rt * 32 + j;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = ((red[0][rj][c] + red[1][rj][c]) + (red[2][rj][c] + red[3][rj][c])) + a.params[cf_off_tail_b(a.n_block) + c];
+                a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
+            }
         }
     }
 }
@@ -240,10 +286,19 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
     a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    const dim3 grid((unsigned)tiles), block(256);
-    if (c2w_host12) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false>), grid, block, 0, stream, a);
-    else if (save_x) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false>), grid, block, 0, stream, a);
+    // up to one workgroup per CU: one ray tile each; beyond, two tiles per workgroup share every weight load
+    const bool two = r2l_coopf_two_tiles(tiles);
+    const dim3 grid((unsigned)(two ? (tiles + 1) / 2 : tiles)), block(256);
+    if (c2w_host12) {
+        if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 1>), grid, block, r2l_coopf_solo_lds(), stream, a);
+    } else if (save_x) {
+        if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 1>), grid, block, r2l_coopf_solo_lds(), stream, a);
+    } else {
+        if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 1>), grid, block, r2l_coopf_solo_lds(), stream, a);
+    }
     R2L_CHECK(hipGetLastError());
     return 0;
 }

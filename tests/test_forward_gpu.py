@@ -10,14 +10,18 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coopf", "main-bf16x3", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "coopf", "coopf2", "main-bf16x3", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
     """Every test runs under each forward kernel family: one wave per tile on the fp16x2 matrix path (r2l_fwd2.hip, the
     default of forward-only launches), on the bf16x3 path (r2l_fwd3.hip, R2L_NO_FWD2=1) and on the fp32 MFMA
     (r2l_forward.hip, R2L_NO_FWD3=1), the cooperative fp16x2 kernels (r2l_coopf_fwd.hip: one tile per workgroup, the default
     of small launches) and the two cooperative fp32-MFMA small-batch families."""
     name = request.param
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name.rstrip("2"))
+    if name == "coopf2":  # two ray tiles per workgroup (what launches of more than one tile per CU take)
+        monkeypatch.setenv("R2L_COOPF_TILES", "2")
+    else:
+        monkeypatch.delenv("R2L_COOPF_TILES", raising=False)
     if name == "main-f32mfma":
         monkeypatch.setenv("R2L_NO_FWD3", "1")
     else:

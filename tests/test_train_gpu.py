@@ -12,7 +12,7 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coopf", "main-bf16x3-trio", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "coopf", "coopf2", "main-bf16x3-trio", "main-f32mfma", "coop", "coop16"])
 def chain_variant(request, monkeypatch):
     """Every test runs under each kernel family of the training step:
       main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip) and dX chain (r2l_bwd2.hip) stashing
@@ -20,14 +20,18 @@ def chain_variant(request, monkeypatch):
                        kernels launched behind them
       coopf            the same trio with the cooperative chains (r2l_coopf_fwd / _bwd.hip: one 32-ray tile per workgroup; the
                        default of steps up to 16 384 rays), same stash, same weight-gradient kernels
+      coopf2           coopf with two ray tiles per workgroup forced (R2L_COOPF_TILES=2: what launches of more than one tile
+                       per CU take)
       main-bf16x3-trio R2L_NO_FWD2 = R2L_NO_BWD2 = R2L_NO_DW2 = 1 (any one of them would do): the whole step on six bf16
                        products per fp32 product and the chunked fp32 stash — exactly the kernels the guards fall back to
       main-f32mfma     R2L_NO_FWD3=1: everything on the exact-fp32 MFMA
       coop / coop16    the cooperative small-batch families."""
     name = request.param
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name)
-    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name.rstrip("2"))
+    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_COOPF_TILES"):
         monkeypatch.delenv(k, raising=False)
+    if name == "coopf2":
+        monkeypatch.setenv("R2L_COOPF_TILES", "2")
     if name == "main-f32mfma":
         monkeypatch.setenv("R2L_NO_FWD3", "1")
     if name == "main-bf16x3-trio":
@@ -131,7 +135,7 @@ def test_three_adam_steps_vs_oracle(chain_variant):
     for k in ref:
         # Adam's first steps move every weight by ~lr regardless of gradient size; compare on that scale
         diff = (new[k].cpu() - ref[k]).abs()
-        if chain_variant in ("main", "coopf") and not k.startswith("tail"):
+        if chain_variant in ("main", "coopf", "coopf2") and not k.startswith("tail"):
             # default trio: the weight-gradient GEMMs of head and body take fp16-rounded operands (r2l_dw16.hip,
             # r2l_dw_head16.hip).  Each gradient entry is a sum over the rays whose rounding errors average out (per-tensor
             # error ~1e-4 of its max here, 512 rays), but Adam normalises every entry by its own magnitude: the entries whose
@@ -321,3 +325,40 @@ def test_fp16_range_guards_in_training():
     for k in sd:
         assert torch.isfinite(grads[k]).all(), k
         assert rel_err(grads[k], gref[k]) < 2e-3, (k, rel_err(grads[k], gref[k]))
+
+
+def test_coopf_two_tiles_bitwise(chain_variant, monkeypatch):
+    """Two ray tiles per workgroup (r2l_coopf_*: NT = 2) share the weight loads and nothing else: rgb, loss and every gradient
+    of a step are bit-for-bit those of one tile per workgroup — on an odd, ragged tile count of MORE tiles than CUs (the last
+    workgroup's second tile re-does the last live tile; the one-tile launch has to keep its workgroups on separate CUs,
+    csrc/r2l_coopf.h FC_SOLO_LDS_BYTES), several launches each — and within rounding of the one-wave-per-tile kernels."""
+    if chain_variant != "coopf":
+        pytest.skip("one comparison")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=43, seed=0)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    n = 32 * 387 - 7
+    g = torch.Generator().manual_seed(5)
+    o = (torch.randn(n, 3, generator=g) * 1.5).cuda(); d = torch.randn(n, 3, generator=g).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda(); tr = torch.rand(n, 16, generator=g).cuda()
+
+    def run():
+        m = build_model(sd, 43)
+        t = R2LTrainer(m, ps)
+        rgb = t.forward_backward(o, d, tgt, perturb=1.0, t_rand=tr)
+        return t.loss_out.clone(), rgb.clone(), t.grads.clone()
+
+    monkeypatch.setenv("R2L_COOPF_TILES", "2")
+    ref = run()
+    assert ref[2].abs().max().item() > 0
+    for tiles in ("1", "2", "1", "1"):
+        monkeypatch.setenv("R2L_COOPF_TILES", tiles)
+        out = run()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b), tiles
+    monkeypatch.delenv("R2L_COOPF_TILES")
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main")
+    out = run()
+    assert (out[1] - ref[1]).abs().max().item() < 2e-6
+    assert torch.nn.functional.cosine_similarity(out[2], ref[2], dim=0).item() > 0.9999

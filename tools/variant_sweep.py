@@ -1,6 +1,6 @@
 """Step / forward time of the chain variants over N (GPU box): which N should switch from the cooperative fp16x2 kernels
 (one tile per workgroup, r2l_coopf) to the one-wave-per-tile ones (R2L_COOPF_MAX_RAYS, csrc/r2l_common.h); the 16-ray
-fp32-MFMA cooperative family for comparison."""
+fp32-MFMA cooperative family for comparison (R2L_FORCE_VARIANT=coop16 by hand); coopf/1, coopf/2 = ray tiles per workgroup."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,15 +11,18 @@ from r2l_amd.train_step import R2LTrainer, lr_schedule
 
 sd = O.make_state_dict(43, seed=0)
 ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
-for n in (1024, 4096, 8192, 12288, 16384, 24576, 32768, 49152, 65536):
+for n in (1024, 4096, 8192, 8224, 12288, 16384, 24576, 32768, 49152, 65536, 98304):
     g = torch.Generator().manual_seed(1)
     o = (torch.randn(n, 3, generator=g) * 1.5).cuda(); d = torch.randn(n, 3, generator=g).cuda(); t = torch.rand(n, 3, generator=g).cuda()
     line = "N %6d:" % n
-    for var in ("coop16", "coopf", "main", None):
+    for var in ("coopf/1", "coopf/2", "main", None):
+        os.environ.pop("R2L_COOPF_TILES", None)
         if var is None:
             os.environ.pop("R2L_FORCE_VARIANT", None)
         else:
-            os.environ["R2L_FORCE_VARIANT"] = var
+            os.environ["R2L_FORCE_VARIANT"] = var.split("/")[0]
+            if "/" in var:
+                os.environ["R2L_COOPF_TILES"] = var.split("/")[1]
         m = build_model(sd, 43)
         tr = R2LTrainer(m, ps)
         for i in range(3):
