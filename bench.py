@@ -217,6 +217,10 @@ def plan_launch(gpus, env, n_visible, argv=None, free_port=None):
     if world != gpus:
         raise SystemExit("bench.py: --gpus %d but launched with WORLD_SIZE=%d" % (gpus, world))
     local_world = int(env.get("LOCAL_WORLD_SIZE", world))
+    if env.get("R2L_BENCH_SHARED_GPU_TEST") == "1":
+        # test hook (tests/test_multirank_gpu.py): every rank on cuda:0 over gloo, to walk the N > 1 code of this file on a
+        # one-GPU box; the line it prints says so and is not a measurement
+        return ("run", world, int(env.get("RANK", "0")), 0)
     if n_visible < local_world:
         raise SystemExit("bench.py: %d local rank(s) but only %d GPU(s) are visible" % (local_world, n_visible))
     return ("run", world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")))
@@ -245,7 +249,11 @@ def main():
     rccl_ranks = 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        shared_gpu_test = os.environ.get("R2L_BENCH_SHARED_GPU_TEST") == "1"
+        if shared_gpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         # the rank count is MEASURED: a SUM all-reduce of ones over RCCL must return --gpus on every rank
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)
@@ -396,6 +404,8 @@ def main():
         # parity spot check of the benchmarked kernel against the CPU baseline output (same pose, same seeded weights: the GPU
         # frame was rendered before the training legs moved them)
         out["parity_max_abs_err_vs_cpu"] = (rgb_gpu_check[rows] - rgb_cpu).abs().max().item()
+    if distributed and shared_gpu_test:
+        out["shared_gpu_test"] = "ranks share ONE GPU over gloo (R2L_BENCH_SHARED_GPU_TEST=1): a walk through the N > 1 code, not a measurement"
     if rank == 0:
         print(json.dumps(out))
     if distributed:

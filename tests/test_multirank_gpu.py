@@ -87,3 +87,27 @@ def test_two_ranks_train_like_one_process(tmp_path, variant):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("ok: max |param") == 2  # (the two ranks' lines may interleave)
     print(r.stdout[-400:])
+
+
+def test_bench_two_ranks_walk(tmp_path):
+    """bench.py's N > 1 code (process group, barrier-bracketed timing with MAX over ranks, frames sharded over ranks,
+    weak / strong / 4096-ray training legs through the bucketed all-reduce, pose-sharded teacher leg, rank-0-only line) run
+    as TWO ranks on this one GPU over gloo (R2L_BENCH_SHARED_GPU_TEST=1): the line must carry n_gpus 2, the measured rank
+    count 2, the legs of a distributed run and the label that it is not a measurement."""
+    import json
+    env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
+    env.update(MASTER_ADDR="127.0.0.1", R2L_BENCH_SHARED_GPU_TEST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and "shared_gpu_test" in out
+    assert out["value"] > 0 and out["config"]["parallelism"].startswith("frames sharded across 2")
+    for leg in ("train", "train_strong", "train_4096", "teacher"):
+        assert leg in out, leg
+    assert out["train_strong"]["scaling"] == "strong" and out["train_strong"]["global_rays_per_step"] == 98304
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
