@@ -179,6 +179,31 @@ class _FrameWriter:
         self.pool.shutdown()
 
 
+def save_video(rgbs, logger, expid, iter_, tag, rank=0, world=1, device=None):
+    """`video_<expid>_iter<k>_<tag>` of main.py:1096-1097 / 1483-1484 from the frames render_path returned (this rank's
+    poses[rank::world]; with world > 1 the ranks' frames are gathered to rank 0 and re-interleaved).  Container: Motion-JPEG
+    AVI instead of the reference's mp4 (video.py says why).  Returns the path on rank 0, None elsewhere."""
+    from .video import write_mjpeg_avi
+    frames = to8b(rgbs) if rgbs.numel() else np.zeros((0, 0, 0, 3), np.uint8)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, frames)
+        if rank != 0:
+            return None
+        total = sum(p.shape[0] for p in parts)
+        hw = next(p.shape[1:] for p in parts if p.shape[0])
+        allf = np.zeros((total,) + tuple(hw), np.uint8)
+        for r, p in enumerate(parts):
+            allf[r::world] = p
+        frames_np = allf
+    else:
+        frames_np = frames
+    path = os.path.join(logger.gen_img_path, "video_%s_iter%s_%s.avi" % (expid, iter_, tag))
+    os.makedirs(logger.gen_img_path, exist_ok=True)
+    write_mjpeg_avi(path, frames_np, fps=30, quality=8)
+    return path
+
+
 def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, savedir=None, rank=0, world=1):
     """Render poses[rank::world]; returns (rgbs [n,H,W,3], misc with test_loss/test_psnr/test_psnr_v2 over ALL frames)
     and test_ssim — the R2L branch of main.py:189-398 (LPIPS/FLIP need network weights / packages that are absent: out
@@ -297,10 +322,12 @@ def main(argv=None):
                                      rank=rank, world=world)
         n_rays = rgbs.shape[0] * H * W if rgbs.numel() else 0
         dt = time.time() - t_
-        logger.info("Rendered %d frames (%d rays) in %.2fs on rank 0 = %.0f rays/s incl. I/O; frames in %s "
-                    "(mp4 muxing needs imageio/ffmpeg, absent on this image)" %
-                    (rgbs.shape[0], n_rays, dt, n_rays / max(dt, 1e-9), logger.gen_img_path))
-        return {"misc": misc, "rgbs": rgbs, "logger": logger}
+        logger.info("Rendered %d frames (%d rays) in %.2fs on rank %d = %.0f rays/s incl. I/O; frames in %s" %
+                    (rgbs.shape[0], n_rays, dt, rank, n_rays / max(dt, 1e-9), logger.gen_img_path))
+        video_path = None
+        if not args.render_test:
+            video_path = save_video(rgbs, logger, expid, iter_, args.video_tag, rank, world, device)
+        return {"misc": misc, "rgbs": rgbs, "logger": logger, "video_path": video_path}
 
     if args.benchmark:
         # torch.utils.benchmark.Timer('render_func(model, pose)').timeit(100) in the reference (main.py:1124-1133)
@@ -374,6 +401,14 @@ def main(argv=None):
                         "TrainHistPSNR %.4f LR %.8f Time %.1fs" %
                         (i, misc["test_psnr"].item(), misc["test_psnr_v2"].item(), misc["test_ssim"].item(), best_psnr,
                          best_psnr_step, hist_psnr, lr, time.time() - t_))
+        if i % args.i_video == 0:
+            # test: using novel poses (main.py:1473-1484)
+            logger.info("Iter %d Rendering video... (n_pose: %d)" % (i, len(video_poses)))
+            t_ = time.time()
+            rgbs, _ = render_path(video_poses, model, point_sampler, device, logger, rank=rank, world=world)
+            path = save_video(rgbs, logger, logger.ExpID, i, args.video_tag, rank, world, device)
+            if rank == 0:
+                logger.info('Iter %d Save video: "%s" (time: %.2fs)' % (i, path, time.time() - t_))
         if i % args.i_weights == 0 and rank == 0:
             name = "ckpt_%d.tar" % i if args.save_intermediate_models else "ckpt.tar"
             path = save_ckpt(os.path.join(logger.weights_path, name), i, model, trainer.optimizer_state_dict(lr),

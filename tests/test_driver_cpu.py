@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import r2l_oracle as O
@@ -61,6 +62,46 @@ def test_render_only_cpu_plumbing(tmp_path, monkeypatch):
     pts = O.sample_test(dirs, O.z_vals(16, 2., 6.), poses[i_split[2][0]][:3, :4])
     ref = O.r2l_forward(net.state_dict(), O.positional_embed(pts, 10)).view(6, 6, 3)
     assert (rgbs[0] - ref).abs().max().item() < 1e-5
+    # --render_only without --render_test: the novel-pose video (main.py:1080-1099); Motion-JPEG AVI here (r2l_amd/video.py)
+    out = driver.main(common + ["--pretrained_ckpt", ck, "--render_only", "--n_pose_video", "5"])
+    assert out["rgbs"].shape == (5, 6, 6, 3)
+    assert os.path.basename(out["video_path"]).startswith("video_") and out["video_path"].endswith("_pose5.avi")
+    from r2l_amd.video import read_mjpeg_avi
+    from r2l_amd.metrics import to8b
+    frames, fps = read_mjpeg_avi(out["video_path"])
+    assert frames.shape == (5, 6, 6, 3) and fps == 30
+    assert np.abs(frames.astype(np.int32) - to8b(out["rgbs"]).astype(np.int32)).mean() < 12  # (JPEG of 6x6 noise-like frames)
+
+
+def test_mjpeg_avi_round_trip(tmp_path):
+    """RIFF structure of the video writer: header fields, index entries pointing at the frame chunks, frames decodable and
+    close to the input at the reference's quality setting (imageio quality=8)."""
+    import struct
+    from r2l_amd.video import read_mjpeg_avi, write_mjpeg_avi
+    yy, xx = np.mgrid[0:48, 0:64]
+    frames = np.stack([np.stack([(xx * 3 + 7 * k) % 256, (yy * 4) % 256, (xx + yy + 9 * k) % 256], -1).astype(np.uint8)
+                       for k in range(4)])
+    path = str(tmp_path / "v.avi")
+    n = write_mjpeg_avi(path, frames, fps=30, quality=8)
+    data = open(path, "rb").read()
+    assert n == len(data) and data[:4] == b"RIFF" and struct.unpack("<I", data[4:8])[0] == len(data) - 8
+    assert data[8:12] == b"AVI " and data[12:16] == b"LIST" and data[20:24] == b"hdrl" and data[24:28] == b"avih"
+    us, _, _, flags, total, _, streams, _, w, h = struct.unpack("<10I", data[32:72])
+    assert (us, flags, total, streams, w, h) == (33333, 0x10, 4, 1, 64, 48)
+    movi = data.index(b"movi")
+    idx = data.index(b"idx1")
+    assert struct.unpack("<I", data[idx + 4:idx + 8])[0] == 16 * 4
+    for k in range(4):
+        cc, fl, off, size = struct.unpack("<4sIII", data[idx + 8 + 16 * k:idx + 24 + 16 * k])
+        assert cc == b"00dc" and fl == 0x10
+        assert data[movi + off:movi + off + 4] == b"00dc" and struct.unpack("<I", data[movi + off + 4:movi + off + 8])[0] == size
+        assert data[movi + off + 8:movi + off + 10] == b"\xff\xd8"  # a JPEG starts here
+    out, fps = read_mjpeg_avi(path)
+    assert out.shape == frames.shape and fps == 30
+    mse = ((out.astype(np.float64) - frames) ** 2).mean()
+    assert 10 * np.log10(255. ** 2 / mse) > 30
+    with pytest.raises(ValueError):
+        write_mjpeg_avi(path, frames.astype(np.float32))
 
 
 def test_hard_ray_pool(golden_dir):
