@@ -27,8 +27,10 @@
 // own 480 - 512 of its 512 registers) on one CU, the tail's packed-FMA chain returned wrong red partial sums in lanes 48 - 63
 // of the older workgroup (rays 16 - 31 of its tile, 1 - 60 tiles per launch, every launch of 16 384 rays) although its inputs
 // (stash, weights) were bit-exact and a recomputation in the same kernel was right; the render forward (206 VGPRs) and the
-// dX chain (184) were exact under the same co-residency.  Not understood; avoided: one workgroup per CU (what these launches
-// are anyway: <= one tile per CU, see r2l_coopf_two_tiles), two-tile workgroups (143 KiB) cannot share a CU at all.
+// dX chain (184) were exact under the same co-residency.  Not the register allocation (the render kernel padded to 256 VGPRs
+// stays exact); gone when the tail's packed-FMA chain is broken up by empty asm barriers, yet the same instruction pattern
+// is bit-exact in other multi-wave kernels: not understood.  Avoided structurally: one workgroup per CU (what
+// these launches are anyway: <= one tile per CU, see r2l_coopf_two_tiles); two-tile workgroups (143 KiB) cannot share a CU.
 // (R2L_COOPF_SHARE_CU=1 drops the padding: the reproducer's switch, nothing else uses it.)
 #define FC_SOLO_LDS_BYTES 24576
 static inline unsigned r2l_coopf_solo_lds() { return r2l_env_on("R2L_COOPF_SHARE_CU") ? 0u : (unsigned)FC_SOLO_LDS_BYTES; }
