@@ -16,16 +16,39 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(512) void stress(unsigned* bad, float* sink, int iters, int mfma_mask, int lds_bytes_touch) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lds_bytes_touch) lds[threadIdx.x] = 0.f;
+    if (lds_bytes_touch > 0) lds[threadIdx.x] = 0.f;
     if ((mfma_mask >> wave) & 1) {  // this wave keeps the matrix pipe busy
         f32x16 acc = {};
         f16x8 a, b;
         for (int k = 0; k < 8; ++k) { a[k] = (_Float16)(0.001f * (lane + k)); b[k] = (_Float16)(0.002f * (lane - k)); }
+        if (lds_bytes_touch < 0) {
+            // ... the way the cooperative chain does: A operands streaming in from L2 (16 B per lane, several loads in
+            // flight), B operands from LDS, MFMAs on both
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* src = reinterpret_cast<const u32x4*>(sink) + lane;
+            u32x4* l = reinterpret_cast<u32x4*>(lds) + (threadIdx.x & 255);
+            *l = u32x4{1u, 2u, 3u, 4u};
+            for (int i = 0; i < iters; ++i) {
+                u32x4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(src + 64 * ((i * 4 + u) & 1023));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const u32x4 bb = *(volatile u32x4*)(l + 0);
+                    a = __builtin_bit_cast(f16x8, w[u]);
+                    b = __builtin_bit_cast(f16x8, bb);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+                }
+            }
+            if (acc[0] == 12345.f) sink[0] = acc[3];
+            return;
+        }
         for (int i = 0; i < iters; ++i) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
         }
-        sink[blockIdx.x * 512 + threadIdx.x] = acc[0] + acc[15];
+        if (acc[0] == 12345.f) sink[0] = acc[3];
         return;
     }
     float w0a = 0.37f + 0.001f * lane, w1a = -0.21f + 0.002f * lane, w0b = 0.11f - 0.003f * lane, w1b = 0.05f + 0.004f * lane;
@@ -70,17 +93,21 @@ int main(int argc, char** argv) {
     float* sink;
     hipMalloc(&bad, 16);
     hipMalloc(&sink, 4096 * 512 * 4);
+    hipMemset(sink, 0, 4096 * 512 * 4);
     struct { const char* name; int grid, mask, lds; } cfg[] = {
         {"1 block/CU, all VALU waves (2 per SIMD)", 256, 0x00, 0},
         {"1 block/CU, waves 4-7 issue MFMAs (1 VALU + 1 MFMA wave per SIMD)", 256, 0xF0, 0},
         {"4 blocks/CU, all VALU waves (8 per SIMD)", 1024, 0x00, 0},
         {"4 blocks/CU, half the waves issue MFMAs", 1024, 0xF0, 0},
         {"2 blocks/CU held apart by 72 KiB LDS each, half MFMA", 512, 0xF0, 72 * 1024},
+        {"1 block/CU, waves 4-7: L2 loads + LDS reads + MFMAs (the chain's mix)", 256, 0xF0, -1},
+        {"2 blocks/CU, waves 4-7: L2 loads + LDS reads + MFMAs", 512, 0xF0, -1},
+        {"2 blocks/CU, waves 1,3,5,7: L2 loads + LDS reads + MFMAs", 512, 0xAA, -1},
     };
     for (auto& c : cfg) {
         hipMemset(bad, 0, 16);
         hipFuncSetAttribute((const void*)stress, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(stress, dim3(c.grid), dim3(512), c.lds ? c.lds : 2048, 0, bad, sink, iters, c.mask, c.lds);
+        hipLaunchKernelGGL(stress, dim3(c.grid), dim3(512), c.lds > 0 ? c.lds : 4096, 0, bad, sink, iters, c.mask, c.lds);
         hipError_t e = hipDeviceSynchronize();
         unsigned h[4];
         hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost);
