@@ -34,6 +34,10 @@ int r2l_pack_backward(const float* params, int n_block, float* wstream_bwd, void
  * r2l_variant_for(N) tells which chain variant a call with N rays will take (0 main — incl. the cooperative fp16x2 kernels
  * of small launches —, 1 coop: layout 32; 2 coop16: layout 16), honouring R2L_FORCE_VARIANT (main | coopf | coop | coop16). */
 int r2l_variant_for(int64_t N);
+/* Within the fp16 trio (layout 2): 0 = the one-wave-per-tile chains serve a launch of N rays, 1 / 2 = the cooperative chains
+ * with that many 32-ray tiles per workgroup (<= 16 384 rays, and 32 769 .. 49 152 rays: csrc/r2l_common.h r2l_use_coopf;
+ * R2L_FORCE_VARIANT=main|coopf and R2L_COOPF_TILES=1|2 pin it).  Results do not depend on the choice beyond rounding. */
+int r2l_coop_tiles_for(int64_t N, int n_block);
 int r2l_forward_layout_for(int64_t N, int with_stash); /* 16, 32, 3 = bf16x3 stage stream, 2 = fp16x2 stage stream (+ the
                                                          * bf16x3 one behind it as range-guard fallback) */
 /* Same for the transposed stream r2l_backward reads for N rays (r2l_pack_backward_layout takes the value). */

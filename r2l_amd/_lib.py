@@ -23,6 +23,7 @@ SIGNATURES = {
     "r2l_pack_forward": (_i, [_p, _i, _p, _p]),
     "r2l_pack_backward": (_i, [_p, _i, _p, _p]),
     "r2l_variant_for": (_i, [_l]),
+    "r2l_coop_tiles_for": (_i, [_l, _i]),
     "r2l_forward_layout_for": (_i, [_l, _i]),
     "r2l_backward_layout_for": (_i, [_l]),
     "r2l_pack_forward_layout": (_i, [_p, _i, _p, _i, _p]),

@@ -438,11 +438,16 @@ int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_ra
 #endif
 enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP = 1, R2L_VARIANT_COOP16 = 2 };
 // Cooperative fp16x2 kernels (r2l_coopf.h: one 32-ray tile per WORKGROUP): a sub-family of the MAIN variant — same streams,
-// stash and fallbacks as r2l_fwd2 / r2l_bwd2, taken instead of them for launches of at most R2L_COOPF_MAX_RAYS rays
+// stash and fallbacks as r2l_fwd2 / r2l_bwd2, taken instead of them for launches of at most R2L_COOPF_MAX_RAYS rays, and
+// for launches between one and one and a half ROUNDS of the one-wave-per-tile kernels (a round = 256 CUs x 128 rays): the
+// two-tile cooperative kernels then run three full rounds of 16 384 rays where those run two, the second half empty
+// (measured, tools/variant_sweep.py, 49 152 rays: step 4.19 vs 4.51 ms, forward 1.44 vs 1.53 ms; 24 576: 2.55 vs 2.44,
+// 65 536: 5.53 vs 5.29, 98 304: 8.20 vs 7.81 — the one-wave-per-tile kernels everywhere else)
 // (R2L_FORCE_VARIANT=coopf: always; =main: never).  Only with the whole fp16 trio enabled (no R2L_NO_* switch).
 #ifndef R2L_COOPF_MAX_RAYS
 #define R2L_COOPF_MAX_RAYS 16384
 #endif
+#define R2L_MAIN_ROUND_RAYS 32768  // one wave per 32-ray tile, four per workgroup, one workgroup per CU, 256 CUs
 static inline bool r2l_env_on(const char* name) {
     const char* e = getenv(name);
     return e && e[0] && e[0] != '0';
@@ -455,7 +460,7 @@ static inline bool r2l_use_coopf(int64_t N, int n_block) {
     const char* e = getenv("R2L_FORCE_VARIANT");
     if (e && e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return true;
     if (e && e[0]) return false;
-    return N <= R2L_COOPF_MAX_RAYS;
+    return N <= R2L_COOPF_MAX_RAYS || (N > R2L_MAIN_ROUND_RAYS && N <= R2L_MAIN_ROUND_RAYS + R2L_MAIN_ROUND_RAYS / 2);
 }
 static inline int r2l_chain_variant(int64_t N) {
     const char* e = getenv("R2L_FORCE_VARIANT");  // read per call (~100 ns) so tests can flip it

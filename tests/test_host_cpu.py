@@ -39,9 +39,22 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     assert lib.r2l_forward_layout_for(4096, 1) == 2 and lib.r2l_backward_layout_for(4096) == 2
     assert lib.r2l_forward_layout_for(98304, 1) == 2 and lib.r2l_forward_layout_for(160000, 0) == 2
     assert lib.r2l_backward_layout_for(98304) == 2
+    # ... cooperative: one tile per workgroup up to one tile per CU, two above, up to 16 384 rays; and again (two tiles) where
+    # the one-wave-per-tile kernels would run a half-empty second round
+    assert [lib.r2l_coop_tiles_for(n, 43) for n in (32, 4096, 8192, 8193, 16384, 16385, 32768, 32769, 49152, 49153, 98304,
+                                                     160000)] == [1, 1, 1, 2, 2, 0, 0, 2, 2, 0, 0, 0]
+    monkeypatch.setenv("R2L_COOPF_TILES", "2")
+    assert lib.r2l_coop_tiles_for(4096, 43) == 2 and lib.r2l_coop_tiles_for(98304, 43) == 0
+    monkeypatch.delenv("R2L_COOPF_TILES")
     monkeypatch.setenv("R2L_FORCE_VARIANT", "coopf")
     assert lib.r2l_variant_for(98304) == 0 and lib.r2l_forward_layout_for(98304, 1) == 2
+    assert lib.r2l_coop_tiles_for(98304, 43) == 2
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main")
+    assert lib.r2l_coop_tiles_for(4096, 43) == 0
     monkeypatch.delenv("R2L_FORCE_VARIANT")
+    monkeypatch.setenv("R2L_NO_DW2", "1")  # no fp16 trio, no cooperative fp16x2 kernels
+    assert lib.r2l_coop_tiles_for(4096, 43) == 0
+    monkeypatch.delenv("R2L_NO_DW2")
     # any switch of the fp16 training trio puts the WHOLE step on the bf16x3 trio (one stash format per step); forward-only
     # launches look at R2L_NO_FWD2 alone
     for k in ("R2L_NO_BWD2", "R2L_NO_DW2"):

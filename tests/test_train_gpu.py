@@ -362,3 +362,36 @@ def test_coopf_two_tiles_bitwise(chain_variant, monkeypatch):
     out = run()
     assert (out[1] - ref[1]).abs().max().item() < 2e-6
     assert torch.nn.functional.cosine_similarity(out[2], ref[2], dim=0).item() > 0.9999
+
+
+def test_mid_size_step_on_cooperative_chains(chain_variant, monkeypatch):
+    """Launches between one and one and a half rounds of the one-wave-per-tile kernels (32 769 .. 49 152 rays) take the
+    two-tile cooperative chains by default (csrc/r2l_common.h r2l_use_coopf): same step within rounding, ragged size."""
+    if chain_variant != "main":
+        pytest.skip("one comparison")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd import _lib
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=43, seed=0)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    n = 40000 - 3
+    g = torch.Generator().manual_seed(6)
+    o = (torch.randn(n, 3, generator=g) * 1.5).cuda(); d = torch.randn(n, 3, generator=g).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda(); tr = torch.rand(n, 16, generator=g).cuda()
+
+    def run():
+        m = build_model(sd, 43)
+        t = R2LTrainer(m, ps)
+        rgb = t.forward_backward(o, d, tgt, perturb=1.0, t_rand=tr)
+        with torch.no_grad():
+            plain = m.forward_rays(o, d, ps)
+        return t.loss_out.clone(), rgb.clone(), t.grads.clone(), plain.clone()
+
+    main = run()
+    assert _lib.load().r2l_coop_tiles_for(n, 43) == 0
+    monkeypatch.delenv("R2L_FORCE_VARIANT")
+    assert _lib.load().r2l_coop_tiles_for(n, 43) == 2
+    auto = run()
+    assert abs(auto[0][0].item() - main[0][0].item()) < 1e-6
+    assert (auto[1] - main[1]).abs().max().item() < 2e-6 and (auto[3] - main[3]).abs().max().item() < 2e-6
+    assert torch.nn.functional.cosine_similarity(auto[2], main[2], dim=0).item() > 0.9999
