@@ -13,14 +13,22 @@
 //     2w, 2w+1 ARE, lane for lane, the B operands of stages 4w .. 4w+3 of the next layer (fragment registers c = 8r .. 8r+7 of
 //     tile T = stage 2T + r), so each wave converts its own 32 values per lane to (hi, mid), writes them to the image
 //     [stage][split][lane][16 B] and — training — stores the hi quad as the stash piece; ONE barrier per layer.
-//   * A operands come straight from L2 into a four-stage register ring (16 loads in flight per wave), no LDS: a wave reads
-//     only its own quarter of a stage.  The ring slot of every stage is a compile-time constant: a layer has 17 stages, so
-//     the phase advances by one per layer and the body is unrolled over two blocks (68 stages).
+//   * A operands come straight from L2 into a register ring of R = 4 stages (16 loads in flight per wave; template
+//     parameter), no LDS: a wave reads only its own quarter of a stage.  The ring slot of every stage is a
+//     compile-time constant: a layer has 17 stages = 1 mod R, so the phase advances by one per layer and the body is
+//     unrolled over R / 2 blocks.
 //   * The kernel is bound by that weight stream (256 KiB per layer and workgroup from L2), not by the matrix pipe.
 #pragma once
 #include "r2l_f2.h"
 
-#define FC_RING 4
+// register-ring depth (stages of A operands in flight per wave), per tiles-per-workgroup.  A one-tile workgroup has the CU
+// to itself and registers to spare, but a ring of 8 (32 loads in flight per wave, no spills) measured 0.264 ms against 0.259
+// for the 4096-ray forward: the stream is bound by what a CU pulls from L2 (~46 B/clk), not by latency
+#ifndef FC_RING_ONE
+#define FC_RING_ONE 4
+#endif
+#define FC_RING_TWO 4
+template <int NT> struct FcRingOf { static constexpr int value = NT == 1 ? FC_RING_ONE : FC_RING_TWO; };
 #define FC_BOP_BYTES 32768   // one B-operand image: 16 stages x (hi, mid) x 1 KiB
 // Dynamic LDS added to every one-tile launch (64 - 72 KiB static) so that a CU never holds TWO of these workgroups.  Measured
 // (round 2, tools/coopf_coresidency.py): with two workgroups of the training forward (236 - 252 VGPRs: the two waves of a SIMD
@@ -39,8 +47,9 @@ typedef __attribute__((address_space(3))) u32x4 fc_lds_u32x4;
 __device__ __forceinline__ u32x4 fc_lds_read(unsigned addr) { return *(fc_lds_u32x4*)(size_t)addr; }
 __device__ __forceinline__ void fc_lds_write(unsigned addr, u32x4 v) { *(fc_lds_u32x4*)(size_t)addr = v; }
 
-struct FcRing {  // four stages x (hi tile 0, hi tile 1, mid tile 0, mid tile 1) of this wave
-    u32x4 a[FC_RING][4];
+template <int R>
+struct FcRing {  // R stages x (hi tile 0, hi tile 1, mid tile 0, mid tile 1) of this wave
+    u32x4 a[R][4];
 };
 struct FcStream {
     u32x4 rs;       // descriptor of the stage stream
@@ -62,10 +71,11 @@ __device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
     fc_load<1024>(a[3], p.rs, p.voff + 8192u, so);
     ++p.g;
 }
-// the four loads of the oldest stage in flight have landed: three younger stages (12 loads) may still fly; vmcnt retires in
-// order, and anything else in the queue (stash stores) only makes the wait stricter
+// the four loads of the oldest stage in flight have landed: the R - 1 younger stages (4 loads each) may still fly; vmcnt
+// retires in order, and anything else in the queue (stash stores) only makes the wait stricter
+template <int R>
 __device__ __forceinline__ void fc_wait(u32x4 (&a)[4]) {
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(4 * (R - 1)));
 }
 __device__ __forceinline__ void fc_barrier() {  // LDS writes of this wave done, then the workgroup barrier (no vmcnt drain)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -81,11 +91,11 @@ __device__ __forceinline__ void fc_store_b32(void* p, unsigned v) {
 
 // acc[ray tile][2 feature tiles] (+)= stage: BIAS: one MFMA per tile (bias hi / mid in k slots 0, 1 against ones), else the three
 // products, small terms first; the NT ray tiles of the workgroup share the A operands.  Then the slot is refilled with the
-// stage four positions ahead.
-template <int SLOT, bool BIAS, bool ZERO, int NT>
-__device__ __forceinline__ void fc_stage(f32x16 (&acc)[NT][2], FcRing& W, FcStream& p, const f16x8 (&bh)[NT], const f16x8 (&bm)[NT]) {
+// stage R positions ahead.
+template <int SLOT, bool BIAS, bool ZERO, int NT, int R>
+__device__ __forceinline__ void fc_stage(f32x16 (&acc)[NT][2], FcRing<R>& W, FcStream& p, const f16x8 (&bh)[NT], const f16x8 (&bm)[NT]) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    fc_wait(W.a[SLOT]);
+    fc_wait<R>(W.a[SLOT]);
     const f16x8 h0 = __builtin_bit_cast(f16x8, W.a[SLOT][0]), h1 = __builtin_bit_cast(f16x8, W.a[SLOT][1]);
     const f16x8 m0 = __builtin_bit_cast(f16x8, W.a[SLOT][2]), m1 = __builtin_bit_cast(f16x8, W.a[SLOT][3]);
     if (BIAS) {
@@ -117,8 +127,25 @@ __device__ __forceinline__ void fc_stage(f32x16 (&acc)[NT][2], FcRing& W, FcStre
 // One layer: its bias (or zero) stage in ring slot PH, then the 16 k-stages against the B-operand images at `bop` + rt *
 // FC_BOP_BYTES (LDS byte address of this lane's 16 bytes of stage 0, split 0, ray tile 0).  ZERO_FIRST: the bias stage
 // initialises acc (C = 0).  B operands are read one stage ahead.
-template <int PH, bool ZERO_FIRST, int NT>
-__device__ __forceinline__ void fc_layer(f32x16 (&acc)[NT][2], FcRing& W, FcStream& p, unsigned bop, const f16x8& ones) {
+template <int PH, int KB, int NT, int R>
+__device__ __forceinline__ void fc_layer_k(f32x16 (&acc)[NT][2], FcRing<R>& W, FcStream& p, unsigned bop, u32x4 (&nh)[NT], u32x4 (&nm)[NT]) {
+    if constexpr (KB < 16) {
+        f16x8 bh[NT], bm[NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            bh[rt] = __builtin_bit_cast(f16x8, nh[rt]);
+            bm[rt] = __builtin_bit_cast(f16x8, nm[rt]);
+            if (KB < 15) {
+                nh[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + (unsigned)(KB + 1) * 2048u);
+                nm[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + (unsigned)(KB + 1) * 2048u + 1024u);
+            }
+        }
+        fc_stage<(PH + 1 + KB) % R, false, false>(acc, W, p, bh, bm);
+        fc_layer_k<PH, KB + 1>(acc, W, p, bop, nh, nm);
+    }
+}
+template <int PH, bool ZERO_FIRST, int NT, int R>
+__device__ __forceinline__ void fc_layer(f32x16 (&acc)[NT][2], FcRing<R>& W, FcStream& p, unsigned bop, const f16x8& ones) {
     u32x4 nh[NT], nm[NT];
     f16x8 o1[NT];
 #pragma unroll
@@ -128,23 +155,7 @@ __device__ __forceinline__ void fc_layer(f32x16 (&acc)[NT][2], FcRing& W, FcStre
         o1[rt] = ones;
     }
     fc_stage<PH, true, ZERO_FIRST>(acc, W, p, o1, o1);
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
-        f16x8 bh[NT], bm[NT];
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt) {
-            bh[rt] = __builtin_bit_cast(f16x8, nh[rt]);
-            bm[rt] = __builtin_bit_cast(f16x8, nm[rt]);
-            if (kb < 15) {
-                nh[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + (unsigned)(kb + 1) * 2048u);
-                nm[rt] = fc_lds_read(bop + (unsigned)rt * FC_BOP_BYTES + (unsigned)(kb + 1) * 2048u + 1024u);
-            }
-        }
-        if ((PH + 1 + kb) % 4 == 0) fc_stage<0, false, false>(acc, W, p, bh, bm);
-        else if ((PH + 1 + kb) % 4 == 1) fc_stage<1, false, false>(acc, W, p, bh, bm);
-        else if ((PH + 1 + kb) % 4 == 2) fc_stage<2, false, false>(acc, W, p, bh, bm);
-        else fc_stage<3, false, false>(acc, W, p, bh, bm);
-    }
+    fc_layer_k<PH, 0>(acc, W, p, bop, nh, nm);
 }
 
 // Eight values of one stage -> (hi, mid) fp16 quads (r2l_f2.h's split: hi = fp16(x), mid = fp16(x - hi)); amax tracks the

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
                 for (int e = 0; e < 4; ++e) g[rt][tt][4 * q + e] = v[e];
             }
 
-    FcRing W;
+    constexpr int R = FcRingOf<NT>::value;
+    FcRing<R> W;
     FcStream P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
         P.g = 0u;
     }
 #pragma unroll
-    for (int k = 0; k < FC_RING; ++k) fc_issue(W.a[k], P);
+    for (int k = 0; k < R; ++k) fc_issue(W.a[k], P);
     f16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
         // the forward's mask words: untracked loads like the ring's (a compiler-tracked one would drain vmcnt, i.e. the ring, at
-        // its first use).  They are older than every load of GEMM A, whose last fc_wait leaves only the 12 youngest in flight.
+        // its first use).  They are older than every load of GEMM A (68), whose last fc_wait leaves only the 4 (R - 1) youngest in flight.
         unsigned mw[NT];
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) asm volatile("global_load_dword %0, %1, off" : "=&v"(mw[rt]) : "v"(mwp[rt]) : "memory");
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
         }
         fc_barrier();
         // GEMM B: g += W1^T (u . mask)
-        fc_layer<(PH + 1) % 4, false>(g, W, P, bop_rd + KIND, ones);
+        fc_layer<(PH + 1) % R, false>(g, W, P, bop_rd + KIND, ones);
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {
             gxh[rt] -= slot / 4;
@@ -192,10 +193,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
             fc_barrier();
         }
     };
+    // the k-th block of the walk starts in phase 2 k mod R: unrolled over R / 2 blocks
 #pragma unroll 1
-    for (int b = a.n_block - 1; b >= 0; b -= 2) {
+    for (int b = a.n_block - 1; b >= 0; b -= R / 2) {
         block(std::integral_constant<int, 0>{}, b == 0);
-        if (b - 1 >= 0) block(std::integral_constant<int, 2>{}, b - 1 == 0);
+        if constexpr (R >= 4) {
+            if (b - 1 >= 0) block(std::integral_constant<int, 2 % R>{}, b - 1 == 0);
+        }
+        if constexpr (R >= 8) {
+            if (b - 2 >= 0) block(std::integral_constant<int, 4 % R>{}, b - 2 == 0);
+            if (b - 3 >= 0) block(std::integral_constant<int, 6 % R>{}, b - 3 == 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

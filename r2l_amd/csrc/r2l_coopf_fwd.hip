@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
     }
 
     // ---- weight ring: stages 0 .. 3 requested -------------------------------------------------------------------------------
-    FcRing W;
+    constexpr int R = FcRingOf<NT>::value;
+    FcRing<R> W;
     FcStream P;
     {
         const unsigned long long sa = (unsigned long long)a.stream;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         P.g = 0u;
     }
 #pragma unroll
-    for (int k = 0; k < FC_RING; ++k) fc_issue(W.a[k], P);
+    for (int k = 0; k < R; ++k) fc_issue(W.a[k], P);
     f16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
@@ -140,6 +141,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
             }
     };
     f32x16 x[NT][2], t[NT][2], x0[NT][2];
+    // stage q + 1 = 16 c + kb + 1 sits in ring slot (kb + 1) % R (R divides 16)
+    auto head_stage = [&](auto kb_tag, int c, unsigned rb) {
+        constexpr int KB = decltype(kb_tag)::value;
+        if (c == 3 && KB == 15) return;
+        f16x8 bh[NT], bm[NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            bh[rt] = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)rt * FC_BOP_BYTES + (unsigned)KB * 2048u));
+            bm[rt] = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)rt * FC_BOP_BYTES + (unsigned)KB * 2048u + 1024u));
+        }
+        fc_stage<(KB + 1) % R, false, false>(x, W, P, bh, bm);
+    };
     produce_pe(0);
     fc_barrier();
     {
@@ -152,20 +165,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
     for (int c = 0; c < 4; ++c) {
         if (c < 3) produce_pe(c + 1);  // into the other images (their last readers passed the barrier that closed chunk c - 1)
         const unsigned rb = bop_rd + (unsigned)(c & 1) * KIND;
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            if (c == 3 && kb == 15) continue;
-            f16x8 bh[NT], bm[NT];
-#pragma unroll
-            for (int rt = 0; rt < NT; ++rt) {
-                bh[rt] = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)rt * FC_BOP_BYTES + (unsigned)kb * 2048u));
-                bm[rt] = __builtin_bit_cast(f16x8, fc_lds_read(rb + (unsigned)rt * FC_BOP_BYTES + (unsigned)kb * 2048u + 1024u));
-            }
-            if ((kb + 1) % 4 == 0) fc_stage<0, false, false>(x, W, P, bh, bm);
-            else if ((kb + 1) % 4 == 1) fc_stage<1, false, false>(x, W, P, bh, bm);
-            else if ((kb + 1) % 4 == 2) fc_stage<2, false, false>(x, W, P, bh, bm);
-            else fc_stage<3, false, false>(x, W, P, bh, bm);
-        }
+        head_stage(std::integral_constant<int, 0>{}, c, rb);   head_stage(std::integral_constant<int, 1>{}, c, rb);
+        head_stage(std::integral_constant<int, 2>{}, c, rb);   head_stage(std::integral_constant<int, 3>{}, c, rb);
+        head_stage(std::integral_constant<int, 4>{}, c, rb);   head_stage(std::integral_constant<int, 5>{}, c, rb);
+        head_stage(std::integral_constant<int, 6>{}, c, rb);   head_stage(std::integral_constant<int, 7>{}, c, rb);
+        head_stage(std::integral_constant<int, 8>{}, c, rb);   head_stage(std::integral_constant<int, 9>{}, c, rb);
+        head_stage(std::integral_constant<int, 10>{}, c, rb);  head_stage(std::integral_constant<int, 11>{}, c, rb);
+        head_stage(std::integral_constant<int, 12>{}, c, rb);  head_stage(std::integral_constant<int, 13>{}, c, rb);
+        head_stage(std::integral_constant<int, 14>{}, c, rb);  head_stage(std::integral_constant<int, 15>{}, c, rb);
         if (c < 3) fc_barrier();
     }
 #pragma unroll
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         }
         fc_barrier();
         // x += W2 relu(t) + b2
-        fc_layer<(PH + 1) % 4, false>(x, W, P, bop_rd + KIND, ones);
+        fc_layer<(PH + 1) % R, false>(x, W, P, bop_rd + KIND, ones);
         if (SAVE) {
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) {
@@ -221,10 +228,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
             fc_barrier();
         }
     };
+    // block b starts in phase 2 b mod R: unrolled over R / 2 blocks
 #pragma unroll 1
-    for (int b = 0; b < a.n_block; b += 2) {
+    for (int b = 0; b < a.n_block; b += R / 2) {
         block(std::integral_constant<int, 0>{}, b == a.n_block - 1);
-        if (b + 1 < a.n_block) block(std::integral_constant<int, 2>{}, b + 1 == a.n_block - 1);
+        if constexpr (R >= 4) {
+            if (b + 1 < a.n_block) block(std::integral_constant<int, 2 % R>{}, b + 1 == a.n_block - 1);
+        }
+        if constexpr (R >= 8) {
+            if (b + 2 < a.n_block) block(std::integral_constant<int, 4 % R>{}, b + 2 == a.n_block - 1);
+            if (b + 3 < a.n_block) block(std::integral_constant<int, 6 % R>{}, b + 3 == a.n_block - 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead loads (stream padding) and the stash stores
 
