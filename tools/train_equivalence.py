@@ -1,0 +1,100 @@
+"""Does the default fp16 trio (fp16x2 chains + ONE-fp16-product weight-gradient GEMMs on fp16-rounded operands) train like
+the fp32-exact families?  The same W256 D88 student (seed 0), the same seeded batches and jitter, the reference's schedule
+(lr 5e-4, warm-up 1e-4 -> 5e-4 over 200 iterations, Adam), three kernel families:
+  fp16 trio (default) | bf16x3 trio (R2L_NO_FWD2/BWD2/DW2=1: products exact to fp32) | fp32 MFMA (R2L_NO_FWD3=1)
+on an analytic scene with silhouettes and shading (three lit spheres on white, rays from the r = 4 sphere like
+create_data's poses).  Held-out PSNR every 250 iterations.  Trajectories of a chaotic optimisation separate whatever the
+rounding (the two fp32-exact families differ only in summation order), so their mutual distance is the yardstick for the
+fp16 trio's distance to either.  GPU box:  python tools/train_equivalence.py [iters=1500] [rays=16384]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import r2l_oracle as O  # noqa: E402  (seeded W256 D88 state dict only)
+from tests.test_forward_gpu import build_model  # noqa: E402
+from model.nerf_raybased import PointSampler  # noqa: E402
+from r2l_amd.train_step import R2LTrainer, lr_schedule  # noqa: E402
+
+FAMILIES = {"fp16 trio (default)": {}, "bf16x3 trio": {"R2L_NO_FWD2": "1", "R2L_NO_BWD2": "1", "R2L_NO_DW2": "1"},
+            "fp32 MFMA": {"R2L_NO_FWD3": "1"}}
+
+
+def scene(o, d):
+    """rgb[N,3] of rays against three diffuse spheres under one light, white background (first hit wins)."""
+    d = torch.nn.functional.normalize(d, dim=-1)
+    centers = torch.tensor([[0., 0., 0.], [0.9, 0.3, 0.4], [-0.7, -0.5, 0.6]], device=o.device)
+    radii = torch.tensor([0.8, 0.45, 0.5], device=o.device)
+    albedo = torch.tensor([[0.9, 0.3, 0.2], [0.2, 0.7, 0.9], [0.3, 0.8, 0.3]], device=o.device)
+    light = torch.nn.functional.normalize(torch.tensor([0.5, 0.8, 0.6], device=o.device), dim=0)
+    best = torch.full((o.shape[0],), 1e9, device=o.device)
+    rgb = torch.ones(o.shape[0], 3, device=o.device)
+    for c, r, a in zip(centers, radii, albedo):
+        oc = o - c
+        b = (oc * d).sum(-1)
+        disc = b * b - ((oc * oc).sum(-1) - r * r)
+        t = -b - torch.sqrt(disc.clamp_min(0.))
+        hit = (disc > 0) & (t > 0) & (t < best)
+        n = torch.nn.functional.normalize(o + t[:, None] * d - c, dim=-1)
+        shade = 0.25 + 0.75 * (n * light).sum(-1).clamp_min(0.)
+        rgb = torch.where(hit[:, None], a[None, :] * shade[:, None], rgb)
+        best = torch.where(hit, t, best)
+    return rgb
+
+
+def rays(n, gen):
+    """origins on the r = 4 sphere, directions towards a point near the centre (what a 400x400 view of the scene covers)"""
+    o = torch.randn(n, 3, generator=gen)
+    o = 4. * o / o.norm(dim=-1, keepdim=True)
+    tgt = (torch.rand(n, 3, generator=gen) - 0.5) * 2.4
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True) * (1. + 0.1 * torch.rand(n, 1, generator=gen))  # un-normalised like get_rays'
+    return o.cuda(), d.cuda()
+
+
+def main(iters=1500, n=16384):
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    sd = O.make_state_dict(43, seed=0)
+    gen = torch.Generator().manual_seed(123)
+    test_o, test_d = rays(65536, gen)
+    test_rgb = scene(test_o, test_d)
+    curves, finals, weights = {}, {}, {}
+    for name, env in FAMILIES.items():
+        for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        m = build_model(sd, 43)
+        tr = R2LTrainer(m, ps)
+        g = torch.Generator().manual_seed(7)       # batches
+        gj = torch.Generator().manual_seed(8)      # jitter
+        curve = []
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for it in range(1, iters + 1):
+            o, d = rays(n, g)
+            tgt = scene(o, d)
+            t_rand = torch.rand(n, 16, generator=gj).cuda()
+            tr.step(o, d, tgt, lr_schedule(it, 5e-4, 500, "0.0001,200"), perturb=1.0, t_rand=t_rand)
+            if it % 250 == 0 or it == iters:
+                with torch.no_grad():
+                    out = m.forward_rays(test_o, test_d, ps)
+                psnr = (-10. * torch.log10(((out - test_rgb) ** 2).mean())).item()
+                curve.append((it, psnr))
+        torch.cuda.synchronize()
+        curves[name], finals[name] = curve, out.clone()
+        weights[name] = m.engine().flat.clone() if hasattr(m, "engine") else None
+        print("%-22s %5.1f s  " % (name, time.time() - t0) + "  ".join("it %d: %.3f dB" % c for c in curve), flush=True)
+    names = list(FAMILIES)
+    print("\nheld-out frame distance between families after %d iterations (PSNR of one family's prediction against another's):" % iters)
+    for i in range(3):
+        for j in range(i + 1, 3):
+            a, b = finals[names[i]], finals[names[j]]
+            print("  %-22s vs %-22s  %.2f dB  (max |dRGB| %.4f)" % (names[i], names[j],
+                  (-10. * torch.log10(((a - b) ** 2).mean())).item(), (a - b).abs().max().item()))
+    print("final held-out PSNR: " + ", ".join("%s %.3f dB" % (k, v[-1][1]) for k, v in curves.items()))
+
+
+if __name__ == "__main__":
+    main(*[int(v) for v in sys.argv[1:3]])
