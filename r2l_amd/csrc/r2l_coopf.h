@@ -61,6 +61,8 @@ template <int IMM>
 __device__ __forceinline__ void fc_load(u32x4& dst, u32x4 rs, unsigned voff, unsigned soff) {
     // untracked by the compiler (it would drain vmcnt at every barrier and loop header): consumers wait with fc_wait
     // (no "memory" clobber: the stream is read-only, and LDS reads of the B operands may be scheduled across it)
+    // (cache policy: default.  Measured on the 4096-ray forward: `nt` 0.40 ms against 0.25 — the stream every workgroup
+    // shares stops being kept in L2 —, sc0 / sc1 / sc0 sc1: no change)
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM));
 }
 __device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
