@@ -11,6 +11,7 @@ import ctypes
 import math
 
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -239,18 +240,34 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
         path = ("fp16 trio: forward and dX chain with 3 fp16 MFMA products per fp32 product (two-way operand splits), dW body "
                 "with 1 (fp16 hi operands from the fp16 stash); range-guarded, bf16x3 trio behind it")
         extra = {"peak_if_every_gemm_took_3_products": 2500.0 / 3., "frac_of_3_product_peak": achieved / (2500.0 / 3.)}
-        if n <= 16384:
-            # cooperative chains (r2l_coopf: one 32-ray tile per workgroup): N / 32 workgroups, each streaming the 25 MB of
-            # packed weights per chain from L2 — measured ~45 B/clk per CU, which is what bounds them, not the matrix pipe
-            path += "; chains: cooperative kernels (one tile per workgroup), bound by the L2 weight stream: %d workgroups x " \
-                    "25.1 MB per chain" % ((n + 31) // 32)
-            extra["weight_stream_bytes_per_step"] = 2 * ((n + 31) // 32) * 25.1e6
+        nt = int(tr.lib.r2l_coop_tiles_for(int(n), tr.eng.n_block))
+        if nt:
+            # cooperative chains (r2l_coopf: one or two 32-ray tiles per workgroup), each workgroup streaming the 25 MB of
+            # packed weights per chain from L2 — measured ~45 B/clk per CU, which is what bounds the small launches
+            wgs = ((n + 31) // 32 + nt - 1) // nt
+            path += "; chains: cooperative kernels (%d tile(s) per workgroup), L2 weight stream: %d workgroups x 25.1 MB per " \
+                    "chain" % (nt, wgs)
+            extra["weight_stream_bytes_per_step"] = 2 * wgs * 25.1e6
 
     elif fwd3 and big:
         peak = 2500.0 / 6.
         path = "bf16x3 trio: forward, dX chain and dW body with 6 bf16 products per fp32 product (%s)" % ", ".join(off)
     elif fwd3:
         path = "fp32 MFMA chains + bf16x3 dW"
+    if distributed:
+        # the exchange alone (the step's whole flat gradient in one all-reduce, nothing to hide behind): what the bucketed
+        # overlap has to cover, for reading the scaling numbers
+        buf = torch.zeros_like(tr.grads)
+        for _ in range(2):
+            tr.reducer.allreduce(buf)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.reducer.allreduce(buf)
+        torch.cuda.synchronize(device)
+        extra["grad_allreduce_alone_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        extra["grad_allreduce_bytes"] = buf.numel() * 4
+        extra["allreduce_buckets"] = tr.n_buckets
     return {"value": n * steps * world / dt, "unit": "rays/s", "steps": steps, "warmup": warm,
             "ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": n,
             "workload": "distillation step (fwd + bwd + Adam + weight re-pack), %d rays/GPU/step, perturb=1; "

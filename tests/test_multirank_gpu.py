@@ -110,4 +110,7 @@ def test_bench_two_ranks_walk(tmp_path):
     for leg in ("train", "train_strong", "train_4096", "teacher"):
         assert leg in out, leg
     assert out["train_strong"]["scaling"] == "strong" and out["train_strong"]["global_rays_per_step"] == 98304
+    r = out["train"]["roofline"]
+    assert r["grad_allreduce_alone_ms"] > 0 and r["grad_allreduce_bytes"] == 5917187 * 4 and r["allreduce_buckets"] == 4
+    assert "2 tile(s) per workgroup" in out["train_strong"]["roofline"]["matrix_path"]  # 49 152 rays per rank
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
