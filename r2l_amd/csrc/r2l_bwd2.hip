@@ -211,27 +211,28 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
         const u32x4 trs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta),
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ta >> 32)) & 0xffffu, 0xffffffffu,
                            0x00020000u};
-        u32x4* gxh = reinterpret_cast<u32x4*>(a.gx + (int64_t)(b + 1) * slot) + lane_unit;
-        u32x4* gth = reinterpret_cast<u32x4*>(a.gt + (int64_t)b * slot) + lane_unit;
+        float* const gxr = a.gx + (int64_t)(b + 1) * slot;
+        float* const gtr = a.gt + (int64_t)b * slot;
+        const unsigned hvoff = (unsigned)(lane_unit * 16);
         const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
         const F3Dma mask_dma{true, trs, mvoff, 0u, ring_lds + (unsigned)(b & 1) * 1024u};
         // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
-        f2_stage<true, true, false>(u, P, B3TakeG{g[0], 0}, B3TakeG{g[0], 4}, mask_dma, no_dma, F2Hst{true, gxh});
+        f2_stage<true, true, false>(u, P, B3TakeG{g[0], 0}, B3TakeG{g[0], 4}, mask_dma, no_dma, F2Hst{true, gxr, hvoff, 0u});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
                                           B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4}, no_dma, no_dma,
-                                          F2Hst{true, gxh + 64 * (kb + 1)});
+                                          F2Hst{true, gxr, hvoff, 1024u * (unsigned)(kb + 1)});
         // (the mask piece was requested 16 stages ago: every stage wait since has retired all but the newest loads)
         const u32x4 mb = *reinterpret_cast<const u32x4*>(ring_lane + (b & 1) * 1024);
         f2_stage<false, false, true>(u, P, F3None{}, F3None{});
         // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
-        f2_stage<true, false, false>(g, P, B3TakeU{u[0], 0, 0, mb}, B3TakeU{u[0], 4, 0, mb}, no_dma, no_dma, F2Hst{true, gth});
+        f2_stage<true, false, false>(g, P, B3TakeU{u[0], 0, 0, mb}, B3TakeU{u[0], 4, 0, mb}, no_dma, no_dma, F2Hst{true, gtr, hvoff, 0u});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), (kb + 1) >> 1, mb},
                                           B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, (kb + 1) >> 1, mb}, no_dma, no_dma,
-                                          F2Hst{true, gth + 64 * (kb + 1)});
+                                          F2Hst{true, gtr, hvoff, 1024u * (unsigned)(kb + 1)});
         f2_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
     }
 

@@ -67,8 +67,15 @@ struct F2Split {
 #define R2L_H16_TILE_UNITS 1024  // 16-byte units per tile and slot
 struct F2Hst {                   // where this lane's 16 B of the NEXT stage's B operand go (on == false: no stash)
     bool on;
-    u32x4* dst;
+    float* slot;    // the stash slot (uniform: a scalar register pair; the chain's launcher advances it per block)
+    unsigned voff;  // this lane's byte offset of stage piece 0 in the slot: (tile * 1024 + lane) * 16
+    unsigned soff;  // + the stage piece, 1024 * kb (uniform: a scalar register, no address arithmetic on the VALU)
 };
+__device__ __forceinline__ void f2_hst_store(const F2Hst& h, u32x4 v) {
+    // raw buffer store, no bounds (the padding rows of the last tile are written too).  Whole 128-byte lines, written once,
+    // read back milliseconds later by another kernel: non-temporal (aux bit 1 = nt)
+    __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(h.slot, 0, -1, 0x00020000), h.voff, h.soff, 2);
+}
 struct F2A4 {  // A operands (fp16 pairs) of four output tiles
     f16x8 h[4], m[4];
 };
@@ -86,7 +93,7 @@ struct F2Side {
     F3Dma dma;
     float& amax;  // running max |B value| of this lane (range guard: fp16 ends at 65504)
     F3Dma extra = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};  // one more 1 KiB piece, issued with step 5 (backward: mask tile)
-    F2Hst hst = F2Hst{false, nullptr};  // second half stage only: stash the assembled hi operand (step 4)
+    F2Hst hst = F2Hst{false, nullptr, 0u, 0u};  // second half stage only: stash the assembled hi operand (step 4)
     const unsigned* uh_first = nullptr;  // the first half stage's packed hi pairs (values 0-3 of the operand)
     float x[4];
     unsigned uh[2], um[2];  // packed fp16 pairs: values (0,1) and (2,3)
@@ -137,8 +144,7 @@ struct F2Side {
             um[0] = pk(x[0], x[1]);
             um[1] = pk(x[2], x[3]);
         } else if (i == 4) {
-            // whole 128-byte lines, written once, read back milliseconds later by another kernel: non-temporal
-            if (hst.on) __builtin_nontemporal_store(u32x4{uh_first[0], uh_first[1], uh[0], uh[1]}, hst.dst);
+            if (hst.on) f2_hst_store(hst, u32x4{uh_first[0], uh_first[1], uh[0], uh[1]});
         }
     }
 };
@@ -224,7 +230,7 @@ template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
 __device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi,
                                          F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
                                          F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
-                                         F2Hst hst = F2Hst{false, nullptr}) {
+                                         F2Hst hst = F2Hst{false, nullptr, 0u, 0u}) {
     F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax, extra_a};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);

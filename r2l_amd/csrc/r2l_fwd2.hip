@@ -241,41 +241,38 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     const int64_t Np = R2L_PAD_ROWS(a.N);
     // (rows of the padding rays of the last tile exist: Np rows per slot)
     const int64_t slot = R2L_TRIO_SLOT(Np);
-    u32x4* hx = SAVE ? reinterpret_cast<u32x4*>(a.save_x) + tile * R2L_H16_TILE_UNITS + lane : nullptr;
-    u32x4* ht = SAVE ? reinterpret_cast<u32x4*>(a.save_t) + tile * R2L_H16_TILE_UNITS + lane : nullptr;
+    const unsigned hvoff = (unsigned)((tile * R2L_H16_TILE_UNITS + lane) * 16);  // this lane's unit of stage piece 0 in a slot
     const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
     if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
         reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
+        float* const hxr = SAVE ? a.save_x + (int64_t)b * slot : nullptr;  // this block's slots
+        float* const htr = SAVE ? a.save_t + (int64_t)b * slot : nullptr;
         // t = W1 x + b1   (its ReLU is applied where t is consumed)
         f2_stage<true, true, false>(t, P, F3Take4<false, SAVE, false>{x[0], 0, nullptr, 0}, F3Take4<false, SAVE, false>{x[0], 4, nullptr, 0},
-                                    no_dma, no_dma, F2Hst{SAVE, hx});
+                                    no_dma, no_dma, F2Hst{SAVE, hxr, hvoff, 0u});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(t, P, F3Take4<false, SAVE, false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, (kb + 1) >> 1},
                                           F3Take4<false, SAVE, false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, (kb + 1) >> 1},
-                                          no_dma, no_dma, F2Hst{SAVE, hx + 64 * (kb + 1)});
+                                          no_dma, no_dma, F2Hst{SAVE, hxr, hvoff, 1024u * (unsigned)(kb + 1)});
         f2_stage<false, false, true>(t, P, F3None{}, F3None{});
         // x += W2 relu(t) + b2   (training: the gatherers also shift [t > 0] into the block's four mask words)
         unsigned mw[4] = {0u, 0u, 0u, 0u};
         f2_stage<true, false, false>(x, P, F3Take4<true, SAVE, false>{t[0], 0, nullptr, 0, &mw[0]},
-                                     F3Take4<true, SAVE, false>{t[0], 4, nullptr, 0, &mw[0]}, no_dma, no_dma, F2Hst{SAVE, ht});
+                                     F3Take4<true, SAVE, false>{t[0], 4, nullptr, 0, &mw[0]}, no_dma, no_dma, F2Hst{SAVE, htr, hvoff, 0u});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(x, P, F3Take4<true, SAVE, false>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
                                           F3Take4<true, SAVE, false>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
-                                          no_dma, no_dma, F2Hst{SAVE, ht + 64 * (kb + 1)});
+                                          no_dma, no_dma, F2Hst{SAVE, htr, hvoff, 1024u * (unsigned)(kb + 1)});
         f2_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
         if (SAVE) {  // values were shifted in MSB-first: bit (T&1)*16 + c after the reversal
             u32x4 mv;
 #pragma unroll
             for (int w = 0; w < 4; ++w) mv[w] = __builtin_bitreverse32(mw[w]);
             *reinterpret_cast<u32x4*>(a.save_t + (int64_t)b * slot + R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) = mv;
-        }
-        if (SAVE) {
-            hx += slot / 4;  // (slots are whole 16-byte units: Np * 264 floats, Np a multiple of 32)
-            ht += slot / 4;
         }
     }
     if (SAVE) {  // slot n: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
