@@ -3,6 +3,7 @@ one GPU a test box has: a 1-rank communicator is a real ncclCommInitRank / ncclA
 (SUM over one rank = identity), and two processes sharing the GPU is not something RCCL supports, so N > 1 is covered by
 the gloo tests of the torch.distributed form (tests/test_driver_cpu.py) and by bench.py's measured rccl_ranks."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -38,3 +39,50 @@ def test_native_allreduce_reports_errors():
     assert rc >= 10000 and b"bad arguments" in lib.r2l_last_error()
     assert lib.r2l_grad_allreduce(None, None, 4, None) >= 10000
     assert lib.r2l_allreduce_destroy(None) == 0
+
+
+TORCH_NCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29631")
+os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)       # the call bench.py and the driver make (nccl = RCCL on ROCm)
+from r2l_amd.dist_utils import bucket_plan
+flat = torch.arange(5917187, dtype=torch.float32, device=dev) * 1e-3
+ref = flat.clone()
+works = []
+for lo, hi, a, b in bucket_plan(43, 4):               # the trainer's buckets: async all-reduces of views of one buffer
+    works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+for w in works:
+    w.wait()                                          # (stream wait, not a host block)
+flat.mul_(1.0)
+torch.cuda.synchronize()
+assert torch.equal(flat, ref)                         # SUM over one rank
+t = torch.tensor([3.5], device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.broadcast(flat, src=0)
+dist.barrier()
+assert t.item() == 3.5 and torch.equal(flat, ref)
+dist.destroy_process_group()
+print("torch nccl single rank ok")
+"""
+
+
+def test_torch_nccl_backend_single_rank(tmp_path):
+    """torch.distributed's nccl (= RCCL) backend as bench.py / the driver use it at world > 1 — process group with device_id,
+    asynchronous all-reduces of the trainer's gradient buckets (views of one flat buffer), MAX reduce, broadcast, barrier —
+    brought up on the one GPU of this box with a communicator of one rank (two ranks need two devices)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "nccl1.py"
+    script.write_text(TORCH_NCCL_WORKER % {"root": root})
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "torch nccl single rank ok" in r.stdout
