@@ -3,16 +3,18 @@
 The .so lands in r2l_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).  hipcc cross-compiles
 gfx950 without a GPU, so this also serves as the CPU-side "does it build" check (__graft_entry__.build).
 """
+import glob
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
-OBJDIR = os.path.join(HERE, "lib", "obj")
+LIBDIR = os.environ.get("R2L_LIB_DIR") or os.path.join(HERE, "lib")  # env override: A/B builds (tools/)
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libr2l_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the point/ray arithmetic must reproduce the reference's separately rounded mul/add
@@ -37,6 +39,27 @@ def _digest(path):
     return h.hexdigest()
 
 
+# ISA audit.  On gfx950 a packed-fp32 VALU op whose LOW lane takes the HIGH dword of src1 (`v_pk_fma_f32 ... op_sel:[0,1,0]`)
+# was caught dropping its low-lane result in lanes 48-63 when a second wave shared the SIMD (csrc/r2l_coopf.h,
+# profiles/r03_coresidency.md).  hipcc forms these from plain scalar code (SLP vectoriser), so every object's device assembly
+# is checked and the build fails if one appears (src1 / src2 low-lane selects; the src0 form is bit-checked in many kernels).
+_PK_F32 = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b.*\bop_sel:\[([01]),([01])(?:,([01]))?\]")
+
+
+def audit_isa(text, what):
+    kernel, bad = "?", []
+    for line in text.splitlines():
+        if re.match(r"^[A-Za-z_][\w$]*:", line):  # a function symbol (basic-block labels start with a dot)
+            kernel = line.split(":")[0]
+        m = _PK_F32.search(line)
+        if m and (m.group(3) == "1" or m.group(4) == "1"):
+            bad.append("%s: %s" % (kernel, line.strip()))
+    if bad and not os.environ.get("R2L_ALLOW_PK_OPSEL"):
+        raise RuntimeError("ISA audit of %s: packed fp32 op with a low-lane src1/src2 op_sel (unsafe on gfx950 with >1 wave per "
+                           "SIMD, see r2l_amd/build.py):\n  %s" % (what, "\n  ".join(bad[:8])))
+    return bad
+
+
 def _compile(src):
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
@@ -44,10 +67,23 @@ def _compile(src):
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-I", os.path.join(HERE, "..", "include"), "-c", path, "-o", obj]
+    # -save-temps=obj: the device assembly of this very compilation lands next to the object (audited, then removed)
+    cmd = [HIPCC] + FLAGS + ["-save-temps=obj", "-I", os.path.join(HERE, "..", "include"), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    base = os.path.join(OBJDIR, src.replace(".hip", ""))
+    temps = [t for t in glob.glob(base + "-hip-*") + glob.glob(base + "-host-*") + glob.glob(base + ".hip-hip-*")]
+    try:
+        asm = [t for t in temps if t.endswith(".s") and "-hip-amdgcn" in t]
+        if not asm:
+            raise RuntimeError("ISA audit: no device assembly produced for %s" % src)
+        for t in asm:
+            with open(t) as f:
+                audit_isa(f.read(), src)
+    finally:
+        for t in temps:
+            os.remove(t)
     with open(stamp, "w") as f:
         f.write(dig)
     return obj, True

@@ -448,6 +448,12 @@ enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP = 1, R2L_VARIANT_COOP16 = 2 };
 #define R2L_COOPF_MAX_RAYS 16384
 #endif
 #define R2L_MAIN_ROUND_RAYS 32768  // one wave per 32-ray tile, four per workgroup, one workgroup per CU, 256 CUs
+// Keep a scalar fp32 chain scalar.  hipcc's SLP vectoriser pairs independent fp32 chains into packed ops with op_sel swizzles;
+// the form whose LOW lane reads the HIGH dword of src1 (`v_pk_fma_f32 ... op_sel:[0,1,0]`) lost results on gfx950 under two
+// waves per SIMD (r2l_coopf.h) and r2l_amd/build.py refuses objects that contain it: an empty asm on the value
+// between the operations is enough to keep them apart.
+__device__ __forceinline__ void r2l_no_pack(float& v) { asm volatile("" : "+v"(v)); }
+
 static inline bool r2l_env_on(const char* name) {
     const char* e = getenv(name);
     return e && e[0] && e[0] != '0';

@@ -20,6 +20,7 @@
 //   * The kernel is bound by that weight stream (256 KiB per layer and workgroup from L2), not by the matrix pipe.
 #pragma once
 #include "r2l_f2.h"
+#include <stdio.h>
 
 // register-ring depth (stages of A operands in flight per wave), per tiles-per-workgroup.  A one-tile workgroup has the CU
 // to itself and registers to spare, but a ring of 8 (32 loads in flight per wave, no spills) measured 0.264 ms against 0.259
@@ -30,19 +31,43 @@
 #define FC_RING_TWO 4
 template <int NT> struct FcRingOf { static constexpr int value = NT == 1 ? FC_RING_ONE : FC_RING_TWO; };
 #define FC_BOP_BYTES 32768   // one B-operand image: 16 stages x (hi, mid) x 1 KiB
-// Dynamic LDS added to every one-tile launch (64 - 72 KiB static) so that a CU never holds TWO of these workgroups.  Measured
-// (round 2, tools/coopf_coresidency.py): with two workgroups of the training forward (236 - 252 VGPRs: the two waves of a SIMD
-// own 480 - 512 of its 512 registers) on one CU, the tail's packed-FMA chain returned wrong red partial sums in lanes 48 - 63
-// of the older workgroup (rays 16 - 31 of its tile, 1 - 60 tiles per launch, every launch of 16 384 rays) although its inputs
-// (stash, weights) were bit-exact and a recomputation in the same kernel was right; the render forward (206 VGPRs) and the
-// dX chain (184) were exact under the same co-residency.  Not the register allocation (the render kernel padded to 256 VGPRs
-// stays exact); gone when the tail's packed-FMA chain is broken up by empty asm barriers, yet the same instruction pattern
-// is bit-exact in other multi-wave kernels: not understood.  Avoided structurally: one workgroup per CU (what
-// these launches are anyway: <= one tile per CU, see r2l_coopf_two_tiles); two-tile workgroups (143 KiB) cannot share a CU.
-// (R2L_COOPF_SHARE_CU=1 drops the padding: the reproducer's switch, nothing else uses it.)
+// ONE one-tile workgroup per CU, as a guarantee.  Round 2 found that with two workgroups of the one-tile training forward on
+// a CU (two waves per SIMD) single rays came back with a wrong red channel; round 3 pinned it down (DESIGN.md §2,
+// tools/coopf_forensics.py, profiles/r03_coresidency.md): exactly ONE term of the tail's 32-term dot product is missing, always
+// in the low lane of a `v_pk_fma_f32 ... op_sel:[0,1,0]` (low lane fed by src1's HIGH dword), always in lanes 48 - 63, with
+// bit-exact inputs — independent of what produced the operands and when (s_nop / reordered v_movs / vmcnt(0) in front of it do
+// not help), never in the op_sel_hi-only form of the same FMA, never with one wave per SIMD.  The tails are now written so
+// that hipcc cannot form that instruction (r2l_no_pack), the build refuses any packed-fp32 op with a low-lane src1 / src2
+// op_sel (r2l_amd/build.py: ISA audit), and — belt and braces, because the trigger is a property of the silicon that only
+// the absence of a second wave is known to avoid — every one-tile launch still carries FC_SOLO_LDS_BYTES of dynamic LDS
+// (64 - 72 KiB static + 24 KiB > half of the CU's 160 KiB), checked per kernel with hipOccupancyMaxActiveBlocksPerMultiprocessor
+// before its first launch (fc_check_solo).  It costs nothing: these launches have at most one tile per CU by construction
+// (r2l_coopf_two_tiles), and two-tile workgroups (143 KiB) cannot share a CU at all.  Only the reproducer builds
+// (tools/build_variant.sh ... -DFC_ALLOW_SHARE_CU) drop the padding.
+#ifdef FC_ALLOW_SHARE_CU
+#define FC_SOLO_LDS_BYTES 0
+#else
 #define FC_SOLO_LDS_BYTES 24576
-static inline unsigned r2l_coopf_solo_lds() { return r2l_env_on("R2L_COOPF_SHARE_CU") ? 0u : (unsigned)FC_SOLO_LDS_BYTES; }
-
+#endif
+// the launch would put at most one such workgroup on a CU?  (asked once per kernel; error text in r2l_last_error)
+template <class K>
+static inline int fc_check_solo(K kernel, const char* name, int* cached) {
+#ifndef FC_ALLOW_SHARE_CU
+    if (*cached == 0) {
+        int nb = 0;
+        R2L_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, (size_t)FC_SOLO_LDS_BYTES));
+        *cached = nb == 1 ? 1 : -nb - 1;
+    }
+    if (*cached != 1) {
+        char msg[192];
+        snprintf(msg, sizeof(msg), "%s: %d workgroups per CU possible, the one-tile cooperative kernels require exactly 1 "
+                 "(r2l_coopf.h FC_SOLO_LDS_BYTES)", name, -*cached - 1);
+        r2l_set_error_msg(msg);
+        return (int)hipErrorLaunchFailure;
+    }
+#endif
+    return 0;
+}
 typedef __attribute__((address_space(3))) u32x4 fc_lds_u32x4;
 __device__ __forceinline__ u32x4 fc_lds_read(unsigned addr) { return *(fc_lds_u32x4*)(size_t)addr; }
 __device__ __forceinline__ void fc_lds_write(unsigned addr, u32x4 v) { *(fc_lds_u32x4*)(size_t)addr = v; }

@@ -251,7 +251,11 @@ int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb,
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     if (r2l_coopf_two_tiles(tiles)) hipLaunchKernelGGL(r2l_coopf_bwd_kernel<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(r2l_coopf_bwd_kernel<1>, dim3((unsigned)tiles), dim3(256), r2l_coopf_solo_lds(), stream, a);
+    else {
+        static int solo_ok = 0;
+        if (int e = fc_check_solo(r2l_coopf_bwd_kernel<1>, "r2l_coopf_bwd_kernel<1>", &solo_ok)) return e;
+        hipLaunchKernelGGL(r2l_coopf_bwd_kernel<1>, dim3((unsigned)tiles), dim3(256), FC_SOLO_LDS_BYTES, stream, a);
+    }
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
             const float dy = -(((float)pj - (float)a.H * 0.5f) / a.focal);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                d[k] = (dx * a.c2w[4 * k + 0] + dy * a.c2w[4 * k + 1]) + (-1.0f) * a.c2w[4 * k + 2];
+                float dxr = dx * a.c2w[4 * k + 0];
+                r2l_no_pack(dxr);  // (no packed multiply + swizzled add for the pair of products: r2l_common.h)
+                d[k] = (dxr + dy * a.c2w[4 * k + 1]) + (-1.0f) * a.c2w[4 * k + 2];
                 o[k] = a.c2w[4 * k + 3];
             }
         }
@@ -259,12 +261,55 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
 #pragma unroll
                 for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
                 f32x4 yv;
+#if defined(FC_TAIL_ASM) && FC_TAIL_ASM > 0
+                // diagnostic builds (tools/coopf_forensics.py, tools/build_variant.sh): the (R, G) accumulation as hand-placed
+                // v_mov / v_pk_fma_f32 sequences in the form hipcc used to generate here, one thing varied per build (DESIGN.md §2,
+                // co-residency fault).  0: no asm, the compiler's own packed chain (the round-2 kernel)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[e] = x[rt][tt][4 * q + e] + x0[rt][tt][4 * q + e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    typedef float fc_f32x2 __attribute__((ext_vector_type(2)));
+                    fc_f32x2 acc = {p3[0], p3[1]};
+#if FC_TAIL_ASM == 4
+                    const fc_f32x2 yp = {yv[e], yv[e]};
+                    const bool odd_form = false;
+#else
+                    const fc_f32x2 yp = {yv[e & ~1], yv[e | 1]};
+                    const bool odd_form = e & 1;
+#endif
+#if FC_TAIL_ASM == 5  // nothing of this wave in flight in the vector-memory pipe while the packed FMAs run
+#define FC_MOVS "s_waitcnt vmcnt(0)\n\tv_mov_b32 v251, %2\n\tv_mov_b32 v250, %1\n\t"
+#elif FC_TAIL_ASM == 3
+#define FC_MOVS "v_mov_b32 v250, %1\n\tv_mov_b32 v251, %2\n\t"
+#elif FC_TAIL_ASM == 2
+#define FC_MOVS "v_mov_b32 v251, %2\n\tv_mov_b32 v250, %1\n\ts_nop 0\n\t"
+#else
+#define FC_MOVS "v_mov_b32 v251, %2\n\tv_mov_b32 v250, %1\n\t"
+#endif
+                    if (odd_form)
+                        asm volatile(FC_MOVS "v_pk_fma_f32 %0, v[250:251], %3, %0 op_sel:[0,1,0]"
+                                     : "+v"(acc) : "v"(wv[0][e]), "v"(wv[1][e]), "v"(yp) : "v250", "v251");
+                    else
+                        asm volatile(FC_MOVS "v_pk_fma_f32 %0, v[250:251], %3, %0 op_sel_hi:[1,0,1]"
+                                     : "+v"(acc) : "v"(wv[0][e]), "v"(wv[1][e]), "v"(yp) : "v250", "v251");
+                    p3[0] = acc[0];
+                    p3[1] = acc[1];
+                    p3[2] = __builtin_fmaf(wv[2][e], yv[e], p3[2]);
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     yv[e] = x[rt][tt][4 * q + e] + x0[rt][tt][4 * q + e];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) p3[c] = __builtin_fmaf(wv[c][e], yv[e], p3[c]);
+                    for (int c = 0; c < 3; ++c) {
+                        p3[c] = __builtin_fmaf(wv[c][e], yv[e], p3[c]);
+#ifndef FC_TAIL_ASM
+                        r2l_no_pack(p3[c]);  // three scalar v_fmac chains: no v_pk_fma_f32 op_sel:[0,1,0] (r2l_coopf.h)
+#endif
+                    }
                 }
+#endif
                 // slot n of save_x: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
                 if (SAVE) *reinterpret_cast<f32x4*>(a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 32 * T + 8 * q + 4 * h) = yv;
             }
@@ -303,15 +348,25 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
     // up to one workgroup per CU: one ray tile each; beyond, two tiles per workgroup share every weight load
     const bool two = r2l_coopf_two_tiles(tiles);
     const dim3 grid((unsigned)(two ? (tiles + 1) / 2 : tiles)), block(256);
+    static int solo_ok[3] = {0, 0, 0};  // one-tile kernels: at most one workgroup per CU, verified before the first launch
     if (c2w_host12) {
         if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 1>), grid, block, r2l_coopf_solo_lds(), stream, a);
+        else {
+            if (int e = fc_check_solo(r2l_coopf_fwd_kernel<true, false, 1>, "r2l_coopf_fwd_kernel<pose>", &solo_ok[0])) return e;
+            hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 1>), grid, block, FC_SOLO_LDS_BYTES, stream, a);
+        }
     } else if (save_x) {
         if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 1>), grid, block, r2l_coopf_solo_lds(), stream, a);
+        else {
+            if (int e = fc_check_solo(r2l_coopf_fwd_kernel<false, true, 1>, "r2l_coopf_fwd_kernel<save>", &solo_ok[1])) return e;
+            hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 1>), grid, block, FC_SOLO_LDS_BYTES, stream, a);
+        }
     } else {
         if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 1>), grid, block, r2l_coopf_solo_lds(), stream, a);
+        else {
+            if (int e = fc_check_solo(r2l_coopf_fwd_kernel<false, false, 1>, "r2l_coopf_fwd_kernel<rays>", &solo_ok[2])) return e;
+            hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, false, 1>), grid, block, FC_SOLO_LDS_BYTES, stream, a);
+        }
     }
     R2L_CHECK(hipGetLastError());
     return 0;

@@ -18,7 +18,11 @@ __global__ void r2l_stratified_z_kernel(const float* __restrict__ near, const fl
         const int64_t r = i / S;
         const int s = (int)(i % S);
         const float n = near[r * nf_stride], f = far[r * nf_stride];
-        auto zv = [&](int k) { return n * ttab[S + k] + f * ttab[k]; };
+        auto zv = [&](int k) {
+            float a = n * ttab[S + k];
+            r2l_no_pack(a);  // (no packed multiply + swizzled add for the pair of products: r2l_common.h)
+            return a + f * ttab[k];
+        };
         float z = zv(s);
         if (t_rand != nullptr) {
             const float lo = s == 0 ? z : .5f * (z + zv(s - 1));

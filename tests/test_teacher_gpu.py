@@ -67,6 +67,22 @@ def test_raw2outputs_shapes_vs_oracle(S, R):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-5, atol=3e-6)
 
 
+def _sample_pdf_last_admissible(bins, weights, got_last):
+    """Membership test for sample_pdf(det=True)'s last sample (u = 1.0): the two answers the reference's op sequence
+    (/root/reference/utils/run_nerf_raybased_helpers.py:315-328) can give, depending on whether its cdf[-1] rounds to
+    <= 1 (clamped index pair (last, last): bins[-1]) or > 1 (pair (last - 1, last), interpolated)."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    cand_a = bins[:, -1]
+    denom = cdf[:, -1] - cdf[:, -2]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    cand_b = bins[:, -2] + (1.0 - cdf[:, -2]) / denom * (bins[:, -1] - bins[:, -2])
+    g = torch.as_tensor(got_last)
+    tol = 1e-5 + 1e-5 * cand_a.abs()
+    return (((g - cand_a).abs() <= tol) | ((g - cand_b).abs() <= tol)).numpy()
+
+
 def test_sample_pdf_sort_golden(golden_dir):
     from r2l_amd.render import sample_pdf_sort
     g = np.load(os.path.join(golden_dir, "sample_pdf.npz"))
@@ -86,9 +102,13 @@ def test_sample_pdf_sort_golden(golden_dir):
         got = zs.cpu().numpy()
         bad = np.abs(got - ref.numpy()) > 1e-5 + 1e-5 * np.abs(ref.numpy())
         if det:
-            # u == 1.0 (det's last sample) sits exactly on cdf[-1] ~= 1 +- 1 ulp: in a degenerate last bin
-            # (pdf < 1e-5, helpers:325-326) the reference's own answer flips between bins[-1] and bins[-2] with the
-            # rounding of its vectorised torch.sum — not reproducible across CPUs, excluded here.
+            # u == 1.0 (det's last sample) sits exactly on cdf[-1] ~= 1 +- 1 ulp, and which side it falls on depends on the
+            # rounding of the reference's own vectorised torch.sum (not reproducible across CPUs).  Both outcomes are
+            # spelled out by helpers:315-328 and the kernel must return ONE OF THEM:
+            #   cdf[-1] <= 1: inds = len(cdf) -> below = above = last -> denom 0 -> 1 -> sample = bins[-1] exactly;
+            #   cdf[-1] >  1: inds = last -> (below, above) = (last - 1, last), denom < 1e-5 -> 1 in a degenerate bin.
+            ok_last = _sample_pdf_last_admissible(mids, w, got[:, -1])
+            assert ok_last.all(), np.argwhere(~ok_last)[:10]
             bad[:, -1] = False
         assert not bad.any(), np.argwhere(bad)[:10]
         ref_all = torch.sort(torch.cat([z, zs.cpu()], -1), -1)[0]

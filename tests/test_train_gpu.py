@@ -364,6 +364,51 @@ def test_coopf_two_tiles_bitwise(chain_variant, monkeypatch):
     assert torch.nn.functional.cosine_similarity(out[2], ref[2], dim=0).item() > 0.9999
 
 
+def test_coopf_one_tile_beside_other_kernels(chain_variant, monkeypatch):
+    """The one-tile cooperative chains (BASELINE configs[2] / [3]: 4096 rays per step) stay bit-exact while OTHER kernels are
+    resident on the same CUs: a second stream keeps every CU busy with (a) elementwise waves (small register footprint: they fit
+    beside a 4 x 240-VGPR cooperative workgroup on every SIMD) and (b) fp16 matrix-pipe waves, for the whole duration of the
+    step.  (Round 2's co-residency fault — two waves on a SIMD, a lost FMA term in the forward's tail — is removed at its
+    instruction, csrc/r2l_coopf.h; a data-parallel step runs beside RCCL kernels, so neighbours are the normal case.)"""
+    if chain_variant != "coopf":
+        pytest.skip("one comparison")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd import _lib
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=43, seed=0)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    n = 4096
+    assert _lib.load().r2l_coop_tiles_for(n, 43) == 1
+    g = torch.Generator().manual_seed(9)
+    o = (torch.randn(n, 3, generator=g) * 1.5).cuda(); d = torch.randn(n, 3, generator=g).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda(); tr = torch.rand(n, 16, generator=g).cuda()
+    m = build_model(sd, 43)
+    t = R2LTrainer(m, ps)
+
+    def run():
+        rgb = t.forward_backward(o, d, tgt, perturb=1.0, t_rand=tr)
+        return t.loss_out.clone(), rgb.clone(), t.grads.clone()
+
+    ref = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.rand(64 << 20, device="cuda")
+    a16 = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+    for kind in ("elementwise", "matmul", "elementwise", "matmul"):
+        with torch.cuda.stream(side):
+            for _ in range(12):  # ~10 ms of neighbours: longer than the 0.8 ms step launched beside them
+                if kind == "elementwise":
+                    big.mul_(1.0000001).add_(1e-9)
+                else:
+                    a16 @ a16
+        outs = [run() for _ in range(4)]
+        side.synchronize()
+        torch.cuda.synchronize()
+        for out in outs:
+            for x, y in zip(out, ref):
+                assert torch.equal(x, y), kind
+
+
 def test_mid_size_step_on_cooperative_chains(chain_variant, monkeypatch):
     """Launches between one and one and a half rounds of the one-wave-per-tile kernels (32 769 .. 49 152 rays) take the
     two-tile cooperative chains by default (csrc/r2l_common.h r2l_use_coopf): same step within rounding, ragged size."""

@@ -1,7 +1,11 @@
-"""Reproducer of the co-residency fault of the cooperative training forward (csrc/r2l_coopf.h, FC_SOLO_LDS_BYTES): one ray
-tile per workgroup WITHOUT the LDS padding (R2L_COOPF_SHARE_CU=1), on launches of more tiles than CUs, against the two-tile
-kernel (143 KiB of LDS: never two on a CU).  Prints, per mode, how many of 10 launches differ and where.  GPU box only.
-  python tools/coopf_coresidency.py [N=16384]"""
+"""Reproducer of the co-residency fault of the cooperative training forward (csrc/r2l_coopf.h): one ray tile per
+workgroup on launches of more tiles than CUs, compared bit for bit with the two-tile kernel (143 KiB of LDS: never two on a
+CU).  The shipped library keeps one-tile workgroups on separate CUs (FC_SOLO_LDS_BYTES, checked at launch), so the fault only
+shows in reproducer builds of the forward:
+  tools/build_variant.sh share_r2  r2l_coopf_fwd.hip -DFC_ALLOW_SHARE_CU -DFC_TAIL_ASM=0   # round 2's tail, two per CU
+  tools/build_variant.sh share_fix r2l_coopf_fwd.hip -DFC_ALLOW_SHARE_CU                   # the shipped tail, two per CU
+  R2L_LIB_PATH=tools/_bin/share_r2/libr2l_hip.so python tools/coopf_coresidency.py [N=16384]
+Prints, per mode, how many of 10 launches differ and where.  GPU box only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,8 +34,8 @@ def run(tiles, mode):
     return rgb, t.grads.clone()
 
 
-for share in ("0", "1"):
-    os.environ["R2L_COOPF_SHARE_CU"] = share
+print("library:", os.environ.get("R2L_LIB_PATH", "(shipped)"))
+for share in ("-",):
     for mode in ("render", "train"):
         ref = run("2", mode)
         bad, where = 0, None
@@ -45,5 +49,5 @@ for share in ("0", "1"):
                     where = "rgb differs on %d rays (first %s), max %.3g, channels %s; grads equal: %s" % (
                         idx.numel(), idx[:4].tolist(), dd.max().item(),
                         ((r[0] - ref[0]).abs().amax(0) > 0).tolist(), torch.equal(r[-1], ref[-1]) if mode == "train" else "-")
-        print("N %d  share_cu=%s  %-6s one tile per workgroup vs two: %d of 10 launches differ%s" % (
+        print("N %d  %s %-6s one tile per workgroup vs two: %d of 10 launches differ%s" % (
             n, share, mode, bad, ("  [" + where + "]") if where else ""))
