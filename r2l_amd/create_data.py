@@ -8,6 +8,7 @@ Per pose the whole stack runs on the GPU through libr2l_hip.so: get_rays -> stra
 RandomState, so the reference's single global np.random replay is distributional, not bitwise.
 """
 import os
+import re
 import queue
 import shutil
 import threading
@@ -71,6 +72,15 @@ def shard_index_base(rank, world, n_pose, chunk_poses, files_per_flush, n_existi
     return n_existing + rank * most_flushes * files_per_flush
 
 
+def next_free_shard_index(names):
+    """First unused data_<k>.npy index of a kept directory: one past the LARGEST index present.  (The reference counts the
+    files, create_data.py:789-792, which is the same thing for its gap-free single-process numbering; a multi-rank run here
+    leaves gaps between the rank ranges — shard_index_base sizes them for the largest flush count — so a count would make
+    the next run overwrite existing shards.)"""
+    used = [int(m.group(1)) for m in (re.fullmatch(r"data_(\d+)\.npy", x) for x in names) if m]
+    return max(used) + 1 if used else 0
+
+
 def main(argv=None):
     args = parse_args(argv)
     validate_accelerated(args)
@@ -96,7 +106,7 @@ def main(argv=None):
         os.makedirs(datadir_new, exist_ok=True)
     if world > 1:
         torch.distributed.barrier()
-    n_existing = len([x for x in os.listdir(datadir_new) if x.endswith(".npy")])  # kept directory: numbering continues
+    n_existing = next_free_shard_index(os.listdir(datadir_new))  # kept directory: numbering continues behind it
     if world > 1:
         torch.distributed.barrier()  # every rank has counted before any rank writes
     n_pose = args.n_pose_kd if isinstance(args.n_pose_kd, int) else int(args.n_pose_kd[0])

@@ -38,6 +38,15 @@ def bucket_plan(n_block, n_buckets):
     return plan
 
 
+def split_shards(n_rand, world):
+    """--N_rand shard files per step (GLOBAL, as in the reference: one DataLoader batch that nn.DataParallel scatters,
+    main.py:794-806,1374) over `world` ranks: the first N_rand % world ranks take one more.  Every rank needs at least one."""
+    if n_rand < world:
+        raise ValueError("--N_rand %d (shard files per step, global) is smaller than the %d ranks" % (n_rand, world))
+    base, rem = divmod(int(n_rand), int(world))
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
 class GradAllReducer:
     def __init__(self, process_group=None, bucket_floats=0):
         self.pg = process_group

@@ -17,6 +17,7 @@ from .logger import Logger
 from .metrics import img2mse, mse2psnr, ssim, to8b
 from .nerf_raybased import NeRF_v3_2, PointSampler, PositionalEmbedder
 from .options import parse_args, validate_accelerated
+from .dist_utils import split_shards
 from .train_step import R2LTrainer, lr_schedule
 
 
@@ -75,6 +76,16 @@ class HardRayPool:
                 self._gen.manual_seed(self.seed)
             return torch.randperm(n_rows, device=device, generator=self._gen)[:n_out]
         return torch.as_tensor(self.rng.permutation(n_rows)[:n_out], device=device)
+
+    def extra_rays(self, batch_size, updates_done):
+        """Rays augment() appends to a batch of `batch_size` after `updates_done` update() calls on batches of that size — a
+        pure function of the two, so every rank of a data-parallel run can tell every other rank's step size without a
+        collective (driver.train: global ray count of a step when --N_rand does not divide by the world size)."""
+        n_in, n_out = self.sizes(batch_size)
+        if n_in <= 0:
+            return 0
+        steps_to_full = max(1, -(-int(np.ceil(batch_size * self.mul)) // n_in))
+        return n_out if updates_done >= steps_to_full else 0
 
     def augment(self, rays_o, rays_d, target):
         if not self.full:
@@ -186,15 +197,16 @@ def save_video(rgbs, logger, expid, iter_, tag, rank=0, world=1, device=None):
     from .video import write_mjpeg_avi
     frames = to8b(rgbs) if rgbs.numel() else np.zeros((0, 0, 0, 3), np.uint8)
     if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, frames)
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(frames, parts, dst=0)  # only rank 0 needs (and holds) the other ranks' frames
         if rank != 0:
             return None
         total = sum(p.shape[0] for p in parts)
-        hw = next(p.shape[1:] for p in parts if p.shape[0])
+        hw = next((p.shape[1:] for p in parts if p.shape[0]), (0, 0, 3))
         allf = np.zeros((total,) + tuple(hw), np.uint8)
         for r, p in enumerate(parts):
-            allf[r::world] = p
+            if p.shape[0]:  # (a rank beyond the number of poses rendered nothing)
+                allf[r::world] = p
         frames_np = allf
     else:
         frames_np = frames
@@ -356,10 +368,19 @@ def main(argv=None):
     # --N_rand is the GLOBAL batch in shard files per step, as in the reference (its DataLoader builds one batch that
     # nn.DataParallel then splits over the GPUs, main.py:794-806,1374): each rank loads N_rand / world shards, so the
     # README command keeps its optimisation schedule (lrate, N_iters, hard-ray pool size) at any GPU count
-    if args.N_rand % world:
-        raise SystemExit("--N_rand %d (shard files per step, global) must be divisible by the %d ranks" % (args.N_rand, world))
-    loader = D.RayShardLoader(files, args.N_rand // world, rank=rank, world=world, device=device,
+    # (not divisible by the rank count — the README's --N_rand 20 on 8 GPUs —: the first N_rand % world ranks take one shard
+    # more and every rank's gradient is weighted by its share of the step's rays, below; nn.DataParallel scattered uneven
+    # batches the same way, main.py:1374)
+    try:
+        shards = split_shards(args.N_rand, world)
+    except ValueError as e:
+        raise SystemExit(str(e))
+    loader = D.RayShardLoader(files, shards[rank], rank=rank, world=world, device=device,
                               threads=max(1, min(args.num_workers, 16)))
+    uneven = len(set(shards)) > 1
+    if uneven:
+        logger.info("--N_rand %d over %d ranks: %s shard files per rank and step; gradients weighted by ray share" %
+                    (args.N_rand, world, shards))
     logger.info("Loaded data. Now total #train files: %d (this rank: %d)" % (len(files), len(loader.files)))
     trainer = R2LTrainer(model, point_sampler, lw_rgb=args.lw_rgb)
     if ckpt is not None and args.resume:
@@ -377,7 +398,11 @@ def main(argv=None):
         if pool is not None:
             rays_o, rays_d, target = pool.augment(rays_o, rays_d, target)
         t_data = time.time() - t0
-        rgb, loss_out = trainer.step(rays_o, rays_d, target, lr, perturb=args.perturb)
+        n_global = None
+        if uneven:  # this step's rays over all ranks: shard rows + what each rank's hard-ray pool appends (deterministic)
+            rows = [q * loader.rows_per_file for q in shards]
+            n_global = sum(r + (pool.extra_rays(r, i - start - 1) if pool is not None else 0) for r in rows)
+        rgb, loss_out = trainer.step(rays_o, rays_d, target, lr, perturb=args.perturb, n_global=n_global)
         if pool is not None:
             pool.update(rgb, rays_o, rays_d, target, batch_size)
         t_batch = time.time() - t0

@@ -95,8 +95,11 @@ class R2LTrainer:
             self._bwd_packed[layout] = ver
 
     # ---- one optimisation step --------------------------------------------------------------------------------------
-    def forward_backward(self, rays_o, rays_d, target, perturb=0., t_rand=None, zero_grad=True):
-        """Forward + backward on this rank's rays; leaves d(loss)/d(params) in self.grads. Returns rgb [N,3]."""
+    def forward_backward(self, rays_o, rays_d, target, perturb=0., t_rand=None, zero_grad=True, n_global=None):
+        """Forward + backward on this rank's rays; leaves d(loss)/d(params) in self.grads. Returns rgb [N,3].
+        n_global: rays of ALL ranks in this step when the ranks' shares differ (--N_rand not divisible by the world size):
+        the gradient is then scaled so that the all-reduced sum, divided by world in Adam, is the reference's single global
+        mean (main.py:1377); None = equal shares (n_global = world * N)."""
         eng = self.eng
         n = rays_o.shape[0]
         eng.ensure_packed(n)
@@ -113,7 +116,7 @@ class R2LTrainer:
         rgb = eng.forward_rays(rays_o, rays_d, self.ps.z_vals, perturb, t_rand, save=(self.save_x, self.save_t))
         if zero_grad:
             self.grads.zero_()
-        grad_scale = 2.0 * self.lw_rgb / (3.0 * n)
+        grad_scale = 2.0 * self.lw_rgb / (3.0 * n) if n_global is None else 2.0 * self.lw_rgb * self.world() / (3.0 * n_global)
         args = (_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target), None,
                 _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat), eng.n_block, grad_scale,
                 _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt), _ptr(self.sqerr), _ptr(self.grads), _ptr(self.dw_slab), n,
@@ -124,8 +127,10 @@ class R2LTrainer:
             part = self.lib.r2l_backward_part
             _lib.check(part(*args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0), "r2l_backward_part(chain, tail)")
             for lo, hi, flat_lo, flat_hi in bucket_plan(eng.n_block, self.n_buckets):
-                what = _lib.BWD_BODY if hi > lo else _lib.BWD_HEAD
-                _lib.check(part(*args, what, lo, hi), "r2l_backward_part(%d, %d)" % (lo, hi))
+                if flat_lo == 0:
+                    _lib.check(part(*args, _lib.BWD_HEAD, 0, 0), "r2l_backward_part(head)")
+                elif hi > lo:  # (a net without body blocks has one empty body bucket: only its tail range to exchange)
+                    _lib.check(part(*args, _lib.BWD_BODY, lo, hi), "r2l_backward_part(%d, %d)" % (lo, hi))
                 self.reducer.submit(self.grads[flat_lo:flat_hi])
         else:
             _lib.check(self.lib.r2l_backward(*args), "r2l_backward")
@@ -154,10 +159,10 @@ class R2LTrainer:
                                    self.reducer.grad_scale(), _stream()), "r2l_adam_step")
         eng.mark_dirty()
 
-    def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None):
+    def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None, n_global=None):
         """zero_grad + forward + backward + all-reduce + Adam.  Returns (rgb[N,3], loss_out[2] = [loss, psnr]) on
         the device (no host sync)."""
-        rgb = self.forward_backward(rays_o, rays_d, target, perturb, t_rand)
+        rgb = self.forward_backward(rays_o, rays_d, target, perturb, t_rand, n_global=n_global)
         self.allreduce_grads()
         self.adam(lr)
         return rgb, self.loss_out

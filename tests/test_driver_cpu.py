@@ -261,3 +261,42 @@ def test_create_data_rank_index_ranges_never_overlap():
         ranges.sort()
         assert all(a[1] <= b[0] for a, b in zip(ranges, ranges[1:])), (n_pose, world, chunk, ranges)
     assert shard_index_base(2, 3, 301, 100, fpf) == 2 * 2 * fpf  # the advisor's example: flush counts 1, 2, 1
+
+
+def test_create_data_numbering_continues_behind_a_gapped_directory():
+    """a 3-rank, 301-pose run leaves gaps between the rank ranges; the next run into the kept directory must start
+    behind the LARGEST index there, not at the file count (which would overwrite the last rank's shards)."""
+    from r2l_amd.create_data import next_free_shard_index, shard_index_base
+    fpf = (100 * 400 * 400) // 4096
+    names = []
+    for rank in range(3):
+        mine = [i for i in range(1, 302) if i % 3 == rank]
+        base = shard_index_base(rank, 3, 301, 100, fpf)
+        names += ["data_%d.npy" % k for k in range(base, base + (len(mine) * 400 * 400) // 4096)]
+    used = sorted(int(n[5:-4]) for n in names)
+    assert len(used) < used[-1] + 1  # there ARE gaps: counting files would land inside rank 2's range
+    nxt = next_free_shard_index(names + ["notes.txt", "data_x.npy"])
+    assert nxt == used[-1] + 1
+    assert min(shard_index_base(r, 2, 10, 100, fpf, nxt) for r in range(2)) > used[-1]
+    assert next_free_shard_index([]) == 0
+
+
+def test_uneven_n_rand_split_and_pool_schedule():
+    """--N_rand that does not divide by the rank count (README: --N_rand 20 on 8 GPUs): floor / ceil shards per rank, and the
+    per-rank step size incl. the hard-ray pool is a pure function every rank can evaluate for every other rank."""
+    from r2l_amd.dist_utils import split_shards
+    from r2l_amd.driver import HardRayPool
+    assert split_shards(20, 8) == [3, 3, 3, 3, 2, 2, 2, 2] and sum(split_shards(20, 8)) == 20
+    assert split_shards(16, 8) == [2] * 8 and split_shards(7, 3) == [3, 2, 2]
+    with pytest.raises(ValueError):
+        split_shards(3, 8)
+    for batch in (4096 * 3, 4096 * 2, 1000):
+        pool = HardRayPool(0.2, 20, rng=np.random.RandomState(0))
+        g = torch.Generator().manual_seed(batch)
+        for updates_done in range(130):
+            o, d, t = (torch.randn(batch, 3, generator=g) for _ in range(3))
+            o2, d2, t2 = pool.augment(o, d, t)
+            assert o2.shape[0] - batch == pool.extra_rays(batch, updates_done), (batch, updates_done)
+            pool.update(torch.rand(o2.shape[0], 3, generator=g), o2, d2, t2, batch)
+        assert pool.full and pool.extra_rays(batch, 130) == int(0.2 * batch)
+    assert HardRayPool(0.0, 20).extra_rays(4096, 10 ** 6) == 0

@@ -35,11 +35,13 @@ assert tr.world() == 2 and tr.n_buckets == 4 and os.environ.get("R2L_RESERVE_CUS
 assert parameters_in_sync(tr.eng.flat)
 assert torch.equal(m.state_dict()["body.1.body.0.weight"].cpu(), sd0["body.1.body.0.weight"])
 g = torch.Generator().manual_seed(3)
-n = 2 * (5000 if variant == "main" else 1024)
+n = 2 * (5000 if variant == "main" else 4096 if variant == "coopf" else 1024)
 o = torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])
 d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
 tgt = torch.rand(n, 3, generator=g)
-sl = slice(rank * n // world, (rank + 1) * n // world)
+uneven = os.environ.get("R2L_TEST_UNEVEN") == "1"   # ranks take 5/8 and 3/8 of the batch (--N_rand not divisible by world)
+cut = [0, n * 5 // 8, n] if uneven else [0, n // 2, n]
+sl = slice(cut[rank], cut[rank + 1])
 emb = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
 ref = {k: v.clone() for k, v in sd0.items()}
 mo = {k: torch.zeros_like(v) for k, v in ref.items()}
@@ -49,15 +51,15 @@ for step in (1, 2, 3):
     loss, _, gr = O.r2l_loss_and_grads(ref, emb, tgt)   # ONE process, the full batch
     for k in ref:
         ref[k], mo[k], vo[k] = O.adam_step(ref[k], gr[k], mo[k], vo[k], step, lr)
-    tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda())
+    tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda(), n_global=n if uneven else None)
     assert tr.reducer.pending() == len(bucket_plan(nb, tr.n_buckets)) == 4   # 3 body buckets (one per block) + the head, in flight until Adam needs them
     tr.allreduce_grads()
     assert tr.reducer.pending() == 0
     tr.adam(lr)
-    # mean of the two half-batch losses == the full-batch loss
-    lo = tr.loss_out[:1].clone()
+    # ray-share-weighted mean of the two ranks' losses == the full-batch loss
+    lo = tr.loss_out[:1].clone() * (cut[rank + 1] - cut[rank]) / n
     dist.all_reduce(lo)
-    assert abs(lo.item() / world - loss.item()) < 2e-6, (step, lo.item() / world, loss.item())
+    assert abs(lo.item() - loss.item()) < 2e-6, (step, lo.item(), loss.item())
     assert parameters_in_sync(tr.eng.flat), step
 new = m.state_dict()
 worst, cos = 0., 1.
@@ -65,7 +67,7 @@ for k in ref:
     worst = max(worst, (new[k].cpu() - ref[k]).abs().max().item())
     a, b = (new[k].cpu() - sd0[k]).flatten().double(), (ref[k] - sd0[k]).flatten().double()
     cos = min(cos, (torch.dot(a, b) / (a.norm() * b.norm())).item())
-if variant == "main":   # fp16-rounded weight-gradient operands: tests/test_train_gpu.py::test_three_adam_steps_vs_oracle
+if variant in ("main", "coopf"):   # fp16-rounded weight-gradient operands: tests/test_train_gpu.py::test_three_adam_steps_vs_oracle
     assert cos > 0.9998 and worst < 2e-3, (cos, worst)
 else:
     assert worst < 2e-5, worst
@@ -75,12 +77,14 @@ print("rank", rank, variant, "ok: max |param - single-process oracle| = %%.2e, m
 """
 
 
-@pytest.mark.parametrize("variant", ["coop16", "main"])
-def test_two_ranks_train_like_one_process(tmp_path, variant):
+@pytest.mark.parametrize("variant,uneven", [("coop16", False), ("main", False), ("coopf", False), ("coopf", True)])
+def test_two_ranks_train_like_one_process(tmp_path, variant, uneven):
+    """coopf = the default dispatch of small steps (configs[3]: 4096 rays per GPU -> one-tile cooperative fp16 chains);
+    uneven = the ranks hold 5/8 and 3/8 of the batch and weight their gradients by ray share (n_global)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
-    env.update(MASTER_ADDR="127.0.0.1", R2L_FORCE_VARIANT=variant)
+    env.update(MASTER_ADDR="127.0.0.1", R2L_FORCE_VARIANT=variant, R2L_TEST_UNEVEN="1" if uneven else "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)], env=env,
                        capture_output=True, text=True, timeout=600)
