@@ -16,6 +16,36 @@ extern "C" {
 
 const char* r2l_last_error(void);
 
+/* ---- explicit dispatch ------------------------------------------------------------------------------------------
+ * Which kernel family serves a call is the library's choice (by ray count) unless the host says otherwise.  Hosts say so
+ * with an r2l_config passed to the *_cfg form of an entry point (cfg == NULL and all-zero fields = AUTO = the plain entry
+ * point).  AUTO fields still honour the R2L_* environment switches of README.md (test / A-B overrides); a non-zero field
+ * wins over the environment.  A forward with a stash and the backward that consumes it must be given the same config, and
+ * so must the r2l_*_layout_for_cfg queries that decide which weight-stream layout to pack for them.
+ * (The reference has no counterpart: its dtype / device choices are torch globals; this replaces `setenv` for hosts that
+ * are not this repo's Python.) */
+enum { R2L_PRECISION_AUTO = 0,
+       R2L_PRECISION_FP16X2 = 1,     /* 3 fp16 MFMA products per fp32 product (~2^-21), range-guarded; dW per dw_mode     */
+       R2L_PRECISION_BF16X3 = 2,     /* 6 bf16 products per fp32 product (fp32-exact products) everywhere                  */
+       R2L_PRECISION_FP32_MFMA = 3   /* v_mfma_f32_32x32x2_f32 everywhere                                                  */ };
+enum { R2L_TILING_AUTO = 0,
+       R2L_TILING_WAVE_PER_TILE = 1, /* one wavefront owns a 32-ray tile ("main")                                          */
+       R2L_TILING_COOP = 2,          /* fp32-MFMA cooperative kernels, 32-ray tile per workgroup                           */
+       R2L_TILING_COOP16 = 3,        /* fp32-MFMA cooperative kernels, 16-ray tile per workgroup                           */
+       R2L_TILING_COOPF = 4          /* fp16x2 cooperative kernels (r2l_coopf_*), coop_tiles ray tiles per workgroup       */ };
+enum { R2L_DW_AUTO = 0,
+       R2L_DW_FP16 = 1,              /* fp16 trio: weight-gradient GEMMs on the operands' fp16 hi halves, 1 product        */
+       R2L_DW_EXACT = 2              /* fp16 trio: ray-side operand as hi + mid (22 bits), 2 products: fp32-grade dW       */ };
+typedef struct r2l_config {
+    int precision;    /* R2L_PRECISION_*                                                                                  */
+    int tiling;       /* R2L_TILING_*                                                                                     */
+    int coop_tiles;   /* 0 auto, 1 or 2: 32-ray tiles per workgroup of the fp16x2 cooperative kernels                      */
+    int reserve_cus;  /* 0 auto (R2L_RESERVE_CUS or none), n > 0: CUs the persistent weight-gradient kernels leave free
+                         for collectives running beside them, -1: none                                                    */
+    int dw_mode;      /* R2L_DW_*                                                                                         */
+    int reserved[3];  /* must be 0                                                                                        */
+} r2l_config;
+
 /* ---- parameter layout ------------------------------------------------------------------------------------------
  * `params` is ONE flat fp32 buffer holding NeRF_v3_2's tensors in state_dict order (model/nerf_raybased.py:500-537):
  *   head.0.weight[256,1008] head.0.bias[256] { body.b.body.0.weight[256,256] .bias[256] body.b.body.2.weight .bias }
@@ -42,6 +72,11 @@ int r2l_forward_layout_for(int64_t N, int with_stash); /* 16, 32, 3 = bf16x3 sta
                                                          * bf16x3 one behind it as range-guard fallback) */
 /* Same for the transposed stream r2l_backward reads for N rays (r2l_pack_backward_layout takes the value). */
 int r2l_backward_layout_for(int64_t N);
+/* The same four queries for calls that will be made with an r2l_config; cfg == NULL: the plain forms. */
+int r2l_variant_for_cfg(int64_t N, const r2l_config* cfg);
+int r2l_coop_tiles_for_cfg(int64_t N, int n_block, const r2l_config* cfg);
+int r2l_forward_layout_for_cfg(int64_t N, int with_stash, const r2l_config* cfg);
+int r2l_backward_layout_for_cfg(int64_t N, const r2l_config* cfg);
 int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream);
 int r2l_pack_backward_layout(const float* params, int n_block, float* wstream, int layout, void* stream);
 
@@ -64,6 +99,12 @@ int r2l_forward_rays(const float* rays_o, const float* rays_d, const float* t_ra
  * c2w_host12: HOST pointer to the row-major [3,4] camera-to-world matrix. */
 int r2l_forward_pose(const float* c2w_host12, int H, int W, float focal, const float* ztab, const float* wstream,
                      const float* params, int n_block, float* rgb, void* stream);
+/* r2l_forward_rays / r2l_forward_pose with explicit dispatch (r2l_config above; cfg == NULL: as the plain forms). */
+int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                         const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
+                         float* save_t, int64_t N, void* stream, const r2l_config* cfg);
+int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float focal, const float* ztab, const float* wstream,
+                         const float* params, int n_block, float* rgb, void* stream, const r2l_config* cfg);
 
 /* rgb[N,3] = NeRF_v3_2.forward(emb[N,1008])  — the module-boundary form (model/nerf_raybased.py:539-544) for callers
  * that still run their own sampler/embedder. */
@@ -113,6 +154,14 @@ int r2l_backward_part(const float* rays_o, const float* rays_d, const float* t_r
                       const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N, void* stream, int parts,
                       int layer_lo, int layer_hi);
+/* r2l_backward_part with explicit dispatch: the config the forward of this step was given (cfg == NULL: the plain form;
+ * parts = R2L_BWD_ALL, layers [0, 2 n_block) = r2l_backward). */
+int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* emb,
+                          const float* rgb, const float* target, const float* drgb, const float* save_x,
+                          const float* save_t, const float* wstream_bwd, const float* params, int n_block,
+                          float grad_scale, float* dpre, float* gx, float* gt, float* sqerr_partial, float* grads,
+                          float* dw_slab, int64_t N, void* stream, int parts, int layer_lo, int layer_hi,
+                          const r2l_config* cfg);
 
 /* ---- gradient all-reduce for hosts without torch.distributed ----------------------------------------------------------
  * The one exchange of data-parallel training (replaces nn.DataParallel's ReduceAddCoalesced + parameter broadcast,
@@ -148,6 +197,10 @@ int r2l_pack_teacher(const float* tparams, float* wstream, void* stream);
  * dirs L=4, helpers:24-74; the netchunk loop disappears) + NeRF.forward (model/nerf_raybased.py:377-401), fused. */
 int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
                     const float* wstream, const float* tparams, float* raw, int64_t R, int S, void* stream);
+/* ... with explicit dispatch: only cfg->precision matters (cfg == NULL: the plain form). */
+int r2l_teacher_mlp_cfg(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
+                        const float* wstream, const float* tparams, float* raw, int64_t R, int S, void* stream,
+                        const r2l_config* cfg);
 
 /* z_out[R,S] = near*(1-t)+far*t, with stratified jitter when t_rand[R,S] != NULL (create_data.py:457-482).
  * near/far: per-ray values read at near[r*nf_stride], far[r*nf_stride]; ttab[2S] = t_vals ++ (1 - t_vals). */

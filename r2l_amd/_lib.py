@@ -14,6 +14,24 @@ _i = ctypes.c_int
 _l = ctypes.c_int64
 _f = ctypes.c_float
 
+
+
+class Config(ctypes.Structure):
+    """r2l_config of include/r2l_hip.h: explicit dispatch for the *_cfg entry points (all zero = AUTO)."""
+    _fields_ = [("precision", _i), ("tiling", _i), ("coop_tiles", _i), ("reserve_cus", _i), ("dw_mode", _i),
+                ("reserved", _i * 3)]
+
+
+PRECISION = {"auto": 0, "fp16x2": 1, "bf16x3": 2, "fp32_mfma": 3}
+TILING = {"auto": 0, "main": 1, "coop": 2, "coop16": 3, "coopf": 4}
+DW_MODE = {"auto": 0, "fp16": 1, "exact": 2}
+_cfgp = ctypes.POINTER(Config)
+
+
+def make_config(precision="auto", tiling="auto", coop_tiles=0, reserve_cus=0, dw_mode="auto"):
+    return Config(PRECISION[precision], TILING[tiling], int(coop_tiles), int(reserve_cus), DW_MODE[dw_mode])
+
+
 # name -> (restype, argtypes); one row per declaration in include/r2l_hip.h
 SIGNATURES = {
     "r2l_last_error": (ctypes.c_char_p, []),
@@ -28,8 +46,14 @@ SIGNATURES = {
     "r2l_backward_layout_for": (_i, [_l]),
     "r2l_pack_forward_layout": (_i, [_p, _i, _p, _i, _p]),
     "r2l_pack_backward_layout": (_i, [_p, _i, _p, _i, _p]),
+    "r2l_variant_for_cfg": (_i, [_l, _cfgp]),
+    "r2l_coop_tiles_for_cfg": (_i, [_l, _i, _cfgp]),
+    "r2l_forward_layout_for_cfg": (_i, [_l, _i, _cfgp]),
+    "r2l_backward_layout_for_cfg": (_i, [_l, _cfgp]),
     "r2l_forward_rays": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _p]),
     "r2l_forward_pose": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
+    "r2l_forward_rays_cfg": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _p, _cfgp]),
+    "r2l_forward_pose_cfg": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _cfgp]),
     "r2l_forward_emb": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p]),
     "r2l_num_tiles": (_l, [_l]),
     "r2l_padded_rows": (_l, [_l]),
@@ -37,6 +61,7 @@ SIGNATURES = {
     "r2l_dw_slab_floats": (_l, []),
     "r2l_backward": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p]),
     "r2l_backward_part": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p, _i, _i, _i]),
+    "r2l_backward_part_cfg": (_i, [_p] * 12 + [_i, _f] + [_p] * 6 + [_l, _p, _i, _i, _i, _cfgp]),
     "r2l_allreduce_unique_id": (_i, [_p]),
     "r2l_allreduce_init": (_i, [_p, _i, _i, _p]),
     "r2l_grad_allreduce": (_i, [_p, _p, _l, _p]),
@@ -47,6 +72,7 @@ SIGNATURES = {
     "r2l_teacher_stream_floats": (_l, []),
     "r2l_pack_teacher": (_i, [_p, _p, _p]),
     "r2l_teacher_mlp": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
+    "r2l_teacher_mlp_cfg": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _cfgp]),
     "r2l_stratified_z": (_i, [_p, _p, _i, _p, _p, _p, _l, _i, _p]),
     "r2l_raw2outputs": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _p]),
     "r2l_sample_pdf_sort": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),

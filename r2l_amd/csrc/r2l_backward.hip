@@ -1110,12 +1110,6 @@ extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS + 16; }
 extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_TRIO_SLOT(R2L_PAD_ROWS(N)); }
 
-extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
-                                 const float* emb, const float* rgb, const float* target, const float* drgb,
-                                 const float* save_x, const float* save_t,
-                                 const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
-                                 float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
-                                 void* stream_, int parts, int layer_lo, int layer_hi);
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
@@ -1123,8 +1117,9 @@ extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const floa
                             const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
                             float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
                             void* stream_) {
-    return r2l_backward_part(rays_o, rays_d, t_rand, ztab, emb, rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block,
-                             grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, R2L_BWD_ALL, 0, 2 * n_block);
+    return r2l_backward_part_cfg(rays_o, rays_d, t_rand, ztab, emb, rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block,
+                                 grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, R2L_BWD_ALL, 0, 2 * n_block,
+                                 nullptr);
 }
 
 // The same backward cut into stages, so that a data-parallel host can hand finished gradient buckets to the collective
@@ -1137,6 +1132,17 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
                                  const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
                                  float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
                                  void* stream_, int parts, int layer_lo, int layer_hi) {
+    return r2l_backward_part_cfg(rays_o, rays_d, t_rand, ztab, emb, rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block,
+                                 grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, parts, layer_lo, layer_hi,
+                                 nullptr);
+}
+extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                                     const float* emb, const float* rgb, const float* target, const float* drgb,
+                                     const float* save_x, const float* save_t,
+                                     const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
+                                     float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
+                                     void* stream_, int parts, int layer_lo, int layer_hi, const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
     if (N <= 0) return 0;
     if (layer_lo < 0) layer_lo = 0;
     if (layer_hi > 2 * n_block) layer_hi = 2 * n_block;
@@ -1155,7 +1161,8 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
     // a whole stage to finish: R2L_RESERVE_CUS=n (set by the host when world_size > 1; r2l_amd/train_step.py uses 8) keeps n
     // CUs out of the weight-gradient launches for the RCCL kernels.  Default 0.
     int reserve = 0;
-    if (const char* e = getenv("R2L_RESERVE_CUS")) reserve = atoi(e);
+    if (g_r2l_cfg.reserve_cus) reserve = g_r2l_cfg.reserve_cus;  // (-1: none)
+    else if (const char* e = getenv("R2L_RESERVE_CUS")) reserve = atoi(e);
     if (reserve < 0 || reserve > n_cu_cached / 2) reserve = 0;
     const int n_cu = n_cu_cached - reserve;
     // 1. dX chain

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "r2l_hip.h"  // r2l_config
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -406,16 +407,29 @@ int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, 
                       const float* scale_dev = nullptr);
 // forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
 // kernel (R2L_NO_FWD3=1: fp32 MFMA)
+// Explicit dispatch (include/r2l_hip.h r2l_config): the *_cfg entry points install the caller's config for the duration of
+// the call (R2LCfgScope, thread-local), and every decision below looks at it first; an AUTO (0) field falls through to the
+// R2L_* environment switch it replaces, read per call (~100 ns) so tests can flip it.
+extern thread_local r2l_config g_r2l_cfg;  // r2l_error.hip
+struct R2LCfgScope {
+    r2l_config saved;
+    explicit R2LCfgScope(const r2l_config* c) : saved(g_r2l_cfg) { if (c) g_r2l_cfg = *c; }
+    ~R2LCfgScope() { g_r2l_cfg = saved; }
+};
+static inline bool r2l_env_on(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
 static inline bool r2l_use_fwd3() {
-    const char* e = getenv("R2L_NO_FWD3");
-    return !(e && e[0] && e[0] != '0');
+    if (g_r2l_cfg.precision) return g_r2l_cfg.precision != R2L_PRECISION_FP32_MFMA;
+    return !r2l_env_on("R2L_NO_FWD3");
 }
 // one-wave-per-tile forward launches: three fp16 products per fp32 product, ~2^-21 relative (r2l_fwd2.hip), with
 // the bf16x3 kernel launched behind it as the range-guard fallback (it returns at once unless the status word is raised).
 // R2L_NO_FWD2=1: bf16x3 only.
 static inline bool r2l_use_fwd2() {
-    const char* e = getenv("R2L_NO_FWD2");
-    return r2l_use_fwd3() && !(e && e[0] && e[0] != '0');
+    if (g_r2l_cfg.precision) return g_r2l_cfg.precision == R2L_PRECISION_FP16X2;
+    return r2l_use_fwd3() && !r2l_env_on("R2L_NO_FWD2");
 }
 int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream);
 int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
@@ -454,25 +468,32 @@ enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP = 1, R2L_VARIANT_COOP16 = 2 };
 // between the operations is enough to keep them apart.
 __device__ __forceinline__ void r2l_no_pack(float& v) { asm volatile("" : "+v"(v)); }
 
-static inline bool r2l_env_on(const char* name) {
-    const char* e = getenv(name);
-    return e && e[0] && e[0] != '0';
-}
 static inline bool r2l_fp16_trio_env() {
+    if (g_r2l_cfg.precision) return g_r2l_cfg.precision == R2L_PRECISION_FP16X2;
     return !r2l_env_on("R2L_NO_FWD3") && !r2l_env_on("R2L_NO_FWD2") && !r2l_env_on("R2L_NO_BWD2") && !r2l_env_on("R2L_NO_DW2");
+}
+// the tiling a host pinned: cfg->tiling, else R2L_FORCE_VARIANT=main|coop|coop16|coopf, else R2L_TILING_AUTO
+static inline int r2l_forced_tiling() {
+    if (g_r2l_cfg.tiling) return g_r2l_cfg.tiling;
+    const char* e = getenv("R2L_FORCE_VARIANT");
+    if (!e || !e[0]) return R2L_TILING_AUTO;
+    if (e[0] == 'm') return R2L_TILING_WAVE_PER_TILE;
+    if (e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return R2L_TILING_COOPF;
+    if (e[0] == 'c') return (e[1] && e[2] && e[3] && e[4] == '1') ? R2L_TILING_COOP16 : R2L_TILING_COOP;
+    return R2L_TILING_WAVE_PER_TILE;  // (anything else used to mean "not the cooperative fp16 kernels")
 }
 static inline bool r2l_use_coopf(int64_t N, int n_block) {
     if (n_block <= 0 || !r2l_fp16_trio_env()) return false;
-    const char* e = getenv("R2L_FORCE_VARIANT");
-    if (e && e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return true;
-    if (e && e[0]) return false;
+    const int t = r2l_forced_tiling();
+    if (t == R2L_TILING_COOPF) return true;
+    if (t != R2L_TILING_AUTO) return false;
     return N <= R2L_COOPF_MAX_RAYS || (N > R2L_MAIN_ROUND_RAYS && N <= R2L_MAIN_ROUND_RAYS + R2L_MAIN_ROUND_RAYS / 2);
 }
 static inline int r2l_chain_variant(int64_t N) {
-    const char* e = getenv("R2L_FORCE_VARIANT");  // read per call (~100 ns) so tests can flip it
-    if (e && e[0] == 'm') return R2L_VARIANT_MAIN;
-    if (e && e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return R2L_VARIANT_MAIN;  // coopf: kernels of the MAIN family
-    if (e && e[0] == 'c') return (e[1] && e[2] && e[3] && e[4] == '1') ? R2L_VARIANT_COOP16 : R2L_VARIANT_COOP;
+    const int t = r2l_forced_tiling();
+    if (t == R2L_TILING_WAVE_PER_TILE || t == R2L_TILING_COOPF) return R2L_VARIANT_MAIN;  // coopf: kernels of the MAIN family
+    if (t == R2L_TILING_COOP16) return R2L_VARIANT_COOP16;
+    if (t == R2L_TILING_COOP) return R2L_VARIANT_COOP;
     if (r2l_fp16_trio_env() && N <= R2L_COOPF_MAX_RAYS) return R2L_VARIANT_MAIN;  // served by the cooperative fp16x2 kernels
     // (one main round on the fp16x2 kernels costs 0.30 of a round of the fp32-MFMA kernel the unit was defined on; measured,
     // tools/variant_sweep.py: 98 304-ray-style steps of 6144 rays 1.99 ms on the one-wave-per-tile kernels vs 2.11 ms on the
@@ -496,7 +517,15 @@ static inline bool r2l_stash_chunked(int64_t N, bool pre_embedded) {
 // stashing fp16 stage pieces, and the fp16 weight-gradient GEMMs on them (r2l_dw16.hip).  Any of R2L_NO_FWD3 / R2L_NO_FWD2 /
 // R2L_NO_BWD2 / R2L_NO_DW2 = 1 puts the whole step on the bf16x3 trio (r2l_fwd3 / r2l_bwd3 / r2l_dw_body3c, chunked fp32
 // stash) — the kernels the range guards fall back to.  (Forward-only launches look at R2L_NO_FWD2 alone.)
-static inline bool r2l_use_trio16() { return r2l_use_fwd2() && !r2l_env_on("R2L_NO_BWD2") && !r2l_env_on("R2L_NO_DW2"); }
+static inline bool r2l_use_trio16() {
+    if (g_r2l_cfg.precision) return g_r2l_cfg.precision == R2L_PRECISION_FP16X2;
+    return r2l_use_fwd2() && !r2l_env_on("R2L_NO_BWD2") && !r2l_env_on("R2L_NO_DW2");
+}
+// weight-gradient GEMMs of the fp16 trio with the ray-side operand as hi + mid (two products): cfg->dw_mode, else R2L_DW_EXACT=1
+static inline bool r2l_dw_exact() {
+    if (g_r2l_cfg.dw_mode) return g_r2l_cfg.dw_mode == R2L_DW_EXACT;
+    return r2l_env_on("R2L_DW_EXACT");
+}
 
 // error plumbing shared by the C-ABI translation units
 extern "C" const char* r2l_last_error(void);

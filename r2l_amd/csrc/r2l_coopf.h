@@ -229,6 +229,8 @@ __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bop
 
 // ray tiles per workgroup: 1 while that keeps the launch within one workgroup per CU, else 2 (R2L_COOPF_TILES=1|2 overrides)
 static inline bool r2l_coopf_two_tiles(int64_t tiles) {
+    if (g_r2l_cfg.coop_tiles == 1) return false;
+    if (g_r2l_cfg.coop_tiles == 2) return true;
     if (const char* e = getenv("R2L_COOPF_TILES")) {
         if (e[0] == '1') return false;
         if (e[0] == '2') return true;

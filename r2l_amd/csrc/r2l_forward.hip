@@ -254,6 +254,12 @@ static int launch_fwd(const R2LFwdArgs& a, hipStream_t stream) {
 extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                                 const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
                                 float* save_t, int64_t N, void* stream) {
+    return r2l_forward_rays_cfg(rays_o, rays_d, t_rand, ztab, wstream, params, n_block, rgb, save_x, save_t, N, stream, nullptr);
+}
+extern "C" int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
+                                    const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
+                                    float* save_t, int64_t N, void* stream, const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
     R2LFwdArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.wstream = wstream; a.params = params; a.n_block = n_block;
@@ -288,6 +294,12 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
 
 extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float focal, const float* ztab,
                                 const float* wstream, const float* params, int n_block, float* rgb, void* stream) {
+    return r2l_forward_pose_cfg(c2w_host12, H, W, focal, ztab, wstream, params, n_block, rgb, stream, nullptr);
+}
+extern "C" int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float focal, const float* ztab,
+                                    const float* wstream, const float* params, int n_block, float* rgb, void* stream,
+                                    const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
     R2LFwdArgs a{};
     for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     a.H = H; a.Wimg = W; a.focal = focal; a.ztab = ztab;

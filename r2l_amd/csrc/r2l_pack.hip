@@ -134,11 +134,17 @@ extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
 
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
 // launches use (r2l_variant_for) can skip the other half of the stream: 10 us each, 3 % of a 4096-ray step.
-extern "C" int r2l_variant_for(int64_t N) { return r2l_chain_variant(N); }
+extern "C" int r2l_variant_for_cfg(int64_t N, const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
+    return r2l_chain_variant(N);
+}
+extern "C" int r2l_variant_for(int64_t N) { return r2l_variant_for_cfg(N, nullptr); }
 // stream layout a forward launch with N rays reads: 16 / 32 (cooperative variants / fp32-MFMA kernels), 3 (the bf16x3
 // kernel, r2l_fwd3.hip: every one-wave-per-tile forward, with or without the training stash) or 2 (fp16x2 kernel,
 // r2l_fwd2.hip, with the bf16x3 stream as its fallback: forward-only launches)
-extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
+extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) { return r2l_forward_layout_for_cfg(N, with_stash, nullptr); }
+extern "C" int r2l_forward_layout_for_cfg(int64_t N, int with_stash, const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
     if (v == R2L_VARIANT_MAIN && (with_stash ? r2l_use_trio16() : r2l_use_fwd2())) return 2;
@@ -147,7 +153,9 @@ extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) {
 }
 // transposed-stream layout the backward of an N-ray launch reads: 16 / 32 as the forward, 3 (bf16x3 dX chain) or 2 (fp16x2 dX
 // chain with the bf16x3 stream behind it as range-guard fallback: r2l_pack_backward_layout(2) fills both)
-extern "C" int r2l_backward_layout_for(int64_t N) {
+extern "C" int r2l_backward_layout_for(int64_t N) { return r2l_backward_layout_for_cfg(N, nullptr); }
+extern "C" int r2l_backward_layout_for_cfg(int64_t N, const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return r2l_use_trio16() ? 2 : 3;

@@ -72,6 +72,26 @@ class R2LEngine:
         self._packed_version = None
         self._dirty = 0
         self._ztab_cache = {}
+        # explicit dispatch handed to every call of this engine (include/r2l_hip.h r2l_config; all zero = AUTO: the library
+        # picks by ray count, R2L_* environment switches still apply).  set_config() changes it.
+        self.cfg = _lib.Config()
+
+    def set_config(self, **kw):
+        """precision='auto|fp16x2|bf16x3|fp32_mfma', tiling='auto|main|coop|coop16|coopf', coop_tiles=0|1|2,
+        reserve_cus=n, dw_mode='auto|fp16|exact'.  Weight streams are layout-specific: they re-pack on the next call."""
+        cur = dict(precision=self.cfg.precision, tiling=self.cfg.tiling, coop_tiles=self.cfg.coop_tiles,
+                   reserve_cus=self.cfg.reserve_cus, dw_mode=self.cfg.dw_mode)
+        names = {"precision": _lib.PRECISION, "tiling": _lib.TILING, "dw_mode": _lib.DW_MODE}
+        for k, v in kw.items():
+            if k not in cur:
+                raise TypeError("unknown config field %r" % k)
+            cur[k] = names[k][v] if k in names and isinstance(v, str) else int(v)
+        self.cfg = _lib.Config(cur["precision"], cur["tiling"], cur["coop_tiles"], cur["reserve_cus"], cur["dw_mode"])
+        self._packed_version = None
+        return self.cfg
+
+    def _cfg(self):
+        return ctypes.byref(self.cfg)
 
     # ---- parameter storage ------------------------------------------------------------------------------------
     def _aliased(self):
@@ -114,7 +134,7 @@ class R2LEngine:
     def layout_for(self, n, with_stash=True):
         """Which part of the packed forward stream a launch with n rays reads: 16 (16-ray cooperative kernels), 32
         (32-ray cooperative / fp32-MFMA kernels), 3 (the bf16x3 kernels) or 2 (fp16x2 forward-only kernel, R2L_FWD2=1)."""
-        return self.lib.r2l_forward_layout_for(int(n), 1 if with_stash else 0)
+        return self.lib.r2l_forward_layout_for_cfg(int(n), 1 if with_stash else 0, self._cfg())
 
     def pack_now(self):
         """Unconditional re-pack of both layouts (used inside captured graphs, where the host-side version check does
@@ -173,9 +193,9 @@ class R2LEngine:
         rgb = torch.empty(n, 3, dtype=torch.float32, device=self.device)
         sx, st = (save if save is not None else (None, None))
         _lib.check(
-            self.lib.r2l_forward_rays(_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(self.ztab(z_vals, perturb)),
-                                      _ptr(self.wstream), _ptr(self.flat), self.n_block, _ptr(rgb), _ptr(sx), _ptr(st),
-                                      n, _stream()), "r2l_forward_rays")
+            self.lib.r2l_forward_rays_cfg(_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(self.ztab(z_vals, perturb)),
+                                          _ptr(self.wstream), _ptr(self.flat), self.n_block, _ptr(rgb), _ptr(sx), _ptr(st),
+                                          n, _stream(), self._cfg()), "r2l_forward_rays")
         return rgb
 
     def forward_pose(self, c2w, H, Wimg, focal, z_vals):
@@ -185,9 +205,9 @@ class R2LEngine:
         host = (ctypes.c_float * 12)(*c.reshape(-1).tolist())
         rgb = torch.empty(H * Wimg, 3, dtype=torch.float32, device=self.device)
         _lib.check(
-            self.lib.r2l_forward_pose(ctypes.cast(host, ctypes.c_void_p), int(H), int(Wimg), float(focal),
-                                      _ptr(self.ztab(z_vals, 0.)), _ptr(self.wstream), _ptr(self.flat), self.n_block,
-                                      _ptr(rgb), _stream()), "r2l_forward_pose")
+            self.lib.r2l_forward_pose_cfg(ctypes.cast(host, ctypes.c_void_p), int(H), int(Wimg), float(focal),
+                                          _ptr(self.ztab(z_vals, 0.)), _ptr(self.wstream), _ptr(self.flat), self.n_block,
+                                          _ptr(rgb), _stream(), self._cfg()), "r2l_forward_pose")
         return rgb
 
     def forward_emb(self, emb, save=None):

@@ -7,6 +7,8 @@ On ROCm tensors every stage runs in libr2l_hip.so (fused embed+MLP, wave-scan al
 sampling + sort: no CPU round trip, no netchunk loop); on CPU tensors the same functions run plain torch ops
 (plumbing only).
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -77,6 +79,7 @@ class TeacherEngine:
             raise RuntimeError("teacher parameter census mismatch: %d" % n)
         self.flat = None
         self._ver = None
+        self.cfg = _lib.Config()  # r2l_config of this teacher's calls (only .precision matters); all zero = AUTO
 
     def _aliased(self):
         if self.flat is None:
@@ -114,9 +117,9 @@ class TeacherEngine:
         R, S = z.shape
         raw = torch.empty(R, S, 4, dtype=torch.float32, device=z.device)
         _lib.check(
-            self.lib.r2l_teacher_mlp(_ptr(rays_o.contiguous()), _ptr(rays_d.contiguous()), _ptr(viewdirs.contiguous()),
-                                     _ptr(z.contiguous()), _ptr(self.wstream), _ptr(self.flat), _ptr(raw), R, S,
-                                     _stream()), "r2l_teacher_mlp")
+            self.lib.r2l_teacher_mlp_cfg(_ptr(rays_o.contiguous()), _ptr(rays_d.contiguous()), _ptr(viewdirs.contiguous()),
+                                         _ptr(z.contiguous()), _ptr(self.wstream), _ptr(self.flat), _ptr(raw), R, S,
+                                         _stream(), ctypes.byref(self.cfg)), "r2l_teacher_mlp")
         return raw
 
 

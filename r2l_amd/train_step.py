@@ -41,10 +41,10 @@ class R2LTrainer:
         # kernels of the next bucket run; R2L_AR_BUCKETS=0 selects one blocking all-reduce after the whole backward
         self.n_buckets = int(os.environ.get("R2L_AR_BUCKETS", "4"))
         self.force_staged = False  # tests: run the staged backward on one GPU (nothing is submitted at world == 1)
-        if self.reducer.world() > 1 and self.n_buckets > 0:
+        if self.reducer.world() > 1 and self.n_buckets > 0 and self.eng.cfg.reserve_cus == 0:
             # the weight-gradient kernels are persistent workgroups that fill every CU: leave a few to the RCCL kernels that
-            # run beside them (r2l_backward_part reads this per call)
-            os.environ.setdefault("R2L_RESERVE_CUS", "8")
+            # run beside them (r2l_config.reserve_cus of this trainer's calls; R2L_RESERVE_CUS overrides the count)
+            self.eng.set_config(reserve_cus=int(os.environ.get("R2L_RESERVE_CUS", "8")))
         self.step_count = 0
         self.cap = 0
         self.dw_slab = None
@@ -86,7 +86,7 @@ class R2LTrainer:
     def _pack_bwd(self, n):
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
-        ver, layout = eng.version(), self.lib.r2l_backward_layout_for(int(n))  # 16 / 32 / 3 / 2: what r2l_backward will read
+        ver, layout = (eng.version(), eng.cfg.precision, eng.cfg.tiling), self.lib.r2l_backward_layout_for_cfg(int(n), eng._cfg())  # 16 / 32 / 3 / 2: what r2l_backward will read
         if self._bwd_packed is None:  # (layout 2 = the fp16x2 stream; its bf16x3 fallback stream packs itself when it runs)
             self._bwd_packed = {16: None, 32: None, 3: None, 2: None}
         if self._bwd_packed[layout] != ver:
@@ -124,16 +124,16 @@ class R2LTrainer:
         if (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
             # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
             # blocks to the first, the head last; every finished range of the flat gradient goes to the collective at once
-            part = self.lib.r2l_backward_part
-            _lib.check(part(*args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0), "r2l_backward_part(chain, tail)")
+            part, cfg = self.lib.r2l_backward_part_cfg, eng._cfg()
+            _lib.check(part(*args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0, cfg), "r2l_backward_part(chain, tail)")
             for lo, hi, flat_lo, flat_hi in bucket_plan(eng.n_block, self.n_buckets):
                 if flat_lo == 0:
-                    _lib.check(part(*args, _lib.BWD_HEAD, 0, 0), "r2l_backward_part(head)")
+                    _lib.check(part(*args, _lib.BWD_HEAD, 0, 0, cfg), "r2l_backward_part(head)")
                 elif hi > lo:  # (a net without body blocks has one empty body bucket: only its tail range to exchange)
-                    _lib.check(part(*args, _lib.BWD_BODY, lo, hi), "r2l_backward_part(%d, %d)" % (lo, hi))
+                    _lib.check(part(*args, _lib.BWD_BODY, lo, hi, cfg), "r2l_backward_part(%d, %d)" % (lo, hi))
                 self.reducer.submit(self.grads[flat_lo:flat_hi])
         else:
-            _lib.check(self.lib.r2l_backward(*args), "r2l_backward")
+            _lib.check(self.lib.r2l_backward_part_cfg(*args, _lib.BWD_ALL, 0, 2 * eng.n_block, eng._cfg()), "r2l_backward")
         _lib.check(
             self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
                                      _ptr(self.loss_out), _stream()), "r2l_loss_finish")

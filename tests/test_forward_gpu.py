@@ -167,3 +167,73 @@ def test_fp16_range_guard_falls_back(chain_variant):
     # relative bar: with activations of 1e5 the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 tail
     assert (rgb[:2048].cpu() - ref).abs().max().item() < TOL
     assert torch.equal(rgb, rgb2)
+
+
+def test_explicit_config_selects_the_family(chain_variant, monkeypatch):
+    """Dispatch through ARGUMENTS (include/r2l_hip.h r2l_config, the *_cfg entry points): one process, one model, four
+    kernel families selected call by call with no environment switch involved — each bit-identical to the same family
+    selected the environment way, all within the parity bar of the oracle; the teacher's precision likewise."""
+    if chain_variant != "main":
+        pytest.skip("one comparison")
+    from model.nerf_raybased import NeRF, PointSampler
+    from r2l_amd.engine import get_engine
+    from r2l_amd.render import teacher_engine
+    sd = O.make_state_dict(n_block=43, seed=0)
+    m = build_model(sd, 43)
+    eng = get_engine(m)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    g = torch.Generator().manual_seed(21)
+    n = 6000
+    o = torch.randn(n, 3, generator=g) * 1.5
+    d = torch.randn(n, 3, generator=g)
+    ref = O.r2l_forward(sd, O.positional_embed(O.sample_train(o[:512], d[:512], O.z_vals(16, 2., 6.), 0.), 10))
+    oc, dc = o.cuda(), d.cuda()
+    families = [
+        (dict(precision="fp16x2", tiling="main"), dict(R2L_FORCE_VARIANT="main")),
+        (dict(precision="bf16x3", tiling="main"), dict(R2L_FORCE_VARIANT="main", R2L_NO_FWD2="1")),
+        (dict(precision="fp32_mfma", tiling="coop16"), dict(R2L_FORCE_VARIANT="coop16", R2L_NO_FWD3="1")),
+        (dict(precision="fp16x2", tiling="coopf", coop_tiles=2), dict(R2L_FORCE_VARIANT="coopf", R2L_COOPF_TILES="2")),
+    ]
+    for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD2", "R2L_NO_FWD3", "R2L_COOPF_TILES"):
+        monkeypatch.delenv(k, raising=False)
+    by_cfg = []
+    with torch.no_grad():
+        for cfg, _ in families:  # arguments only: the environment is clean
+            eng.set_config(**cfg)
+            by_cfg.append(m.forward_rays(oc, dc, ps, perturb=0.).clone())
+        eng.set_config(precision="auto", tiling="auto", coop_tiles=0)
+        for (cfg, env), rgb in zip(families, by_cfg):
+            assert (rgb[:512].cpu() - ref).abs().max().item() < TOL, cfg
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert torch.equal(m.forward_rays(oc, dc, ps, perturb=0.), rgb), cfg
+            for k in env:
+                monkeypatch.delenv(k)
+    assert not torch.equal(by_cfg[0], by_cfg[1]) and not torch.equal(by_cfg[1], by_cfg[2])  # they ARE different kernels
+    # explicit fields beat the environment
+    monkeypatch.setenv("R2L_NO_FWD3", "1")
+    eng.set_config(precision="bf16x3", tiling="main")
+    with torch.no_grad():
+        assert torch.equal(m.forward_rays(oc, dc, ps, perturb=0.), by_cfg[1])
+    monkeypatch.delenv("R2L_NO_FWD3")
+    # teacher: precision through its config
+    tsd = O.make_teacher_state_dicts(11, 1, alpha_bias=0.5)[0]
+    t = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+    t.load_state_dict(tsd)
+    te = teacher_engine(t.cuda())
+    R, S = 257, 64
+    to, td = torch.randn(R, 3, generator=g), torch.randn(R, 3, generator=g)
+    vd = td / td.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, -1)[0]
+    raws = []
+    from r2l_amd import _lib
+    for prec, env in (("fp16x2", {}), ("bf16x3", {"R2L_NO_FWD2": "1"}), ("fp32_mfma", {"R2L_NO_FWD3": "1"})):
+        te.cfg = _lib.make_config(precision=prec)
+        raws.append(te.mlp(to.cuda(), td.cuda(), vd.cuda(), z.cuda()).clone())
+        te.cfg = _lib.Config()
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert torch.equal(te.mlp(to.cuda(), td.cuda(), vd.cuda(), z.cuda()), raws[-1]), prec
+        for k in env:
+            monkeypatch.delenv(k)
+    assert not torch.equal(raws[0], raws[1]) and not torch.equal(raws[1], raws[2])

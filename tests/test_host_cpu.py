@@ -26,6 +26,46 @@ def test_library_exports_every_declared_symbol():
     assert lib.r2l_num_tiles(33) == 2
 
 
+def test_explicit_config_dispatch(monkeypatch):
+    """r2l_config (include/r2l_hip.h): the *_cfg queries answer for the config they are given — NULL / all-zero = the plain
+    forms (environment switches apply), a non-zero field wins over the environment — and leave no state behind."""
+    import ctypes
+    from r2l_amd import _lib
+    lib = _lib.load()
+    for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_COOPF_TILES"):
+        monkeypatch.delenv(k, raising=False)
+    ref = ctypes.byref
+    auto = _lib.make_config()
+    assert ctypes.sizeof(_lib.Config) == 32
+    for n in (32, 4096, 20000, 98304, 160000):
+        assert lib.r2l_variant_for_cfg(n, None) == lib.r2l_variant_for_cfg(n, ref(auto)) == lib.r2l_variant_for(n)
+        assert lib.r2l_forward_layout_for_cfg(n, 1, ref(auto)) == lib.r2l_forward_layout_for(n, 1)
+        assert lib.r2l_backward_layout_for_cfg(n, None) == lib.r2l_backward_layout_for(n)
+        assert lib.r2l_coop_tiles_for_cfg(n, 43, ref(auto)) == lib.r2l_coop_tiles_for(n, 43)
+    bf = _lib.make_config(precision="bf16x3")
+    f32 = _lib.make_config(precision="fp32_mfma")
+    f16 = _lib.make_config(precision="fp16x2")
+    assert lib.r2l_forward_layout_for_cfg(98304, 1, ref(bf)) == 3 and lib.r2l_backward_layout_for_cfg(98304, ref(bf)) == 3
+    assert lib.r2l_forward_layout_for_cfg(160000, 0, ref(bf)) == 3
+    assert lib.r2l_forward_layout_for_cfg(98304, 1, ref(f32)) == 32 and lib.r2l_backward_layout_for_cfg(98304, ref(f32)) == 32
+    assert lib.r2l_variant_for_cfg(4096, ref(bf)) == 2 and lib.r2l_coop_tiles_for_cfg(4096, 43, ref(bf)) == 0
+    # tiling and tiles per workgroup
+    assert lib.r2l_variant_for_cfg(98304, ref(_lib.make_config(tiling="coop16"))) == 2
+    assert lib.r2l_variant_for_cfg(4096, ref(_lib.make_config(tiling="main"))) == 0
+    assert lib.r2l_coop_tiles_for_cfg(4096, 43, ref(_lib.make_config(tiling="main"))) == 0
+    assert lib.r2l_coop_tiles_for_cfg(98304, 43, ref(_lib.make_config(tiling="coopf"))) == 2
+    assert lib.r2l_coop_tiles_for_cfg(4096, 43, ref(_lib.make_config(coop_tiles=2))) == 2
+    assert lib.r2l_coop_tiles_for_cfg(12288, 43, ref(_lib.make_config(coop_tiles=1))) == 1
+    # explicit fields beat the environment; AUTO fields follow it; nothing sticks after the call
+    monkeypatch.setenv("R2L_NO_FWD2", "1")
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "coop")
+    assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_variant_for(98304) == 1
+    both = _lib.make_config(precision="fp16x2", tiling="main")
+    assert lib.r2l_forward_layout_for_cfg(98304, 1, ref(both)) == 2 and lib.r2l_variant_for_cfg(98304, ref(both)) == 0
+    assert lib.r2l_variant_for_cfg(98304, ref(f16)) == 1  # tiling AUTO: the environment's coop
+    assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_variant_for(98304) == 1
+
+
 def test_dispatch_and_buffer_size_helpers(monkeypatch):
     """Host-side decisions of the library (no device work): which kernel family / stream layout an N-ray launch takes under
     the environment switches, and the caller-side buffer sizes that go with them."""

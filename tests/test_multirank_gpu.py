@@ -31,7 +31,7 @@ sd = O.make_state_dict(n_block=nb, seed=40 + rank)     # every rank builds ITS O
 m = build_model(sd, nb)
 ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
 tr = R2LTrainer(m, ps)                                  # ... and continues with rank 0's
-assert tr.world() == 2 and tr.n_buckets == 4 and os.environ.get("R2L_RESERVE_CUS") == "8"
+assert tr.world() == 2 and tr.n_buckets == 4 and tr.eng.cfg.reserve_cus == 8 and "R2L_RESERVE_CUS" not in os.environ
 assert parameters_in_sync(tr.eng.flat)
 assert torch.equal(m.state_dict()["body.1.body.0.weight"].cpu(), sd0["body.1.body.0.weight"])
 g = torch.Generator().manual_seed(3)
