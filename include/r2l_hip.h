@@ -105,6 +105,11 @@ int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, const float* 
                          float* save_t, int64_t N, void* stream, const r2l_config* cfg);
 int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float focal, const float* ztab, const float* wstream,
                          const float* params, int n_block, float* rgb, void* stream, const r2l_config* cfg);
+/* K frames in ONE launch — the test-set loop of main.py:300-309 (render_path renders every test pose: 200 at testskip=1)
+ * without a launch and a partly filled last round of workgroups per frame: rgb[K*H*W,3], frame k from the DEVICE table
+ * c2w_dev[K][3][4].  Same values as K calls of r2l_forward_pose.  One-wave-per-tile tilings only (an error otherwise). */
+int r2l_forward_poses_cfg(const float* c2w_dev, int K, int H, int W, float focal, const float* ztab, const float* wstream,
+                          const float* params, int n_block, float* rgb, void* stream, const r2l_config* cfg);
 
 /* rgb[N,3] = NeRF_v3_2.forward(emb[N,1008])  — the module-boundary form (model/nerf_raybased.py:539-544) for callers
  * that still run their own sampler/embedder. */

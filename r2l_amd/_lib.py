@@ -54,6 +54,7 @@ SIGNATURES = {
     "r2l_forward_pose": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
     "r2l_forward_rays_cfg": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _p, _cfgp]),
     "r2l_forward_pose_cfg": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _cfgp]),
+    "r2l_forward_poses_cfg": (_i, [_p, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p, _cfgp]),
     "r2l_forward_emb": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p]),
     "r2l_num_tiles": (_l, [_l]),
     "r2l_padded_rows": (_l, [_l]),

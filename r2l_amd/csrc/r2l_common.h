@@ -407,6 +407,26 @@ int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, 
                       const float* scale_dev = nullptr);
 // forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
 // kernel (R2L_NO_FWD3=1: fp32 MFMA)
+// pose mode: the camera of ray rc and its pixel index.  One pose by value (c2w), or — one launch over several frames
+// (r2l_forward_poses: no tail round and no launch gap per frame) — a device table c2w_dev[K][12], frame = rc / (H * W)
+struct R2LPoseRay { float c[12]; int64_t pix; };
+__device__ __forceinline__ R2LPoseRay r2l_pose_of(const float (&c2w)[12], const float* c2w_dev, int64_t hw, int64_t rc) {
+    R2LPoseRay r;
+    r.pix = rc;
+    if (c2w_dev != nullptr) {
+        const int64_t p = rc / hw;
+        r.pix = rc - p * hw;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r.c[i] = c2w_dev[p * 12 + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r.c[i] = c2w[i];
+    }
+    return r;
+}
+// the multi-pose launch in progress on this thread (set by r2l_forward_poses_cfg around the single-pose dispatch)
+extern thread_local const float* g_r2l_c2w_dev;  // r2l_error.hip
+
 // Explicit dispatch (include/r2l_hip.h r2l_config): the *_cfg entry points install the caller's config for the duration of
 // the call (R2LCfgScope, thread-local), and every decision below looks at it first; an AUTO (0) field falls through to the
 // R2L_* environment switch it replaces, read per call (~100 ns) so tests can flip it.

@@ -3,6 +3,7 @@
 #include <stdio.h>
 
 static thread_local char g_err[512] = "";
+thread_local const float* g_r2l_c2w_dev = nullptr;
 thread_local r2l_config g_r2l_cfg = {};  // the config of the *_cfg call in progress on this thread (r2l_common.h)
 
 void r2l_set_error(const char* what, hipError_t e) {

@@ -16,6 +16,7 @@ struct R2LFwdArgs {
     const float* emb;      // [N,1008] pre-embedded input (module-boundary compatibility path)
     const float* ztab;     // [32]: z_lower[16], z_span[16]  (z = z_lower + z_span * t_rand ; z = z_lower if !t_rand)
     float c2w[12];         // row-major [3,4] camera-to-world (pose mode)
+    const float* c2w_dev;  // several frames per launch: [K][12] on the device (r2l_common.h r2l_pose_of), else nullptr
     int H, Wimg;
     float focal;
     // parameters
@@ -92,14 +93,15 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
         } else {
             // PointSampler.__init__/sample_test (nerf_raybased.py:80-99): dirs = [(i-W/2)/f, -(j-H/2)/f, -1],
             // rays_d[k] = sum_b dirs[b] * c2w[k][b], rays_o = c2w[:,3]
-            const int pj = (int)(rc / a.Wimg), pi = (int)(rc % a.Wimg);
+            const R2LPoseRay pr = r2l_pose_of(a.c2w, a.c2w_dev, (int64_t)a.H * a.Wimg, rc);
+            const int pj = (int)(pr.pix / a.Wimg), pi = (int)(pr.pix % a.Wimg);
             const float dx = ((float)pi - (float)a.Wimg * 0.5f) / a.focal;
             const float dy = -(((float)pj - (float)a.H * 0.5f) / a.focal);
             const float dz = -1.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                d[k] = (dx * a.c2w[4 * k + 0] + dy * a.c2w[4 * k + 1]) + dz * a.c2w[4 * k + 2];
-                o[k] = a.c2w[4 * k + 3];
+                d[k] = (dx * pr.c[4 * k + 0] + dy * pr.c[4 * k + 1]) + dz * pr.c[4 * k + 2];
+                o[k] = pr.c[4 * k + 3];
             }
         }
         // the 8 sample depths of this half-wave (samples 8h .. 8h+7)
@@ -296,15 +298,44 @@ extern "C" int r2l_forward_pose(const float* c2w_host12, int H, int W, float foc
                                 const float* wstream, const float* params, int n_block, float* rgb, void* stream) {
     return r2l_forward_pose_cfg(c2w_host12, H, W, focal, ztab, wstream, params, n_block, rgb, stream, nullptr);
 }
+static int forward_pose_impl(const float* c2w_host12, int64_t n_frames, int H, int W, float focal, const float* ztab,
+                             const float* wstream, const float* params, int n_block, float* rgb, void* stream);
+
 extern "C" int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float focal, const float* ztab,
                                     const float* wstream, const float* params, int n_block, float* rgb, void* stream,
                                     const r2l_config* cfg) {
     R2LCfgScope scope(cfg);
+    return forward_pose_impl(c2w_host12, 1, H, W, focal, ztab, wstream, params, n_block, rgb, stream);
+}
+
+// K frames in ONE launch: rgb[K*H*W,3], poses from a device table (include/r2l_hip.h).  The cooperative tilings (small
+// launches; only when pinned by the config / environment) take one pose by value: not here.
+extern "C" int r2l_forward_poses_cfg(const float* c2w_dev, int K, int H, int W, float focal, const float* ztab,
+                                     const float* wstream, const float* params, int n_block, float* rgb, void* stream,
+                                     const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
+    if (K <= 0) return 0;
+    const int64_t N = (int64_t)K * H * W;
+    if (c2w_dev == nullptr || r2l_chain_variant(N) != R2L_VARIANT_MAIN || r2l_use_coopf(N, n_block)) {
+        r2l_set_error_msg("r2l_forward_poses: needs a device pose table and a one-wave-per-tile tiling (cooperative tilings: "
+                          "call r2l_forward_pose per frame)");
+        return (int)hipErrorInvalidValue;
+    }
+    const float dummy[12] = {0};
+    g_r2l_c2w_dev = c2w_dev;
+    const int rc = forward_pose_impl(dummy, K, H, W, focal, ztab, wstream, params, n_block, rgb, stream);
+    g_r2l_c2w_dev = nullptr;
+    return rc;
+}
+
+static int forward_pose_impl(const float* c2w_host12, int64_t n_frames, int H, int W, float focal, const float* ztab,
+                             const float* wstream, const float* params, int n_block, float* rgb, void* stream) {
     R2LFwdArgs a{};
     for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
+    a.c2w_dev = g_r2l_c2w_dev;
     a.H = H; a.Wimg = W; a.focal = focal; a.ztab = ztab;
     a.wstream = wstream; a.params = params; a.n_block = n_block;
-    a.rgb = rgb; a.N = (int64_t)H * W;
+    a.rgb = rgb; a.N = n_frames * H * W;
     const int variant = a.N > 0 ? r2l_chain_variant(a.N) : R2L_VARIANT_MAIN;
     if (variant == R2L_VARIANT_COOP16)
         return r2l_coop16_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal,

@@ -82,6 +82,7 @@ struct F2Args {
     const float* t_rand;
     const float* ztab;
     float c2w[12];
+    const float* c2w_dev;  // several frames per launch: [K][12] on the device (r2l_common.h r2l_pose_of), else nullptr
     int H, Wimg;
     float focal;
     const unsigned char* stream;  // fwd2 stage stream
@@ -120,13 +121,14 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
             d[k] = a.rays_d[rc * 3 + k];
         }
     } else {
-        const int pj = (int)(rc / a.Wimg), pi = (int)(rc % a.Wimg);
+        const R2LPoseRay pr = r2l_pose_of(a.c2w, a.c2w_dev, (int64_t)a.H * a.Wimg, rc);
+        const int pj = (int)(pr.pix / a.Wimg), pi = (int)(pr.pix % a.Wimg);
         const float dx = ((float)pi - (float)a.Wimg * 0.5f) / a.focal;
         const float dy = -(((float)pj - (float)a.H * 0.5f) / a.focal);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            d[k] = (dx * a.c2w[4 * k + 0] + dy * a.c2w[4 * k + 1]) + (-1.0f) * a.c2w[4 * k + 2];
-            o[k] = a.c2w[4 * k + 3];
+            d[k] = (dx * pr.c[4 * k + 0] + dy * pr.c[4 * k + 1]) + (-1.0f) * pr.c[4 * k + 2];
+            o[k] = pr.c[4 * k + 3];
         }
     }
     float z[8];  // the 8 sample depths of this half-wave (samples 8h .. 8h+7)
@@ -344,6 +346,7 @@ int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_ra
     a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + r2l_fwd2_status_offset(n_block));
     a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
+    a.c2w_dev = c2w_host12 ? g_r2l_c2w_dev : nullptr;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     if (c2w_host12) hipLaunchKernelGGL((r2l_fwd2_kernel<true, false>), grid, block, 0, stream, a);

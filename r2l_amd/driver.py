@@ -143,6 +143,9 @@ def create_r2l(args, device, logger):
     return model, embedder, history, ckpt
 
 
+POSES_PER_LAUNCH = 9
+
+
 def render_frame(model, point_sampler, c2w):
     """One frame [H,W,3] (main.py:300-324 R2L branch): fused sample -> encode -> network."""
     with torch.no_grad():
@@ -229,17 +232,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "8"))) if savedir is not None else None
     on_gpu = device.type == "cuda"
     t_loop = time.time()
-    for i in mine:
-        if on_gpu:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        t0 = time.time()
-        rgb = render_frame(model, point_sampler, poses[i])
-        if on_gpu:
-            e1.record()
-            events.append((i, e0, e1))
-        else:
-            logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, time.time() - t0))
+    def account(i, rgb):
         rgbs.append(rgb)
         if gt_imgs is not None:
             gt = gt_imgs[i].to(rgb.device, non_blocking=True)
@@ -251,12 +244,34 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             writer.save(rgb, os.path.join(savedir, "%03d.png" % i))
             if gt_imgs is not None:
                 writer.save(gt_imgs[i], os.path.join(savedir, "%03d_gt.png" % i))
+
+    if on_gpu:
+        # POSES_PER_LAUNCH frames per launch (engine.forward_poses: no launch gap and no partly filled last round of
+        # workgroups per frame; 9 x 1250 workgroups = 43.95 rounds of the 256 CUs at 400x400)
+        for g0 in range(0, len(mine), POSES_PER_LAUNCH):
+            idx = mine[g0:g0 + POSES_PER_LAUNCH]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            c2ws = torch.stack([torch.as_tensor(poses[i], dtype=torch.float32)[:3, :4] for i in idx], 0)
+            with torch.no_grad():
+                frames = model.render_poses(c2ws, point_sampler).view(len(idx), point_sampler.H, point_sampler.W, 3)
+            e1.record()
+            events.append((idx, e0, e1))
+            for k, i in enumerate(idx):
+                account(i, frames[k])
+    else:
+        for i in mine:
+            t0 = time.time()
+            rgb = render_frame(model, point_sampler, poses[i])
+            logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, time.time() - t0))
+            account(i, rgb)
     if writer is not None:
         writer.close()
     if on_gpu:
         sync(device)
-        for i, e0, e1 in events:
-            logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, e0.elapsed_time(e1) * 1e-3))
+        for idx, e0, e1 in events:
+            for i in idx:  # (one launch per group of frames: its time divided evenly)
+                logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, e0.elapsed_time(e1) * 1e-3 / len(idx)))
         if mine:
             logger.info("%d frames in %.3fs wall (%.1f ms/frame incl. metrics and image writing)" %
                         (len(mine), time.time() - t_loop, (time.time() - t_loop) * 1e3 / len(mine)))

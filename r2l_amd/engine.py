@@ -210,6 +210,25 @@ class R2LEngine:
                                           _ptr(rgb), _stream(), self._cfg()), "r2l_forward_pose")
         return rgb
 
+    def forward_poses(self, c2ws, H, Wimg, focal, z_vals):
+        """rgb[K, H*W, 3] for the K frames seen from c2ws[K,3(+),4] in ONE launch (r2l_forward_poses_cfg): no launch gap and
+        no partly filled last round of workgroups per frame.  Pinned cooperative tilings: frame by frame."""
+        c = torch.as_tensor(c2ws, dtype=torch.float32)[:, :3, :4]
+        K = int(c.shape[0])
+        n = K * int(H) * int(Wimg)
+        self.ensure_packed(n, with_stash=False)
+        if K == 0:
+            return torch.empty(0, H * Wimg, 3, dtype=torch.float32, device=self.device)
+        if self.lib.r2l_variant_for_cfg(n, self._cfg()) != 0 or self.lib.r2l_coop_tiles_for_cfg(n, self.n_block, self._cfg()):
+            return torch.stack([self.forward_pose(c[k], H, Wimg, focal, z_vals) for k in range(K)], 0)
+        cd = c.to(self.device).contiguous()
+        rgb = torch.empty(K, H * Wimg, 3, dtype=torch.float32, device=self.device)
+        _lib.check(
+            self.lib.r2l_forward_poses_cfg(_ptr(cd), K, int(H), int(Wimg), float(focal), _ptr(self.ztab(z_vals, 0.)),
+                                           _ptr(self.wstream), _ptr(self.flat), self.n_block, _ptr(rgb), _stream(),
+                                           self._cfg()), "r2l_forward_poses")
+        return rgb
+
     def forward_emb(self, emb, save=None):
         """rgb[N,3] from the already embedded input [N,1008] (nn.Module-boundary compatibility path)."""
         self.ensure_packed()

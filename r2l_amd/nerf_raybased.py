@@ -214,6 +214,14 @@ class NeRF_v3_2(nn.Module):
         ps = point_sampler
         return self.engine().forward_pose(c2w, ps.H, ps.W, ps.focal, ps.z_vals)
 
+    def render_poses(self, c2ws, point_sampler):
+        """rgb[K, H*W, 3] for K frames in one launch (the test-set loop of main.py:300-309 without per-frame launches)."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            return torch.stack([self.render_pose(c, point_sampler) for c in c2ws], 0)
+        ps = point_sampler
+        return self.engine().forward_poses(c2ws, ps.H, ps.W, ps.focal, ps.z_vals)
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # the teacher network   (reference: NeRF, nerf_raybased.py:337-401)

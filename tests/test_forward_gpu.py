@@ -237,3 +237,19 @@ def test_explicit_config_selects_the_family(chain_variant, monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
     assert not torch.equal(raws[0], raws[1]) and not torch.equal(raws[1], raws[2])
+
+
+def test_multi_pose_launch_equals_per_pose(chain_variant, model88):
+    """r2l_forward_poses_cfg: K frames in one launch are bit for bit the K single-pose launches (a frame size that is NOT a
+    multiple of the 32-ray tile, so tiles straddle frames); pinned cooperative tilings go frame by frame in the host layer."""
+    from model.nerf_raybased import PointSampler
+    sd, m = model88
+    H, W = 37, 41
+    ps = PointSampler(H, W, 50., 16, 2., 6., device="cuda")
+    poses = torch.stack([T(O.pose_spherical(30. * k, -20. - 3 * k, 4.)[:3, :4]) for k in range(5)], 0)
+    with torch.no_grad():
+        one = torch.stack([m.render_pose(p, ps) for p in poses], 0)
+        many = m.render_poses(poses, ps)
+    assert many.shape == (5, H * W, 3) and torch.equal(one, many)
+    ref = O.r2l_forward(sd, O.positional_embed(O.sample_test(O.pixel_dirs(H, W, 50.), O.z_vals(16, 2., 6.), poses[3])[:200], 10))
+    assert (many[3, :200].cpu() - ref).abs().max().item() < TOL
