@@ -9,6 +9,7 @@
 //   3. r2l_dw_head_kernel   : dW_head = G_head^T PE(rays) with the 1008-d positional encoding recomputed on the fly.
 //   4. r2l_dw_tail_kernel   : tail weight/bias gradients (3x256) by plain reduction.
 #include "r2l_common.h"
+#include "r2l_f2.h"
 #include "r2l_dw.h"
 #include "r2l_hip.h"
 
@@ -1257,7 +1258,10 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         // dX chain raised its status word (this step fell back to the bf16x3 chains and their fp32 stash) it returns at once
         // and the bf16x3 kernel behind it does the work
         if (trio16) {
+            // (exact mode: the chains of this step stashed the mid halves too — the same config / environment as the forward)
+            a.mid_off = r2l_dw_exact() ? (unsigned)R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) : 0u;
             const int rc = r2l_dw16_launch(a, wgs, bwd_status, stream);
+            a.mid_off = 0u;
             if (rc) return rc;
             a.run_if = bwd_status;
             hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
@@ -1299,6 +1303,7 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             a.unscale = 1.0f / gscale;
             a.scale_dev = scale_dev;
             a.run_unless = bwd_status;
+            a.exact = r2l_dw_exact();
             const int rc = r2l_dw_head16_launch(a, slices, stream);
             if (rc) return rc;
             a.run_unless = nullptr;

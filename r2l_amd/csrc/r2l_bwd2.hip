@@ -67,6 +67,7 @@ struct B2Args {
     float* gt;
     float* sqerr_partial;
     int64_t N;
+    unsigned stash_mid;  // != 0: also stash the mid halves of g / masked u, this many bytes behind the hi pieces (r2l_f2.h)
 };
 
 // gatherers: four B values of the next stage (+ their stash store)
@@ -92,6 +93,8 @@ struct B3TakeU {  // u values masked by relu'(t_b) (mask words of the forward: b
     }
 };
 
+// MID: the mid halves of g / masked u are stashed too (exact weight gradients; template parameter: see r2l_fwd2.hip)
+template <bool MID>
 __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char mring[4][B3_RING][1024];
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
         float* const gtr = a.gt + (int64_t)b * slot;
         const unsigned hvoff = (unsigned)(lane_unit * 16);
         const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+        constexpr bool mid = MID;
         const F3Dma mask_dma{true, trs, mvoff, 0u, ring_lds + (unsigned)(b & 1) * 1024u};
         // GEMM A: u = W2^T g.  stage 0 (zero stage, zero-initialises u) gathers g block 0; stage 1+kb gathers g block kb+1
         f2_stage<true, true, false>(u, P, B3TakeG{g[0], 0}, B3TakeG{g[0], 4}, mask_dma, no_dma, F2Hst{true, gxr, hvoff, 0u});
@@ -222,18 +226,23 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(u, P, B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1)},
                                           B3TakeG{g[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4}, no_dma, no_dma,
-                                          F2Hst{true, gxr, hvoff, 1024u * (unsigned)(kb + 1)});
+                                          F2Hst{true, gxr, hvoff, 1024u * (unsigned)(kb + 1)},
+                                          F2Hst{mid, gxr, hvoff, 1024u * (unsigned)kb + a.stash_mid});
         // (the mask piece was requested 16 stages ago: every stage wait since has retired all but the newest loads)
         const u32x4 mb = *reinterpret_cast<const u32x4*>(ring_lane + (b & 1) * 1024);
-        f2_stage<false, false, true>(u, P, F3None{}, F3None{});
+        f2_stage<false, false, true>(u, P, F3None{}, F3None{}, no_dma, no_dma, F2Hst{false, nullptr, 0u, 0u},
+                                     F2Hst{mid, gxr, hvoff, 1024u * 15u + a.stash_mid});
         // GEMM B: g += W1^T (u . mask).  stage 17 (zero stage) gathers masked-u block 0; stage 18+kb gathers block kb+1
         f2_stage<true, false, false>(g, P, B3TakeU{u[0], 0, 0, mb}, B3TakeU{u[0], 4, 0, mb}, no_dma, no_dma, F2Hst{true, gtr, hvoff, 0u});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(g, P, B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1), (kb + 1) >> 1, mb},
                                           B3TakeU{u[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, (kb + 1) >> 1, mb}, no_dma, no_dma,
-                                          F2Hst{true, gtr, hvoff, 1024u * (unsigned)(kb + 1)});
-        f2_stage<false, false, true>(g, P, F3None{}, F3None{});  // next: the zero stage of the next block (or the padding)
+                                          F2Hst{true, gtr, hvoff, 1024u * (unsigned)(kb + 1)},
+                                          F2Hst{mid, gtr, hvoff, 1024u * (unsigned)kb + a.stash_mid});
+        // next: the zero stage of the next block (or the padding)
+        f2_stage<false, false, true>(g, P, F3None{}, F3None{}, no_dma, no_dma, F2Hst{false, nullptr, 0u, 0u},
+                                     F2Hst{mid, gtr, hvoff, 1024u * 15u + a.stash_mid});
     }
 
     if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
@@ -288,8 +297,10 @@ int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, 
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
+    a.stash_mid = r2l_dw_exact() ? (unsigned)R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) : 0u;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    hipLaunchKernelGGL(r2l_bwd2_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    if (a.stash_mid != 0u) hipLaunchKernelGGL(r2l_bwd2_kernel<true>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(r2l_bwd2_kernel<false>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -203,9 +203,11 @@ __device__ __forceinline__ void fc_split8(const float (&v)[8], u32x4& uh, u32x4&
 struct FcIdentity {
     __device__ __forceinline__ float operator()(float v, int, int) const { return v; }
 };
-template <bool RELU, bool SAVE, bool MASK, class Sel = FcIdentity>
+// (MID: the mid quads are stashed as well, mid_units 16-byte units behind the hi pieces — exact weight gradients; a template
+// parameter so that the default kernels keep their register allocation)
+template <bool RELU, bool SAVE, bool MASK, class Sel = FcIdentity, bool MID = false>
 __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bopw, u32x4* hst, unsigned* mword, float& amax,
-                                           const Sel& sel = Sel()) {
+                                           const Sel& sel = Sel(), int64_t mid_units = 0) {
     unsigned mw = 0u;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -222,7 +224,10 @@ __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bop
             fc_split8(v, uh, um, amax);
             fc_lds_write(bopw + (unsigned)(2 * tt + r) * 2048u, uh);
             fc_lds_write(bopw + (unsigned)(2 * tt + r) * 2048u + 1024u, um);
-            if (SAVE) fc_store_nt(hst + 64 * (2 * tt + r), uh);
+            if (SAVE) {
+                fc_store_nt(hst + 64 * (2 * tt + r), uh);
+                if (MID) fc_store_nt(hst + 64 * (2 * tt + r) + mid_units, um);
+            }
         }
     if (MASK) *mword = mw;
 }

@@ -29,7 +29,7 @@ struct CfBwdArgs {
     float* gx;
     float* gt;
     float* sqerr_partial;
-    int64_t N;
+    int64_t N;    int64_t mid_units;  // != 0: mid quads stashed this many 16-byte units behind the hi pieces (exact weight gradients)
 };
 
 // masked u: bit tt*16 + c of the forward's mask word of this wave
@@ -38,7 +38,7 @@ struct CfMask {
     __device__ __forceinline__ float operator()(float v, int tt, int c) const { return ((w >> (tt * 16 + c)) & 1u) ? v : 0.f; }
 };
 
-template <int NT>
+template <int NT, bool MID = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
     // B-operand images: [g | masked u][ray tile][16 stages x (hi, mid) x 1 KiB]
     __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
 
     // g B operands in the kind-0 images, masked-u B operands in the kind-1 images; a barrier after each production
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) fc_produce<false, true, false>(g[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, gxh[rt], nullptr, amax);
+    for (int rt = 0; rt < NT; ++rt) fc_produce<false, true, false, FcIdentity, MID>(g[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, gxh[rt], nullptr, amax, FcIdentity(), a.mid_units);
     fc_barrier();
     auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {
             asm volatile("" : "+v"(mw[rt]));  // (uses of mw stay behind GEMM A)
-            fc_produce<false, true, false>(u[rt], bop_wr + KIND + (unsigned)rt * FC_BOP_BYTES, gth[rt], nullptr, amax, CfMask{mw[rt]});
+            fc_produce<false, true, false, CfMask, MID>(u[rt], bop_wr + KIND + (unsigned)rt * FC_BOP_BYTES, gth[rt], nullptr, amax, CfMask{mw[rt]}, a.mid_units);
         }
         fc_barrier();
         // GEMM B: g += W1^T (u . mask)
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
         if (!last) {
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
-                fc_produce<false, true, false>(g[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, gxh[rt], nullptr, amax);
+                fc_produce<false, true, false, FcIdentity, MID>(g[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, gxh[rt], nullptr, amax, FcIdentity(), a.mid_units);
             fc_barrier();
         }
     };
@@ -249,12 +249,21 @@ int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb,
     a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t;
     a.stream = reinterpret_cast<const unsigned char*>(wstream_bwd2); a.params = params; a.n_block = n_block;
     a.grad_scale = grad_scale; a.dpre = dpre; a.gx = gx; a.gt = gt; a.sqerr_partial = sqerr_partial; a.N = N;
+    a.mid_units = r2l_dw_exact() ? R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) / 16 : 0;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    if (r2l_coopf_two_tiles(tiles)) hipLaunchKernelGGL(r2l_coopf_bwd_kernel<2>, dim3((unsigned)((tiles + 1) / 2)), dim3(256), 0, stream, a);
-    else {
-        static int solo_ok = 0;
-        if (int e = fc_check_solo(r2l_coopf_bwd_kernel<1>, "r2l_coopf_bwd_kernel<1>", &solo_ok)) return e;
-        hipLaunchKernelGGL(r2l_coopf_bwd_kernel<1>, dim3((unsigned)tiles), dim3(256), FC_SOLO_LDS_BYTES, stream, a);
+    static int solo_ok[2] = {0, 0};
+    if (a.mid_units != 0) {  // exact weight gradients: the mid halves of g / masked u are stashed too
+        if (r2l_coopf_two_tiles(tiles))
+            hipLaunchKernelGGL((r2l_coopf_bwd_kernel<2, true>), dim3((unsigned)((tiles + 1) / 2)), dim3(256), 0, stream, a);
+        else {
+            if (int e = fc_check_solo(r2l_coopf_bwd_kernel<1, true>, "r2l_coopf_bwd_kernel<1, mid>", &solo_ok[1])) return e;
+            hipLaunchKernelGGL((r2l_coopf_bwd_kernel<1, true>), dim3((unsigned)tiles), dim3(256), FC_SOLO_LDS_BYTES, stream, a);
+        }
+    } else if (r2l_coopf_two_tiles(tiles)) {
+        hipLaunchKernelGGL((r2l_coopf_bwd_kernel<2>), dim3((unsigned)((tiles + 1) / 2)), dim3(256), 0, stream, a);
+    } else {
+        if (int e = fc_check_solo(r2l_coopf_bwd_kernel<1>, "r2l_coopf_bwd_kernel<1>", &solo_ok[0])) return e;
+        hipLaunchKernelGGL((r2l_coopf_bwd_kernel<1>), dim3((unsigned)tiles), dim3(256), FC_SOLO_LDS_BYTES, stream, a);
     }
     R2L_CHECK(hipGetLastError());
     return 0;

@@ -28,9 +28,10 @@ struct CfFwdArgs {
     float* save_x;  // training stash (fp16 stage pieces, r2l_f2.h) or nullptr
     float* save_t;
     int64_t N;
+    int64_t mid_units;  // != 0: mid quads stashed this many 16-byte units behind the hi pieces (exact weight gradients)
 };
 
-template <bool POSE, bool SAVE, int NT>
+template <bool POSE, bool SAVE, int NT, bool MID = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
     // B-operand images: [x | relu(t)][ray tile][16 stages x (hi, mid) x 1 KiB]
     __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
     // (the kind-0 images were last read in chunk 2 of the head, two barriers ago)
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax);
+    for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false, FcIdentity, MID>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax, FcIdentity(), a.mid_units);
     fc_barrier();
     auto block = [&](auto ph_tag, bool last) {
         constexpr int PH = decltype(ph_tag)::value;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {
             unsigned mw = 0u;
-            fc_produce<true, SAVE, SAVE>(t[rt], bop_wr + KIND + (unsigned)rt * FC_BOP_BYTES, ht[rt], &mw, amax);
+            fc_produce<true, SAVE, SAVE, FcIdentity, MID>(t[rt], bop_wr + KIND + (unsigned)rt * FC_BOP_BYTES, ht[rt], &mw, amax, FcIdentity(), a.mid_units);
             if (SAVE) fc_store_b32(mwp[rt], mw);
         }
         fc_barrier();
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         }
         if (!last) {
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax);
+            for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false, FcIdentity, MID>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax, FcIdentity(), a.mid_units);
             fc_barrier();
         }
     };
@@ -344,16 +345,23 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
     a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + r2l_fwd2_status_offset(n_block));
     a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
+    a.mid_units = (save_x != nullptr && r2l_dw_exact()) ? R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) / 16 : 0;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     // up to one workgroup per CU: one ray tile each; beyond, two tiles per workgroup share every weight load
     const bool two = r2l_coopf_two_tiles(tiles);
     const dim3 grid((unsigned)(two ? (tiles + 1) / 2 : tiles)), block(256);
-    static int solo_ok[3] = {0, 0, 0};  // one-tile kernels: at most one workgroup per CU, verified before the first launch
+    static int solo_ok[4] = {0, 0, 0, 0};  // one-tile kernels: at most one workgroup per CU, verified before the first launch
     if (c2w_host12) {
         if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 2>), grid, block, 0, stream, a);
         else {
             if (int e = fc_check_solo(r2l_coopf_fwd_kernel<true, false, 1>, "r2l_coopf_fwd_kernel<pose>", &solo_ok[0])) return e;
             hipLaunchKernelGGL((r2l_coopf_fwd_kernel<true, false, 1>), grid, block, FC_SOLO_LDS_BYTES, stream, a);
+        }
+    } else if (save_x && a.mid_units != 0) {  // exact weight gradients: the mid halves are stashed too
+        if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 2, true>), grid, block, 0, stream, a);
+        else {
+            if (int e = fc_check_solo(r2l_coopf_fwd_kernel<false, true, 1, true>, "r2l_coopf_fwd_kernel<save, mid>", &solo_ok[3])) return e;
+            hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 1, true>), grid, block, FC_SOLO_LDS_BYTES, stream, a);
         }
     } else if (save_x) {
         if (two) hipLaunchKernelGGL((r2l_coopf_fwd_kernel<false, true, 2>), grid, block, 0, stream, a);

@@ -41,6 +41,9 @@ struct R2LDwArgs {
     // launched with run_if returns at once while that word is 0
     unsigned* status = nullptr;
     const unsigned* run_if = nullptr;
+    // exact weight gradients of the fp16 trio (r2l_dw16.hip): != 0 -> the slots also hold the operands' mid halves, this many
+    // bytes behind the hi stage pieces (r2l_f2.h R2L_H16_MID_BYTES), and every fp32 product is taken as hi*hi + hi*mid + mid*hi
+    unsigned mid_off = 0u;
 };
 
 #define DW_SLAB_FLOATS (R2L_W * R2L_W + R2L_W)  // one layer: dW[256][256] then db[256], as in the flat gradient
@@ -66,6 +69,7 @@ struct R2LDwHeadArgs {
     const float* scale_dev = nullptr;  // {gscale, 1 / gscale} on the device (generic mode); overrides the two above
     const unsigned* run_unless = nullptr;
     const unsigned* run_if = nullptr;
+    bool exact = false;  // r2l_dw_head16: both operands as hi + mid, three products (exact weight gradients)
 };
 
 // Per-lane description of one encoding column k (fixed for the whole kernel): which sample / axis it reads and what it

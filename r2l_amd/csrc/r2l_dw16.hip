@@ -29,9 +29,14 @@
 #include "r2l_f2.h"
 #include "r2l_dw.h"
 
-#define DW16_NB 4
 #define DW16_OP_BYTES 16384
-#define DW16_STAGE_BYTES 32768
+// EXACT (r2l_config.dw_mode = R2L_DW_EXACT): the tile's image is [G hi | A hi | G mid | A mid] (64 KiB, two tiles in flight
+// instead of four), 48 MFMAs per 16 rays instead of 16: mid*hi + hi*mid + hi*hi, small terms first — the three-product
+// scheme of the chains (r2l_f2.h), so dW carries fp32-grade products for twice the stash traffic (still HBM-bound).
+template <bool EXACT> struct Dw16Cfg {
+    static constexpr int NB = EXACT ? 2 : 4;
+    static constexpr unsigned STAGE_BYTES = EXACT ? 65536u : 32768u;
+};
 
 typedef short dw16_s16x4 __attribute__((ext_vector_type(4)));
 typedef short dw16_s16x8 __attribute__((ext_vector_type(8)));
@@ -59,11 +64,16 @@ __device__ __forceinline__ float dw16_add_hi(unsigned h, float acc) {
     return r;
 }
 
-struct Dw16Frags {  // operands of one k-step (16 rays): four 32-feature tiles of each operand
+template <bool EXACT>
+struct Dw16Frags {  // operands of one k-step (16 rays): four 32-feature tiles of each operand (EXACT: hi and mid halves)
     f16x8 g[4], x[4];
+    f16x8 gm[EXACT ? 4 : 1], xm[EXACT ? 4 : 1];
 };
 
+template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, const unsigned* run_unless) {
+    constexpr int DW16_NB = Dw16Cfg<EXACT>::NB;
+    constexpr unsigned DW16_STAGE_BYTES = Dw16Cfg<EXACT>::STAGE_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char img[DW16_NB][DW16_STAGE_BYTES];
     if (run_unless != nullptr && __builtin_nontemporal_load(run_unless) != 0u) {
         // this step's stash is the bf16x3 trio's (fp32): hand the launch to the kernel behind this one
@@ -138,18 +148,38 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                 const unsigned po = (unsigned)((i >> 1) * 2048 + (i & 1) * 256);
                 f3_dma16(grs, dvoff, so + po, ld + (unsigned)i * 1024u);
                 f3_dma16(ars, dvoff, so + po, ld + DW16_OP_BYTES + (unsigned)i * 1024u);
+                if (EXACT) {
+                    f3_dma16(grs, dvoff, so + po + a.mid_off, ld + 2 * DW16_OP_BYTES + (unsigned)i * 1024u);
+                    f3_dma16(ars, dvoff, so + po + a.mid_off, ld + 3 * DW16_OP_BYTES + (unsigned)i * 1024u);
+                }
             }
         };
-        auto read = [&](Dw16Frags& R, int s, int ks) {
+        auto read = [&](Dw16Frags<EXACT>& R, int s, int ks) {
             const unsigned bo = (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES + (unsigned)ks * 1024u;
             const unsigned gp = gl + bo, ap = al + bo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 R.g[e] = dw16_frag(gp, (unsigned)e * 2048u);
                 R.x[e] = dw16_frag(ap, (unsigned)e * 2048u);
+                if (EXACT) {
+                    R.gm[e] = dw16_frag(gp, 2 * DW16_OP_BYTES + (unsigned)e * 2048u);
+                    R.xm[e] = dw16_frag(ap, 2 * DW16_OP_BYTES + (unsigned)e * 2048u);
+                }
             }
         };
-        auto mma = [&](const Dw16Frags& R) {
+        auto mma = [&](const Dw16Frags<EXACT>& R) {
+            if (EXACT) {  // small terms first
+#pragma unroll
+                for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+                    for (int ei = 0; ei < 4; ++ei)
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.gm[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+#pragma unroll
+                for (int eo = 0; eo < 4; ++eo)
+#pragma unroll
+                    for (int ei = 0; ei < 4; ++ei)
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.xm[ei], acc[eo][ei], 0, 0, 0);
+            }
 #pragma unroll
             for (int eo = 0; eo < 4; ++eo)
 #pragma unroll
@@ -161,22 +191,29 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     const u32x4 w = __builtin_bit_cast(u32x4, R.g[eo]);
 #pragma unroll
                     for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(w[d], dw16_add_lo(w[d], bsum[eo]));
+                    if (EXACT) {
+                        const u32x4 wm = __builtin_bit_cast(u32x4, R.gm[eo]);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(wm[d], dw16_add_lo(wm[d], bsum[eo]));
+                    }
                 }
             }
         };
-        Dw16Frags R0, R1;
-        // prologue: tiles 0 .. 3 requested, tile 0 published (latency exposed once per segment)
+        Dw16Frags<EXACT> R0, R1;
+        // prologue: tiles 0 .. NB-1 requested, tile 0 published (latency exposed once per segment)
 #pragma unroll
         for (int s = 0; s < DW16_NB; ++s) issue(s);
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (EXACT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // 2 tiles x 16 loads per wave
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // 4 tiles x 8
         __syncthreads();
         read(R0, 0, 0);
         for (int s = 0; s < ntiles; ++s) {
             read(R1, s, 1);
             mma(R0);
-            // tile s+1 landed (its 8 loads have the 16 of tiles s+2, s+3 behind them); behind the barrier everybody's share is
-            // visible and nobody reads the image of tile s any more (its fragments are in registers)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            // tile s+1 landed (its 8 loads have the 16 of tiles s+2, s+3 behind them; EXACT: nothing behind its 16); behind the
+            // barrier everybody's share is visible and nobody reads the image of tile s any more (its fragments are in registers)
+            if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             __syncthreads();
             issue(s + DW16_NB);
             read(R0, s + 1, 0);
@@ -231,7 +268,8 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
 }
 
 int r2l_dw16_launch(const R2LDwArgs& a, int64_t wgs, const unsigned* run_unless, hipStream_t stream) {
-    hipLaunchKernelGGL(r2l_dw16_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a, run_unless);
+    if (a.mid_off != 0u) hipLaunchKernelGGL(r2l_dw16_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, stream, a, run_unless);
+    else hipLaunchKernelGGL(r2l_dw16_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, stream, a, run_unless);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

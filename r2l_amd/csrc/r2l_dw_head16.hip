@@ -60,7 +60,9 @@ __device__ __forceinline__ h16_rsrc_t h16_rsrc(const float* base, unsigned bytes
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <bool JITTER>
+// EXACT (r2l_config.dw_mode = R2L_DW_EXACT): both operands as fp16 hi + mid, mid*hi + hi*mid + hi*hi per tile (48 MFMAs per
+// k-step instead of 16; the kernel stays VALU-bound).
+template <bool JITTER, bool EXACT>
 __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadArgs a) {
     if (a.run_unless != nullptr && __builtin_nontemporal_load(a.run_unless) != 0u) return;  // the fp32 kernel behind does it
     const float gscale = a.scale_dev != nullptr ? a.scale_dev[0] : a.gscale;
@@ -136,12 +138,21 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
     ld_g(rg);
     ld_rays(rr);
     for (int s = 0; s < nsteps; ++s) {
-        f16x8 ga[8];
+        f16x8 ga[8], gm[EXACT ? 8 : 1];
         const float sc = gscale;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            ga[e] = __builtin_bit_cast(f16x8, u32x4{pk(rg.g[e][0] * sc, rg.g[e][1] * sc), pk(rg.g[e][2] * sc, rg.g[e][3] * sc),
-                                                    pk(rg.g[e][4] * sc, rg.g[e][5] * sc), pk(rg.g[e][6] * sc, rg.g[e][7] * sc)});
+            u32x4 uh;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) uh[d] = pk(rg.g[e][2 * d] * sc, rg.g[e][2 * d + 1] * sc);
+            ga[e] = __builtin_bit_cast(f16x8, uh);
+            if (EXACT) {
+                u32x4 um;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    um[d] = pk(f2_res_lo(uh[d], rg.g[e][2 * d] * sc), f2_res_hi(uh[d], rg.g[e][2 * d + 1] * sc));
+                gm[e] = __builtin_bit_cast(f16x8, um);
+            }
             if (kq == 0 && wave == 0)
                 bsum[e] += ((rg.g[e][0] + rg.g[e][1]) + (rg.g[e][2] + rg.g[e][3])) + ((rg.g[e][4] + rg.g[e][5]) + (rg.g[e][6] + rg.g[e][7]));
         }
@@ -163,11 +174,33 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
                 p1[i] = pc.trig ? cs : (pc.kb >= 0 ? xb : 0.f);
             }
         }
-        const f16x8 b0 = __builtin_bit_cast(f16x8, u32x4{pk(p0[0], p0[1]), pk(p0[2], p0[3]), pk(p0[4], p0[5]), pk(p0[6], p0[7])});
-        const f16x8 b1 = __builtin_bit_cast(f16x8, u32x4{pk(p1[0], p1[1]), pk(p1[2], p1[3]), pk(p1[4], p1[5]), pk(p1[6], p1[7])});
+        u32x4 u0, u1, m0, m1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            u0[d] = pk(p0[2 * d], p0[2 * d + 1]);
+            u1[d] = pk(p1[2 * d], p1[2 * d + 1]);
+            if (EXACT) {
+                m0[d] = pk(f2_res_lo(u0[d], p0[2 * d]), f2_res_hi(u0[d], p0[2 * d + 1]));
+                m1[d] = pk(f2_res_lo(u1[d], p1[2 * d]), f2_res_hi(u1[d], p1[2 * d + 1]));
+            }
+        }
+        const f16x8 b0 = __builtin_bit_cast(f16x8, u0), b1 = __builtin_bit_cast(f16x8, u1);
         __builtin_amdgcn_sched_barrier(0);
         ld_rays(rr);
         __builtin_amdgcn_sched_barrier(0);
+        if (EXACT) {  // small terms first
+            const f16x8 bm0 = __builtin_bit_cast(f16x8, m0), bm1 = __builtin_bit_cast(f16x8, m1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm[e], b0, acc[e][0], 0, 0, 0);
+                acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm[e], b1, acc[e][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[e], bm0, acc[e][0], 0, 0, 0);
+                acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[e], bm1, acc[e][1], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[e], b0, acc[e][0], 0, 0, 0);
@@ -208,8 +241,13 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_head16_kernel(const R2LDwHeadAr
 
 int r2l_dw_head16_launch(const R2LDwHeadArgs& a, int64_t slices, hipStream_t stream) {
     const dim3 grid((unsigned)(slices * 4)), block(256);
-    if (a.t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head16_kernel<true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((r2l_dw_head16_kernel<false>), grid, block, 0, stream, a);
+    if (a.exact) {
+        if (a.t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head16_kernel<true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_dw_head16_kernel<false, true>), grid, block, 0, stream, a);
+    } else {
+        if (a.t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head16_kernel<true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_dw_head16_kernel<false, false>), grid, block, 0, stream, a);
+    }
     R2L_CHECK(hipGetLastError());
     return 0;
 }

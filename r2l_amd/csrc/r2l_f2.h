@@ -65,6 +65,11 @@ struct F2Split {
 // (half the bytes of the fp32 stash of the bf16x3 trio, which keeps the slot size: the range-guard fallback rewrites a slot
 // in that format).  Word R2L_STASH_FMT_WORD of save_x says which format the forward left behind (0: this one).
 #define R2L_H16_TILE_UNITS 1024  // 16-byte units per tile and slot
+// Exact weight gradients (r2l_config.dw_mode = R2L_DW_EXACT): the chains also stash the MID halves of the same operands, as a
+// second set of stage pieces R2L_H16_MID_BYTES(Np) behind the first in the slot (the half of its data area the hi pieces leave
+// free), and r2l_dw16 / r2l_dw_head16 take hi*hi + hi*mid + mid*hi — fp32-grade products, twice the stash traffic.  A stage
+// stores the mid half of its OWN B operand (f2_stage's hmid), the hi half of the NEXT stage's (hst).
+#define R2L_H16_MID_BYTES(Np) ((int64_t)(Np) * 512)
 struct F2Hst {                   // where this lane's 16 B of the NEXT stage's B operand go (on == false: no stash)
     bool on;
     float* slot;    // the stash slot (uniform: a scalar register pair; the chain's launcher advances it per block)
@@ -230,7 +235,11 @@ template <bool BIAS_K, bool ZERO_K, bool BIAS_NEXT, class GLo, class GHi>
 __device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi,
                                          F3Dma extra_a = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
                                          F3Dma extra_b = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u},
-                                         F2Hst hst = F2Hst{false, nullptr, 0u, 0u}) {
+                                         F2Hst hst = F2Hst{false, nullptr, 0u, 0u},
+                                         F2Hst hmid = F2Hst{false, nullptr, 0u, 0u}) {
+    // exact weight gradients: the MID half of THIS stage's B operand goes to its own piece (hmid: the stage's piece +
+    // R2L_H16_MID_BYTES).  It is the register quad the MFMAs of the stage read: no copy, nothing extra kept alive.
+    if (!BIAS_K && hmid.on) f2_hst_store(hmid, __builtin_bit_cast(u32x4, P.sb.m));
     F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax, extra_a};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);

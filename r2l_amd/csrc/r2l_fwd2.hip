@@ -93,9 +93,12 @@ struct F2Args {
     float* save_x;  // training: the stash slots of X_0 .. X_{n-1} / relu(hidden) as fp16 stage pieces (r2l_f2.h), slot n of
     float* save_t;  //           save_x = X_n + X_0 row-major fp32; or nullptr
     int64_t N;
+    unsigned stash_mid;  // != 0: also stash the operands' mid halves, this many bytes behind the hi pieces (r2l_f2.h)
 };
 
-template <bool POSE, bool SAVE>
+// MID (training stash only): the operands' mid halves are stashed too (exact weight gradients, r2l_f2.h); a template
+// parameter because even a uniform branch around the store inside a stage costs the default kernel ~150 more spilled VGPRs
+template <bool POSE, bool SAVE, bool MID = false>
 __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
 
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     const int64_t slot = R2L_TRIO_SLOT(Np);
     const unsigned hvoff = (unsigned)((tile * R2L_H16_TILE_UNITS + lane) * 16);  // this lane's unit of stage piece 0 in a slot
     const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    constexpr bool mid = SAVE && MID;
     if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
         reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
 #pragma unroll 1
@@ -258,8 +262,10 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(t, P, F3Take4<false, SAVE, false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, (kb + 1) >> 1},
                                           F3Take4<false, SAVE, false>{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, (kb + 1) >> 1},
-                                          no_dma, no_dma, F2Hst{SAVE, hxr, hvoff, 1024u * (unsigned)(kb + 1)});
-        f2_stage<false, false, true>(t, P, F3None{}, F3None{});
+                                          no_dma, no_dma, F2Hst{SAVE, hxr, hvoff, 1024u * (unsigned)(kb + 1)},
+                                          F2Hst{mid, hxr, hvoff, 1024u * (unsigned)kb + a.stash_mid});
+        f2_stage<false, false, true>(t, P, F3None{}, F3None{}, no_dma, no_dma, F2Hst{false, nullptr, 0u, 0u},
+                                     F2Hst{mid, hxr, hvoff, 1024u * 15u + a.stash_mid});
         // x += W2 relu(t) + b2   (training: the gatherers also shift [t > 0] into the block's four mask words)
         unsigned mw[4] = {0u, 0u, 0u, 0u};
         f2_stage<true, false, false>(x, P, F3Take4<true, SAVE, false>{t[0], 0, nullptr, 0, &mw[0]},
@@ -268,8 +274,11 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
         for (int kb = 0; kb < 15; ++kb)
             f2_stage<false, false, false>(x, P, F3Take4<true, SAVE, false>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
                                           F3Take4<true, SAVE, false>{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, (kb + 1) >> 1, &mw[(kb + 1) >> 2]},
-                                          no_dma, no_dma, F2Hst{SAVE, htr, hvoff, 1024u * (unsigned)(kb + 1)});
-        f2_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next block's bias stage (or the padding)
+                                          no_dma, no_dma, F2Hst{SAVE, htr, hvoff, 1024u * (unsigned)(kb + 1)},
+                                          F2Hst{mid, htr, hvoff, 1024u * (unsigned)kb + a.stash_mid});
+        // next: the next block's bias stage (or the padding)
+        f2_stage<false, false, true>(x, P, F3None{}, F3None{}, no_dma, no_dma, F2Hst{false, nullptr, 0u, 0u},
+                                     F2Hst{mid, htr, hvoff, 1024u * 15u + a.stash_mid});
         if (SAVE) {  // values were shifted in MSB-first: bit (T&1)*16 + c after the reversal
             u32x4 mv;
 #pragma unroll
@@ -347,9 +356,11 @@ int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_ra
     a.n_block = n_block; a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N; a.H = H; a.Wimg = W; a.focal = focal;
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     a.c2w_dev = c2w_host12 ? g_r2l_c2w_dev : nullptr;
+    a.stash_mid = (save_x != nullptr && r2l_dw_exact()) ? (unsigned)R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) : 0u;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     if (c2w_host12) hipLaunchKernelGGL((r2l_fwd2_kernel<true, false>), grid, block, 0, stream, a);
+    else if (save_x && a.stash_mid != 0u) hipLaunchKernelGGL((r2l_fwd2_kernel<false, true, true>), grid, block, 0, stream, a);
     else if (save_x) hipLaunchKernelGGL((r2l_fwd2_kernel<false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((r2l_fwd2_kernel<false, false>), grid, block, 0, stream, a);
     R2L_CHECK(hipGetLastError());

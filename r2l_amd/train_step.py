@@ -30,10 +30,15 @@ class R2LTrainer:
     nn.DataParallel computed on GPU 0.
     """
 
-    def __init__(self, module, point_sampler, betas=(0.9, 0.999), eps=1e-8, lw_rgb=1.0, process_group=None):
+    def __init__(self, module, point_sampler, betas=(0.9, 0.999), eps=1e-8, lw_rgb=1.0, process_group=None, dw_mode=None):
+        """dw_mode: None (keep the engine's config: default 'auto' = fp16 weight-gradient operands unless R2L_DW_EXACT=1),
+        'fp16' or 'exact' (weight-gradient GEMMs of the fp16 trio on hi + mid operands: fp32-grade dW, ~2x the stash
+        traffic; README.md "Training modes")."""
         self.module = module
         self.ps = point_sampler
         self.eng = get_engine(module)
+        if dw_mode is not None:
+            self.eng.set_config(dw_mode=dw_mode)
         self.lib = self.eng.lib
         self.betas, self.eps, self.lw_rgb = betas, eps, lw_rgb
         self.reducer = GradAllReducer(process_group)

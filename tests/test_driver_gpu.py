@@ -168,7 +168,8 @@ def test_trained_weights_gradient_parity_vs_oracle(trained_student, monkeypatch)
     loss, _, _ = O.r2l_loss_and_grads(sd, emb, b[:, 6:].cpu())
     _, _, g64 = O.r2l_loss_and_grads({k: v.double() for k, v in sd.items()}, emb.double(), b[:, 6:].cpu().double())
     med, worst, tail = {}, {}, {}
-    for fam, env in (("fp16 trio", {}), ("bf16x3 trio", {"R2L_NO_DW2": "1"}), ("fp32 mfma", {"R2L_NO_FWD3": "1"})):
+    for fam, env in (("fp16 trio", {}), ("fp16 trio, exact dW", {"R2L_DW_EXACT": "1"}), ("bf16x3 trio", {"R2L_NO_DW2": "1"}),
+                     ("fp32 mfma", {"R2L_NO_FWD3": "1"})):
         with monkeypatch.context() as mp:
             mp.setenv("R2L_FORCE_VARIANT", "main")
             for k, v in env.items():
@@ -190,6 +191,13 @@ def test_trained_weights_gradient_parity_vs_oracle(trained_student, monkeypatch)
     for fam in med:
         assert med[fam] < 2e-3 and worst[fam] < 5e-2 and tail[fam] < 1e-4, fam
     assert med["fp16 trio"] < 2.5 * max(med["fp32 mfma"], med["bf16x3 trio"])
+    # exact-dW mode (hi + mid operands, three products in the weight-gradient GEMMs).  Measured (profiles/r03_summary.md):
+    # 4.51e-4 against 4.55e-4 for the default trio on these weights — on TRAINED weights the distance to the fp64 truth is the
+    # chain's (mask flips of near-zero pre-activations under the fp16x2 forward / dX chain), not the rounding of the
+    # weight-gradient operands, so exact dW cannot pull the trio to the fp32 families' figure; what it buys shows where the
+    # masks are stable: the strict 2e-5 Adam bar of tests/test_train_gpu.py::test_three_adam_steps_vs_oracle.
+    assert med["fp16 trio, exact dW"] < 1.1 * med["fp16 trio"]
+    assert med["fp16 trio, exact dW"] < 2.5 * max(med["fp32 mfma"], med["bf16x3 trio"])
 
 
 def test_hard_ray_pool_on_gpu(golden_dir):

@@ -12,7 +12,8 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coopf", "coopf2", "main-bf16x3-trio", "main-f32mfma", "coop", "coop16"])
+@pytest.fixture(autouse=True, params=["main", "coopf", "coopf2", "main-exact", "coopf-exact", "main-bf16x3-trio", "main-f32mfma",
+                                      "coop", "coop16"])
 def chain_variant(request, monkeypatch):
     """Every test runs under each kernel family of the training step:
       main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip) and dX chain (r2l_bwd2.hip) stashing
@@ -22,14 +23,19 @@ def chain_variant(request, monkeypatch):
                        default of steps up to 16 384 rays), same stash, same weight-gradient kernels
       coopf2           coopf with two ray tiles per workgroup forced (R2L_COOPF_TILES=2: what launches of more than one tile
                        per CU take)
+      main-exact /     the fp16 trio with EXACT weight gradients (R2L_DW_EXACT=1 = r2l_config.dw_mode R2L_DW_EXACT): the chains
+      coopf-exact      also stash the operands' mid halves and r2l_dw16 / r2l_dw_head16 take three products — held to the
+                       strict bars of the fp32-exact families
       main-bf16x3-trio R2L_NO_FWD2 = R2L_NO_BWD2 = R2L_NO_DW2 = 1 (any one of them would do): the whole step on six bf16
                        products per fp32 product and the chunked fp32 stash — exactly the kernels the guards fall back to
       main-f32mfma     R2L_NO_FWD3=1: everything on the exact-fp32 MFMA
       coop / coop16    the cooperative small-batch families."""
     name = request.param
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name.rstrip("2"))
-    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_COOPF_TILES"):
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name.replace("-exact", "").rstrip("2"))
+    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_COOPF_TILES", "R2L_DW_EXACT"):
         monkeypatch.delenv(k, raising=False)
+    if name.endswith("-exact"):
+        monkeypatch.setenv("R2L_DW_EXACT", "1")
     if name == "coopf2":
         monkeypatch.setenv("R2L_COOPF_TILES", "2")
     if name == "main-f32mfma":
