@@ -167,6 +167,18 @@ int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, const float*
                           float grad_scale, float* dpre, float* gx, float* gt, float* sqerr_partial, float* grads,
                           float* dw_slab, int64_t N, void* stream, int parts, int layer_lo, int layer_hi,
                           const r2l_config* cfg);
+/* A data-parallel host with idle CUs (small per-GPU batches: the cooperative chains occupy one CU per 32 or 64 rays) can cut the
+ * dX chain itself: R2L_BWD_CHAIN with a layer range [layer_lo, layer_hi) that is a proper sub-range of [0, 2 n_block) runs ONE
+ * SEGMENT of the chain — whole blocks, issued from the top (layer_hi = 2 n_block first) down to layer_lo = 0, each on the same
+ * stream — and the weight gradients of a finished segment (R2L_BWD_BODY over the same range, on ANOTHER stream, behind an
+ * event) and their all-reduce run beside the next segment.  Results are bit-identical to the uncut chain.  Only where
+ * r2l_chain_segments_ok_cfg(N, n_block, cfg) says 1, and only together with R2L_BWD_NOFALLBACK on every stage of the step:
+ * the bf16x3 fallback kernels are not launched, so a step whose chain raised the status word (*r2l_backward_status_word != 0
+ * afterwards: range guard, or the forward had fallen back) has NO valid gradient — r2l_adam_step_guarded skips its update on
+ * the device, the host notices later (no sync) and goes back to the uncut form.  r2l_amd/train_step.py is the worked example. */
+#define R2L_BWD_NOFALLBACK 16
+int r2l_chain_segments_ok_cfg(int64_t N, int n_block, const r2l_config* cfg);
+const unsigned* r2l_backward_status_word(const float* wstream_bwd, int n_block);
 
 /* ---- gradient all-reduce for hosts without torch.distributed ----------------------------------------------------------
  * The one exchange of data-parallel training (replaces nn.DataParallel's ReduceAddCoalesced + parameter broadcast,
@@ -186,6 +198,11 @@ int r2l_allreduce_destroy(r2l_comm* comm);
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* ... the same update unless *skip_if != 0 (a device word, e.g. r2l_backward_status_word of a R2L_BWD_NOFALLBACK step, or its
+ * MAX over the ranks): then parameters and moments are left untouched; skip_if == NULL: r2l_adam_step. */
+int r2l_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                          float beta1, float beta2, float eps, int step, float grad_scale, const unsigned* skip_if,
+                          void* stream);
 
 /* out2[0] = inv_denom * sum(sqerr_partial) (= img2mse * lw_rgb, helpers:19), out2[1] = psnr (helpers:20). */
 int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_denom, float* out2, void* stream);

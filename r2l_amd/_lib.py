@@ -68,6 +68,9 @@ SIGNATURES = {
     "r2l_grad_allreduce": (_i, [_p, _p, _l, _p]),
     "r2l_allreduce_destroy": (_i, [_p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
+    "r2l_adam_step_guarded": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p]),
+    "r2l_chain_segments_ok_cfg": (_i, [_l, _i, _cfgp]),
+    "r2l_backward_status_word": (_p, [_p, _i]),
     "r2l_loss_finish": (_i, [_p, _l, _f, _p, _p]),
     "r2l_teacher_param_count": (_l, []),
     "r2l_teacher_stream_floats": (_l, []),
@@ -88,7 +91,7 @@ SIGNATURES = {
 }
 
 # stage bits of r2l_backward_part (include/r2l_hip.h)
-BWD_CHAIN, BWD_BODY, BWD_HEAD, BWD_TAIL, BWD_ALL = 1, 2, 4, 8, 15
+BWD_CHAIN, BWD_BODY, BWD_HEAD, BWD_TAIL, BWD_ALL, BWD_NOFALLBACK = 1, 2, 4, 8, 15, 16
 
 _lib = None
 

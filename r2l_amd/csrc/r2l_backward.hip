@@ -1112,6 +1112,20 @@ extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * D
 extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_TRIO_SLOT(R2L_PAD_ROWS(N)); }
 
 
+// May the dX chain of an N-ray step be cut into block segments (R2L_BWD_CHAIN with a layer range)?  1 when the step takes the
+// cooperative fp16 chains (small launches of the default trio), else 0.
+extern "C" int r2l_chain_segments_ok_cfg(int64_t N, int n_block, const r2l_config* cfg) {
+    R2LCfgScope scope(cfg);
+    return (N > 0 && r2l_chain_variant(N) == R2L_VARIANT_MAIN && r2l_use_fwd3() && r2l_use_trio16() && r2l_use_coopf(N, n_block)) ? 1 : 0;
+}
+// Device word that the fp16 dX chain raises when a step needs the bf16x3 fallback (range guard, or the forward fell back):
+// 0 after a clean step.  A host that runs steps with R2L_BWD_NOFALLBACK hands it to r2l_adam_step_guarded.
+extern "C" const unsigned* r2l_backward_status_word(const float* wstream_bwd, int n_block) {
+    const float* w3 = wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
+    const float* w2 = w3 + r2l_bwd3_stream_floats(n_block);
+    return reinterpret_cast<const unsigned*>(w2 + r2l_bwd2_status_offset(n_block));
+}
+
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                             const float* emb, const float* rgb, const float* target, const float* drgb,
                             const float* save_x, const float* save_t,
@@ -1147,6 +1161,13 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
     if (N <= 0) return 0;
     if (layer_lo < 0) layer_lo = 0;
     if (layer_hi > 2 * n_block) layer_hi = 2 * n_block;
+    // R2L_BWD_CHAIN with a proper sub-range of the layers: ONE SEGMENT of the dX chain (include/r2l_hip.h)
+    const bool chain_seg = (parts & R2L_BWD_CHAIN) && layer_hi > layer_lo && !(layer_lo == 0 && layer_hi == 2 * n_block);
+    const bool no_fallback = (parts & R2L_BWD_NOFALLBACK) != 0;
+    if (chain_seg && ((layer_lo | layer_hi) & 1)) {
+        r2l_set_error_msg("r2l_backward_part: a chain segment covers whole blocks (even layer bounds)");
+        return (int)hipErrorInvalidValue;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     static int n_cu_cached = 0;  // one device type per process
     if (n_cu_cached == 0) {
@@ -1203,22 +1224,34 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         // splits, 3 fp16 products per fp32 product (r2l_bwd2.hip), stashing fp16 stage pieces for r2l_dw16.hip, with the
         // bf16x3 chain behind it as fallback (returns at once unless the status word behind the bwd2 stream was raised: range
         // guard, or the forward already fell back and left an fp32 stash); otherwise the bf16x3 chain (r2l_bwd3.hip)
+        if (chain_seg && !(trio16 && r2l_use_coopf(N, n_block) && no_fallback)) {
+            r2l_set_error_msg("r2l_backward_part: chain segments need the cooperative fp16 chains (r2l_chain_segments_ok_cfg) and "
+                              "R2L_BWD_NOFALLBACK");
+            return (int)hipErrorInvalidValue;
+        }
         if (trio16) {
-            R2L_CHECK(hipMemsetAsync(bwd_status, 0, 64, stream));
-            if (scale_dev != nullptr) {
-                hipLaunchKernelGGL(r2l_gscale_kernel, dim3(1), dim3(1024), 0, stream, drgb, 3 * N, const_cast<float*>(scale_dev));
-                R2L_CHECK(hipGetLastError());
+            if (!chain_seg || layer_hi == 2 * n_block) {  // (the first segment opens the step)
+                R2L_CHECK(hipMemsetAsync(bwd_status, 0, 64, stream));
+                if (scale_dev != nullptr) {
+                    hipLaunchKernelGGL(r2l_gscale_kernel, dim3(1), dim3(1024), 0, stream, drgb, 3 * N, const_cast<float*>(scale_dev));
+                    R2L_CHECK(hipGetLastError());
+                }
             }
             const int rc2 = r2l_bwd2_backward(rgb, target, drgb, save_x, save_t, w2, params, n_block, grad_scale, dpre, gx, gt,
-                                              sqerr_partial, N, stream, gscale, bwd_status, scale_dev);
+                                              sqerr_partial, N, stream, gscale, bwd_status, scale_dev,
+                                              chain_seg ? layer_hi / 2 - 1 : -1, chain_seg ? layer_lo / 2 : 0);
             if (rc2) return rc2;
-            // the fallback's stream is packed in front of it, and only when it will run
-            const int rp = r2l_bwd3_pack(params, n_block, const_cast<float*>(w3), stream, bwd_status);
-            if (rp) return rp;
+            if (!no_fallback) {
+                // the fallback's stream is packed in front of it, and only when it will run
+                const int rp = r2l_bwd3_pack(params, n_block, const_cast<float*>(w3), stream, bwd_status);
+                if (rp) return rp;
+            }
         }
-        const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t, w3, params, n_block, grad_scale, dpre, gx, gt,
-                                         sqerr_partial, N, stream, gscale, trio16 ? bwd_status : nullptr, scale_dev);
-        if (rc) return rc;
+        if (!(trio16 && no_fallback)) {
+            const int rc = r2l_bwd3_backward(rgb, target, drgb, save_x, save_t, w3, params, n_block, grad_scale, dpre, gx, gt,
+                                             sqerr_partial, N, stream, gscale, trio16 ? bwd_status : nullptr, scale_dev);
+            if (rc) return rc;
+        }
     } else {
         R2LBwdArgs a{};
         a.rgb = rgb; a.target = target; a.drgb = drgb; a.save_x = save_x; a.save_t = save_t; a.wstream = wstream_bwd;
@@ -1264,7 +1297,7 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             a.mid_off = 0u;
             if (rc) return rc;
             a.run_if = bwd_status;
-            hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
+            if (!no_fallback) hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         } else if (split) {
             hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);
         }
@@ -1309,7 +1342,8 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             a.run_unless = nullptr;
             a.run_if = bwd_status;
         }
-        if (emb != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<true, false>), hg, hb, 0, stream, a);
+        if (trio16 && emb == nullptr && no_fallback) {
+        } else if (emb != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<true, false>), hg, hb, 0, stream, a);
         else if (t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<false, true>), hg, hb, 0, stream, a);
         else hipLaunchKernelGGL((r2l_dw_head_kernel<false, false>), hg, hb, 0, stream, a);
         R2L_CHECK(hipGetLastError());

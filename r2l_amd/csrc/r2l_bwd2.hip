@@ -285,10 +285,14 @@ int r2l_bwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t
 int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
-                      const float* scale_dev) {
+                      const float* scale_dev, int b_start, int b_end) {
     if (r2l_use_coopf(N, n_block))  // small launches: the cooperative chain (r2l_coopf_bwd.hip), same stream / stash / status word
         return r2l_coopf_backward(rgb, target, drgb, save_x, save_t, wstream_bwd2, params, n_block, grad_scale, dpre, gx, gt,
-                                  sqerr_partial, N, stream, gscale, status, scale_dev);
+                                  sqerr_partial, N, stream, gscale, status, scale_dev, b_start, b_end);
+    if (b_start >= 0 && !(b_start == n_block - 1 && b_end == 0)) {
+        r2l_set_error_msg("r2l_bwd2_backward: only the cooperative chains can be cut into block ranges");
+        return (int)hipErrorInvalidValue;
+    }
     B2Args a{};
     a.status = status;
     a.scale_dev = scale_dev;

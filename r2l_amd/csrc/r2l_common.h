@@ -404,7 +404,7 @@ int r2l_bwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t
 int r2l_bwd2_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
-                      const float* scale_dev = nullptr);
+                      const float* scale_dev = nullptr, int b_start = -1, int b_end = 0);
 // forward launches (with or without the training stash) big enough for the one-wave-per-tile kernels take the bf16x3
 // kernel (R2L_NO_FWD3=1: fp32 MFMA)
 // pose mode: the camera of ray rc and its pixel index.  One pose by value (c2w), or — one launch over several frames

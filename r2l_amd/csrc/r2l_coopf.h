@@ -255,4 +255,4 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
 int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                        const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                        float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
-                       const float* scale_dev);
+                       const float* scale_dev, int b_start = -1, int b_end = 0);  // blocks b_start (-1: the last) down to b_end

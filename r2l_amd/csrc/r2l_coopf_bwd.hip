@@ -29,7 +29,14 @@ struct CfBwdArgs {
     float* gx;
     float* gt;
     float* sqerr_partial;
-    int64_t N;    int64_t mid_units;  // != 0: mid quads stashed this many 16-byte units behind the hi pieces (exact weight gradients)
+    int64_t N;
+    int64_t mid_units;  // != 0: mid quads stashed this many 16-byte units behind the hi pieces (exact weight gradients)
+    // One launch walks the blocks b_start, b_start - 1, .., b_end (whole chain: n_block - 1 .. 0).  A data-parallel host may cut
+    // the chain into several launches (r2l_backward_part: R2L_BWD_CHAIN with a layer range) so that the weight gradients — and
+    // the gradient exchange — of the blocks already walked run beside the rest of the chain on the CUs a small launch leaves
+    // idle: g then crosses the launch boundary as fp32 fragments in the tile's row-major area of gx slot 0 (which only the
+    // last launch finally fills), every other value takes the path it takes in one launch: results are bit-identical.
+    int b_start, b_end;
 };
 
 // masked u: bit tt*16 + c of the forward's mask word of this wave
@@ -62,6 +69,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     const int64_t Np = R2L_PAD_ROWS(a.N);
     const int64_t slot = R2L_TRIO_SLOT(Np);
     const float* tw = a.params + cb_off_tail_w(a.n_block);
+    const bool first = a.b_start == a.n_block - 1, final = a.b_end == 0;
 
     // ---- loss gradient through the sigmoid, per-tile squared error (every wave computes it; wave 0 writes) -------------------
     float dp[NT][3];
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
             dp[rt][c] = valid ? dl * (r * (1.0f - r)) : 0.f;
         }
         if (!valid) se = 0.f;
-        if (wave == 0) {
+        if (wave == 0 && first) {
             if (valid && h == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) a.dpre[ray * 3 + c] = dp[rt][c];
@@ -113,17 +121,32 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
         }
     };
     f32x16 g[NT][2], u[NT][2];
+    // this lane's 32 fragment values of a tile where they cross a launch boundary (gx slot 0, the tile's 32 KiB)
+    auto carry_at = [&](int rt) { return a.gx + tile[rt] * (R2L_TILE_RAYS * R2L_W) + (wave * 64 + lane) * 32; };
+    if (first) {
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt)
+        for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-                tail_t(rt, tt, q, v);
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+                    tail_t(rt, tt, q, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[rt][tt][4 * q + e] = v[e];
-            }
+                    for (int e = 0; e < 4; ++e) g[rt][tt][4 * q + e] = v[e];
+                }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(carry_at(rt) + 16 * tt + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[rt][tt][4 * q + e] = v[e];
+                }
+    }
 
     constexpr int R = FcRingOf<NT>::value;
     FcRing<R> W;
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
         P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         P.voff = (unsigned)lane * 16u + (unsigned)wave * 2048u;
-        P.g = 0u;
+        P.g = (unsigned)(a.n_block - 1 - a.b_start) * 34u;  // 34 stages per block: [zero, 16 of W2^T, zero, 16 of W1^T]
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) fc_issue(W.a[k], P);
@@ -153,9 +176,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
         const int64_t unit0 = tile[rt] * R2L_H16_TILE_UNITS + lane + 256 * wave;
-        gxh[rt] = reinterpret_cast<u32x4*>(a.gx + (int64_t)a.n_block * slot) + unit0;  // slot b + 1 of block b = n_block - 1
-        gth[rt] = reinterpret_cast<u32x4*>(a.gt + (int64_t)(a.n_block - 1) * slot) + unit0;
-        mwp[rt] = reinterpret_cast<const unsigned*>(a.save_t + (int64_t)(a.n_block - 1) * slot + R2L_MASK_OFFSET(Np) +
+        gxh[rt] = reinterpret_cast<u32x4*>(a.gx + (int64_t)(a.b_start + 1) * slot) + unit0;  // slot b + 1 of block b = b_start
+        gth[rt] = reinterpret_cast<u32x4*>(a.gt + (int64_t)a.b_start * slot) + unit0;
+        mwp[rt] = reinterpret_cast<const unsigned*>(a.save_t + (int64_t)a.b_start * slot + R2L_MASK_OFFSET(Np) +
                                                     tile[rt] * 256 + lane * 4) + wave;
     }
 
@@ -195,19 +218,31 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     };
     // the k-th block of the walk starts in phase 2 k mod R: unrolled over R / 2 blocks
 #pragma unroll 1
-    for (int b = a.n_block - 1; b >= 0; b -= R / 2) {
-        block(std::integral_constant<int, 0>{}, b == 0);
+    for (int b = a.b_start; b >= a.b_end; b -= R / 2) {
+        block(std::integral_constant<int, 0>{}, b == a.b_end);
         if constexpr (R >= 4) {
-            if (b - 1 >= 0) block(std::integral_constant<int, 2 % R>{}, b - 1 == 0);
+            if (b - 1 >= a.b_end) block(std::integral_constant<int, 2 % R>{}, b - 1 == a.b_end);
         }
         if constexpr (R >= 8) {
-            if (b - 2 >= 0) block(std::integral_constant<int, 4 % R>{}, b - 2 == 0);
-            if (b - 3 >= 0) block(std::integral_constant<int, 6 % R>{}, b - 3 == 0);
+            if (b - 2 >= a.b_end) block(std::integral_constant<int, 4 % R>{}, b - 2 == a.b_end);
+            if (b - 3 >= a.b_end) block(std::integral_constant<int, 6 % R>{}, b - 3 == a.b_end);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+
+    if (!final) {  // the chain continues in the next launch
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(carry_at(rt) + 16 * tt + 4 * q) =
+                        f32x4{g[rt][tt][4 * q], g[rt][tt][4 * q + 1], g[rt][tt][4 * q + 2], g[rt][tt][4 * q + 3]};
+        return;
+    }
 
     // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0], row-major fp32 (the head weight gradient reads rows) -----
     // (dy recomputed: the same operations on the same values as the chain's seed)
@@ -240,8 +275,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
 int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                        const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                        float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
-                       const float* scale_dev) {
+                       const float* scale_dev, int b_start, int b_end) {
     CfBwdArgs a{};
+    a.b_start = b_start < 0 ? n_block - 1 : b_start;
+    a.b_end = b_end;
     a.status = status;
     a.scale_dev = scale_dev;
     a.fmt = reinterpret_cast<const unsigned*>(save_x) + R2L_STASH_FMT_WORD(n_block, R2L_PAD_ROWS(N));

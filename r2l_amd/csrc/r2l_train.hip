@@ -6,7 +6,8 @@
 
 __global__ void r2l_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
-                                float sqrt_bc2, float gscale) {
+                                float sqrt_bc2, float gscale, const unsigned* __restrict__ skip_if) {
+    if (skip_if != nullptr && __builtin_nontemporal_load(skip_if) != 0u) return;  // (r2l_adam_step_guarded)
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -22,11 +23,16 @@ __global__ void r2l_adam_kernel(float* __restrict__ p, const float* __restrict__
 
 extern "C" int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                              float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    return r2l_adam_step_guarded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, nullptr, stream);
+}
+extern "C" int r2l_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                     float beta1, float beta2, float eps, int step, float grad_scale, const unsigned* skip_if,
+                                     void* stream) {
     if (n <= 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(r2l_adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale, skip_if);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -76,11 +76,11 @@ class GradAllReducer:
         return handles
 
     # ---- overlapped form: submit finished buckets as the backward produces them ------------------------------------------
-    def submit(self, bucket):
+    def submit(self, bucket, op=None):
         """Start the all-reduce of a finished, contiguous range of the flat gradient (a view).  The kernels that wrote
-        it must already be enqueued on the current stream."""
+        it must already be enqueued on the current stream.  (op: SUM; MAX for the step-validity word of segmented steps.)"""
         if self.world() > 1:
-            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._works.append(dist.all_reduce(bucket, op=op or dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def pending(self):
         return len(self._works)

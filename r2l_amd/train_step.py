@@ -30,7 +30,8 @@ class R2LTrainer:
     nn.DataParallel computed on GPU 0.
     """
 
-    def __init__(self, module, point_sampler, betas=(0.9, 0.999), eps=1e-8, lw_rgb=1.0, process_group=None, dw_mode=None):
+    def __init__(self, module, point_sampler, betas=(0.9, 0.999), eps=1e-8, lw_rgb=1.0, process_group=None, dw_mode=None,
+                 chain_segments=None):
         """dw_mode: None (keep the engine's config: default 'auto' = fp16 weight-gradient operands unless R2L_DW_EXACT=1),
         'fp16' or 'exact' (weight-gradient GEMMs of the fp16 trio on hi + mid operands: fp32-grade dW, ~2x the stash
         traffic; README.md "Training modes")."""
@@ -46,6 +47,24 @@ class R2LTrainer:
         # kernels of the next bucket run; R2L_AR_BUCKETS=0 selects one blocking all-reduce after the whole backward
         self.n_buckets = int(os.environ.get("R2L_AR_BUCKETS", "4"))
         self.force_staged = False  # tests: run the staged backward on one GPU (nothing is submitted at world == 1)
+        # Small steps (the cooperative chains leave CUs idle): the dX chain itself cut into `chain_segments` block segments,
+        # the weight gradients of a finished segment — and their all-reduce — on a second stream beside the next segment
+        # (include/r2l_hip.h R2L_BWD_CHAIN with a layer range).  Such steps run WITHOUT the bf16x3 fallback kernels: a step
+        # whose chain raised the range-guard word is skipped on the device (r2l_adam_step_guarded, on every rank: MAX over
+        # ranks), noticed here one step later without a host sync, and the trainer goes back to the uncut form for good.
+        # Gradients are bit-identical to the staged form.  On one GPU it only adds launches (4096 rays: 0.78 ms one call, 0.85
+        # in 3 segments, 0.96 staged in 4 buckets; profiles/r03_staged_backward.txt), so the default is 1 (off) there and 3 at
+        # world > 1, where it replaces the staged form for the steps it applies to (argument, or R2L_CHAIN_SEGMENTS=n;
+        # unmeasured on more than one GPU).
+        default = "3" if self.reducer.world() > 1 and self.n_buckets > 0 else "1"
+        self.chain_segments = int(os.environ.get("R2L_CHAIN_SEGMENTS", default)) if chain_segments is None else int(chain_segments)
+        self.segments_disabled = False
+        self.skipped_steps = 0
+        self._side = None
+        self._status_dev = None
+        self._status_host = None
+        self._status_event = None
+        self._guard = None  # device word handed to the guarded Adam of the current step, or None
         if self.reducer.world() > 1 and self.n_buckets > 0 and self.eng.cfg.reserve_cus == 0:
             # the weight-gradient kernels are persistent workgroups that fill every CU: leave a few to the RCCL kernels that
             # run beside them (r2l_config.reserve_cus of this trainer's calls; R2L_RESERVE_CUS overrides the count)
@@ -126,7 +145,12 @@ class R2LTrainer:
                 _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat), eng.n_block, grad_scale,
                 _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt), _ptr(self.sqerr), _ptr(self.grads), _ptr(self.dw_slab), n,
                 _stream())
-        if (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
+        self._guard = None
+        self._check_skipped()
+        if (self.chain_segments > 1 and zero_grad and not self.segments_disabled and
+                self.lib.r2l_chain_segments_ok_cfg(int(n), eng.n_block, eng._cfg())):
+            self._segmented_backward(args)
+        elif (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
             # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
             # blocks to the first, the head last; every finished range of the flat gradient goes to the collective at once
             part, cfg = self.lib.r2l_backward_part_cfg, eng._cfg()
@@ -144,6 +168,56 @@ class R2LTrainer:
                                      _ptr(self.loss_out), _stream()), "r2l_loss_finish")
         return rgb
 
+    # ---- segmented dX chain (small steps) -----------------------------------------------------------------------------------
+    def _segmented_backward(self, args):
+        eng, part, cfg, NF = self.eng, self.lib.r2l_backward_part_cfg, self.eng._cfg(), _lib.BWD_NOFALLBACK
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=eng.device)
+            self._status_dev = torch.zeros(1, dtype=torch.int32, device=eng.device)
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            word = ctypes.cast(self.lib.r2l_backward_status_word(_ptr(self.wstream_bwd), eng.n_block), ctypes.c_void_p).value
+            off = (word - self.wstream_bwd.data_ptr()) // 4
+            self._status_src = self.wstream_bwd[off:off + 1].view(torch.int32)  # the chain's range-guard word
+        side = self._side
+        side_args = args[:-1] + (ctypes.c_void_p(side.cuda_stream),)
+        plan = bucket_plan(eng.n_block, self.chain_segments)
+        first = True
+        for lo, hi, flat_lo, flat_hi in plan:
+            if flat_lo == 0 or hi <= lo:
+                continue
+            what = _lib.BWD_CHAIN | NF | (_lib.BWD_TAIL if first else 0)
+            _lib.check(part(*args, what, lo, hi, cfg), "r2l_backward_part(chain segment %d..%d)" % (lo, hi))
+            first = False
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                _lib.check(part(*side_args, _lib.BWD_BODY | NF, lo, hi, cfg), "r2l_backward_part(body %d..%d)" % (lo, hi))
+                self.reducer.submit(self.grads[flat_lo:flat_hi])
+        with torch.cuda.stream(side):  # the head needs gx[0] of the last segment (already waited for) and shares dw_slab with the body
+            _lib.check(part(*side_args, _lib.BWD_HEAD | NF, 0, 0, cfg), "r2l_backward_part(head)")
+            self.reducer.submit(self.grads[0:bucket_plan(eng.n_block, 1)[-1][3]])
+            self._status_dev.copy_(self._status_src)  # valid step? (0) — the same answer on every rank: MAX
+            self.reducer.submit(self._status_dev, op=dist.ReduceOp.MAX)
+            done = torch.cuda.Event()
+            done.record(side)
+        main.wait_event(done)
+        self._guard = self._status_dev
+
+    def _check_skipped(self):
+        """Did an earlier segmented step turn out invalid (its update was skipped on the device)?  Looks at a word copied to
+        pinned memory behind that step's Adam; never waits for the GPU."""
+        if self._status_event is not None and self._status_event.query():
+            self._status_event = None
+            if int(self._status_host[0]) != 0:
+                self.skipped_steps += 1
+                self.segments_disabled = True
+                import logging
+                logging.getLogger("r2l_amd").warning(
+                    "a segmented training step needed the bf16x3 fallback (fp16 range guard): its update was skipped on every "
+                    "rank; continuing with the uncut backward (chain_segments off)")
+
     def world(self):
         return self.reducer.world()
 
@@ -159,9 +233,14 @@ class R2LTrainer:
         self.step_count += 1
         eng = self.eng
         _lib.check(
-            self.lib.r2l_adam_step(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                   eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
-                                   self.reducer.grad_scale(), _stream()), "r2l_adam_step")
+            self.lib.r2l_adam_step_guarded(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                           eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                           self.reducer.grad_scale(), _ptr(self._guard), _stream()), "r2l_adam_step")
+        if self._guard is not None:  # segmented step: its validity word goes to the host behind the update (checked next step)
+            self._status_host.copy_(self._guard, non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+            self._guard = None
         eng.mark_dirty()
 
     def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None, n_global=None):

@@ -52,7 +52,12 @@ for step in (1, 2, 3):
     for k in ref:
         ref[k], mo[k], vo[k] = O.adam_step(ref[k], gr[k], mo[k], vo[k], step, lr)
     tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda(), n_global=n if uneven else None)
-    assert tr.reducer.pending() == len(bucket_plan(nb, tr.n_buckets)) == 4   # 3 body buckets (one per block) + the head, in flight until Adam needs them
+    if variant == "coopf":
+        # small steps of the default trio at world > 1: the dX chain in 3 segments, each segment's weight gradients and
+        # all-reduce on a second stream beside the next segment; + the head bucket + the step-validity word (MAX)
+        assert tr.chain_segments == 3 and tr._guard is not None and tr.reducer.pending() == 3 + 1 + 1
+    else:
+        assert tr.reducer.pending() == len(bucket_plan(nb, tr.n_buckets)) == 4   # 3 body buckets (one per block) + the head, in flight until Adam needs them
     tr.allreduce_grads()
     assert tr.reducer.pending() == 0
     tr.adam(lr)
@@ -61,6 +66,7 @@ for step in (1, 2, 3):
     dist.all_reduce(lo)
     assert abs(lo.item() - loss.item()) < 2e-6, (step, lo.item(), loss.item())
     assert parameters_in_sync(tr.eng.flat), step
+assert tr.skipped_steps == 0 and not tr.segments_disabled
 new = m.state_dict()
 worst, cos = 0., 1.
 for k in ref:

@@ -269,6 +269,87 @@ def test_staged_backward_equals_single_call(n, buckets, monkeypatch):
         assert torch.equal(staged, tr.grads)  # and the staged form is bit-reproducible run to run as well
 
 
+@pytest.mark.parametrize("n", [4096, 12288 - 5])
+def test_segmented_chain_equals_uncut(chain_variant, n, monkeypatch):
+    """The dX chain of a small step cut into block segments (R2L_BWD_CHAIN with a layer range; weight gradients of a finished
+    segment on a second stream beside the next segment, R2L_BWD_NOFALLBACK, guarded Adam): the chain's outputs — gx[0], the
+    stash the weight-gradient kernels read, loss — are BIT-IDENTICAL to the uncut chain, hence the gradients equal the staged
+    form with the same buckets bit for bit, and the one-call form up to the summation order of per-workgroup partials; three
+    Adam steps end on the same parameters bit for bit; one tile (4096 rays) and two tiles (12 283) per workgroup."""
+    if chain_variant not in ("coopf", "coopf-exact"):
+        pytest.skip("segments are a property of the cooperative fp16 chains")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd import _lib
+    from r2l_amd.train_step import R2LTrainer, lr_schedule
+    monkeypatch.delenv("R2L_FORCE_VARIANT")  # the default dispatch takes these sizes to the cooperative chains by itself
+    sd = O.make_state_dict(n_block=43, seed=3)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    g = torch.Generator().manual_seed(n)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+    u = torch.rand(n, 16, generator=g).cuda()
+
+    def run(segments, staged):
+        m = build_model(sd, 43)
+        tr = R2LTrainer(m, ps, chain_segments=segments)
+        assert tr.lib.r2l_chain_segments_ok_cfg(n, 43, tr.eng._cfg()) == 1
+        tr.force_staged, tr.n_buckets = staged, 4
+        tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+        g1, gx0, l1 = tr.grads.clone(), tr.gx[:tr.lib.r2l_padded_rows(n) * 256].clone(), tr.loss_out.clone()
+        for i in range(3):
+            tr.step(o, d, tgt, lr_schedule(i + 1, 5e-4, 500, "0.0001,200"), perturb=1., t_rand=u)
+        torch.cuda.synchronize()
+        assert tr.skipped_steps == 0 and not tr.segments_disabled
+        return g1, gx0, l1, tr.eng.flat.clone()
+
+    one = run(1, False)
+    staged = run(1, True)
+    seg = run(4, False)
+    assert torch.equal(seg[1], one[1]) and torch.equal(seg[2], one[2])  # gx[0] (end of the chain), loss
+    assert torch.equal(seg[0], staged[0]) and torch.equal(seg[3], staged[3])  # same buckets: same partial sums, same order
+    a, b = split_flat(one[0].cpu(), sd), split_flat(seg[0].cpu(), sd)
+    for k in sd:
+        assert rel_err(b[k], a[k]) < 1e-5, k
+
+
+def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, monkeypatch):
+    """A segmented step runs without the bf16x3 fallback kernels: when the step belongs to them (here: a head scaled until
+    |x_0| ~ 1e5 leaves fp16's range, so the forward falls back and every chain segment raises the status word) the update is
+    skipped ON THE DEVICE — parameters and Adam moments untouched —, the trainer notices one step later without a host sync
+    and goes back to the uncut backward, whose fallback handles the same batch."""
+    if chain_variant != "coopf":
+        pytest.skip("one comparison")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    sd = {k: v.clone() for k, v in O.make_state_dict(n_block=3, seed=4).items()}
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    n = 4096
+    g = torch.Generator().manual_seed(1)
+    o = (torch.randn(n, 3, generator=g) * 1.5).cuda()
+    d = torch.randn(n, 3, generator=g).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+    tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    tr.step(o, d, tgt, 1e-4)
+    torch.cuda.synchronize()
+    assert not torch.equal(tr.eng.flat.cpu(), torch.cat([v.reshape(-1) for v in sd.values()]))  # a clean segmented step updates
+    assert tr.skipped_steps == 0
+    sd["head.0.weight"] *= 3.0e4
+    sd["head.0.bias"] *= 3.0e4
+    for k in sd:
+        if k.startswith("tail."):
+            sd[k] = sd[k] * 1.0e-5
+    tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    p0, m0 = tr.eng.flat.clone(), tr.exp_avg.clone()
+    tr.step(o, d, tgt, 1e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.eng.flat, p0) and torch.equal(tr.exp_avg, m0)  # skipped on the device
+    tr.step(o, d, tgt, 1e-4)  # the trainer has seen the word by now: this one runs uncut, with the fallback kernels
+    torch.cuda.synchronize()
+    assert tr.skipped_steps == 1 and tr.segments_disabled
+    assert not torch.equal(tr.eng.flat, p0) and torch.isfinite(tr.eng.flat).all()
+
+
 def test_generic_mode_backward_after_forward_rays():
     """C-ABI generic mode: r2l_forward_rays (with stash) followed by r2l_backward(target = NULL, drgb = caller's dL/drgb).  On
     the default trio the stash is fp16 and the dX chain needs a power-of-two scale it cannot derive from an MSE scale: it is

@@ -13,16 +13,20 @@ def main():
     dev = torch.device("cuda", 0)
     net, ps, _ = bench.make_model(dev)
     from r2l_amd.train_step import R2LTrainer, lr_schedule
-    for n in (98304, 12288):
+    for n in (98304, 12288, 4096):
         g = torch.Generator().manual_seed(1)
         o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(dev)
         d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
         tgt = torch.rand(n, 3, generator=g).to(dev)
         tr = R2LTrainer(net, ps)
-        for label, staged, buckets, reserve in (("one call", False, 4, None), ("staged, 4 buckets", True, 4, None),
-                                                ("staged, 4 buckets, 8 CUs reserved", True, 4, "8"),
-                                                ("staged, 8 buckets, 8 CUs reserved", True, 8, "8")):
-            tr.force_staged, tr.n_buckets = staged, buckets
+        cases = [("one call", False, 4, None, 1), ("staged, 4 buckets", True, 4, None, 1),
+                 ("staged, 4 buckets, 8 CUs reserved", True, 4, "8", 1), ("staged, 8 buckets, 8 CUs reserved", True, 8, "8", 1)]
+        if tr.lib.r2l_chain_segments_ok_cfg(n, tr.eng.n_block, tr.eng._cfg()):
+            # the dX chain itself cut into segments, weight gradients of a finished segment on a second stream beside the next
+            cases += [("chain in %d segments, dW beside it" % k, False, 4, None, k) for k in (2, 3, 4, 6)]
+            cases += [("chain in 4 segments, 8 CUs reserved", False, 4, "8", 4)]
+        for label, staged, buckets, reserve, segments in cases:
+            tr.force_staged, tr.n_buckets, tr.chain_segments = staged, buckets, segments
             if reserve:
                 os.environ["R2L_RESERVE_CUS"] = reserve
             else:
