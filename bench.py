@@ -7,10 +7,12 @@ N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (the dri
 started bare it launches the N ranks itself (plan_launch) — and exits non-zero rather than run on fewer GPUs than
 --gpus says.  The printed line carries n_gpus and rccl_ranks (the latter measured by an all-reduce).
 
-Workload (config.workload): BASELINE.json configs[1] — render 400x400 frames (160 000 rays each, 16 samples/ray,
-L=10, W256 D88, seeded weights, synthetic pose_spherical poses).  One "step" = one frame per GPU through the fused
-HIP forward (ray sampling + positional encoding + 88-layer ResMLP + RGB head).  Inputs (pose, weights) are resident
-before the timed region.  Frames shard across ranks with no collective -> "scaling": "weak".
+Workload (config.workload): BASELINE.json configs[1] — render 400x400 test frames (160 000 rays each, 16 samples/ray,
+L=10, W256 D88, seeded weights, synthetic pose_spherical poses).  One "step" = ONE LAUNCH of the fused HIP forward (ray
+sampling + positional encoding + 88-layer ResMLP + RGB head) = FRAMES_PER_STEP (9) test frames per GPU, the way
+driver.render_path walks the 200 test poses (r2l_forward_poses_cfg: 9 x 1250 workgroups = 43.95 rounds of the 256 CUs, no
+launch gap and no partly filled last round per frame).  Inputs (poses, weights) are resident before the timed region.  Frames
+shard across ranks with no collective -> "scaling": "weak".
 The same JSON line carries a "train" object (distillation step: forward + backward + Adam; at N > 1 the bucketed RCCL
 all-reduce of the flat gradient overlapped with the weight-gradient stages), "train_strong" (N > 1: the single-GPU batch
 split over the ranks), "train_4096" and "teacher", timed by the same barrier-bracketed recipe.
@@ -34,6 +36,7 @@ PEAK_FP32_MFMA = 157.3  # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md chip t
 PEAK_BF16_MFMA = 2500.0  # TFLOP/s dense bf16 MFMA (same guide; the sparsity-inflated headline figure is not used)
 H = W = 400
 FOCAL = 555.5555155968841
+FRAMES_PER_STEP = 9  # driver.POSES_PER_LAUNCH: test frames per render launch
 
 
 def make_model(device):
@@ -58,6 +61,22 @@ def barrier_sync(distributed):
     torch.cuda.synchronize()
 
 
+LEG_WALL = {}  # leg name -> host wall seconds incl. warm-up and set-up (so that the driver's clock can be reconciled leg by leg)
+
+
+class leg_clock:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        LEG_WALL[self.name] = LEG_WALL.get(self.name, 0.) + time.perf_counter() - self.t0
+
+
 def timed(fn, steps, warmup, distributed, device):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.
     Also returns the mean device time per step from HIP events recorded on the launch stream."""
@@ -80,7 +99,7 @@ def timed(fn, steps, warmup, distributed, device):
     return dt, kernel_ms
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, grid_threads=None):
     """HBM-side bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary (profiles/
     rNN_bench_pmc_summary.json, made by tools/profile_gpu.sh in separate counter passes): FETCH_SIZE x 2 (gfx950 tallies
     the 128-B requests of 16 B/lane loads at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both reported in KiB.
@@ -93,14 +112,19 @@ def pmc_traffic(kernel_prefix):
         return None, None
     with open(files[-1]) as f:
         table = _json.load(f)
-    for name, c in table.items():
-        if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2. * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024., os.path.relpath(files[-1], os.path.dirname(root))
+    hits = [(name, c) for name, c in table.items()
+            if name.startswith(kernel_prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+    if grid_threads is not None:  # the launch of THIS workload (the summary keys end in " grid=<work-items>")
+        hits = [h for h in hits if h[0].endswith(" grid=%d" % grid_threads)] or []
+    for name, c in hits:
+        return (2. * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024., os.path.relpath(files[-1], os.path.dirname(root))
     return None, None
 
 
 def cpu_baseline(sd, n_rays=32768):
-    """The oracle (CPU restatement of the reference op sequence) timed on the host cores: reported, not a target.
+    """The oracle (CPU restatement of the reference op sequence) timed on the host cores: reported, not a target
+    (SURVEY.md §8d / BASELINE.md §3: forward at 4096 / 32 768 rays / one frame, training step at 4096 rays, medians of 5,
+    one training step with autograd anomaly mode on as the reference runs it, model/nerf_raybased.py:4).
     torch's intra-op pool scales badly past a few dozen threads on these 256x256 GEMMs (measured on the EPYC 9575F box:
     16 threads 32.6 k rays/s, 64 threads 12.5 k, 256 threads 0.4 k), so a few thread counts are tried and the best kept."""
     from oracle import r2l_oracle as Or
@@ -111,18 +135,32 @@ def cpu_baseline(sd, n_rays=32768):
     rows = torch.randperm(H * W, generator=g)[:n_rays]
     ncpu = os.cpu_count() or 1
     best, best_threads, rgb = None, 1, None
+
+    def fwd(idx):
+        t0 = time.perf_counter()
+        pts = Or.sample_test(dirs, z, c2w)
+        out = Or.r2l_forward(sd, Or.positional_embed(pts if idx is None else pts[idx], 10))
+        return time.perf_counter() - t0, out
+
     with torch.no_grad():
         for nt in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)}):
             torch.set_num_threads(nt)
-            Or.r2l_forward(sd, Or.positional_embed(Or.sample_test(dirs, z, c2w)[rows[:2048]], 10))  # warm-up
-            t0 = time.perf_counter()
-            pts = Or.sample_test(dirs, z, c2w)[rows]
-            rgb = Or.r2l_forward(sd, Or.positional_embed(pts, 10))
-            dt = time.perf_counter() - t0
+            fwd(rows[:2048])  # warm-up
+            dt, _ = fwd(rows)
             if best is None or dt < best:
                 best, best_threads = dt, nt
+        torch.set_num_threads(best_threads)
+        med = {}
+        for name, idx in (("4096", rows[:4096]), ("32768", rows)):
+            ts = []
+            for _ in range(5):
+                dt, out = fwd(idx)
+                ts.append(dt)
+            med[name] = sorted(ts)[2]
+            if name == "32768":
+                rgb = out
+        t_frame, _ = fwd(None)  # the whole 400x400 frame, once
     # training step on the host: sample_train + encode + forward + autograd backward + Adam, N = 4096
-    torch.set_num_threads(best_threads)
     n_tr = 4096
     o = torch.randn(n_tr, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])
     d = torch.nn.functional.normalize(torch.randn(n_tr, 3, generator=g), dim=-1)
@@ -130,15 +168,19 @@ def cpu_baseline(sd, n_rays=32768):
     p = {k: v.clone() for k, v in sd.items()}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v2 = {k: torch.zeros_like(v) for k, v in p.items()}
-    times = []
-    for it in range(1, 5):
+
+    def train_once(it):
         t0 = time.perf_counter()
         emb = Or.positional_embed(Or.sample_train(o, d, z, 1.0, t_rand=torch.rand(n_tr, 16, generator=g)), 10)
         grads = Or.r2l_loss_and_grads(p, emb, tgt)[2]
         for k in p:
             p[k], m[k], v2[k] = Or.adam_step(p[k], grads[k], m[k], v2[k], it, 5e-4)
-        times.append(time.perf_counter() - t0)
-    train_s = sorted(times[1:])[1]  # median of 3 after one warm-up
+        return time.perf_counter() - t0
+
+    times = [train_once(it) for it in range(1, 7)]
+    train_s = sorted(times[1:])[2]  # median of 5 after one warm-up
+    with torch.autograd.set_detect_anomaly(True):  # the reference's setting (model/nerf_raybased.py:4)
+        train_anomaly_s = train_once(7)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -148,11 +190,15 @@ def cpu_baseline(sd, n_rays=32768):
                     break
     except OSError:
         pass
-    return {"value": n_rays / best, "unit": "rays/s", "cores": best_threads, "kind": "port",
+    return {"value": n_rays / med["32768"], "unit": "rays/s", "cores": best_threads, "kind": "port",
+            "forward": {"rays_4096": 4096 / med["4096"], "rays_32768": n_rays / med["32768"], "frame_160000": H * W / t_frame,
+                        "unit": "rays/s", "sample": "medians of 5 (4096, 32 768 rays); one run of the whole 400x400 frame"},
             "train": {"value": n_tr / train_s, "unit": "rays/s", "rays_per_step": n_tr, "cores": best_threads,
-                      "sample": "median of 3 oracle training steps (sample + encode + fwd + autograd bwd + Adam)"},
-            "sample": "%d rays of one 400x400 frame: sample + encode + W256D88 forward, fp32 torch CPU ops, best of "
-                      "{16,32,64} threads on %d logical CPUs; %s" % (n_rays, ncpu, cpu_model)}, rgb, rows
+                      "anomaly_mode_on": n_tr / train_anomaly_s,
+                      "sample": "median of 5 oracle training steps (sample + encode + fwd + autograd bwd + Adam); one more step "
+                                "with torch.autograd.set_detect_anomaly(True), the reference's setting"},
+            "sample": "%d rays of one 400x400 frame: sample + encode + W256D88 forward, fp32 torch CPU ops, median of 5 with the "
+                      "best of {16,32,64} threads on %d logical CPUs; %s" % (n_rays, ncpu, cpu_model)}, rgb, rows
 
 
 def teacher_leg(device, world, rank, distributed, frames=2):
@@ -276,19 +322,24 @@ def main():
     thetas = [-180.0 + 9.0 * i for i in range(40)]
     poses = [pose_spherical(t, -30., 4.)[:3, :4] for t in thetas]
     frames = {}
+    pose_t = torch.stack([torch.as_tensor(p, dtype=torch.float32) for p in poses], 0).to(device)  # resident before the clock
 
     def render_step(i):
+        k0 = ((i * world + rank) * FRAMES_PER_STEP) % len(poses)
+        idx = [(k0 + j) % len(poses) for j in range(FRAMES_PER_STEP)]
         with torch.no_grad():
-            frames["rgb"] = net.render_pose(poses[(i * world + rank) % len(poses)], ps)
+            frames["rgb"] = net.render_poses(pose_t[idx], ps)
 
-    dt, kernel_ms = timed(render_step, a.steps, a.warmup, distributed, device)
-    rays = H * W * a.steps * world
+    with leg_clock("render"):
+        dt, kernel_ms = timed(render_step, a.steps, a.warmup, distributed, device)
+    rays = FRAMES_PER_STEP * H * W * a.steps * world
     value = rays / dt
-    achieved = H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
+    achieved = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
     fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # matrix-pipe paths built from low-precision MFMA products
     fwd2 = fwd3 and not os.environ.get("R2L_NO_FWD2", "0").strip("0")  # default of forward-only launches: 3 fp16 products
     traffic, traffic_src = pmc_traffic("void r2l_fwd2_kernel<true" if fwd2 else
-                                       ("void r2l_fwd3_kernel<true" if fwd3 else "void r2l_fwd_kernel<1, false>"))
+                                       ("void r2l_fwd3_kernel<true" if fwd3 else "void r2l_fwd_kernel<1, false>"),
+                                       grid_threads=(FRAMES_PER_STEP * H * W + 127) // 128 * 256)
     # matrix-pipe peak in ALGORITHMIC FLOP/s: every fp32 product costs three fp16 MFMA products on the default path (six
     # bf16 products on the bf16x3 path), so it is the dense fp16/bf16 MFMA peak / 3 (/ 6); the exact-fp32 MFMA peak is kept
     # beside it for reference
@@ -313,22 +364,25 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": dtype,
         "data": "synthetic",
-        "config": {"workload": "R2L W256D88 render_test 400x400 testskip=1: 1 frame (160000 rays, 16 samples/ray, "
-                               "L=10) per GPU per step, fused sample+encode+ResMLP forward; seeded weights, "
-                               "pose_spherical poses",
-                   "rays_per_step_per_gpu": H * W, "parallelism": "frames sharded across %d rank(s), no collective"
-                                                               % world},
+        "frames_per_step": FRAMES_PER_STEP, "ms_per_frame": dt / a.steps * 1e3 / FRAMES_PER_STEP,
+        "config": {"workload": "R2L W256D88 render_test 400x400 testskip=1: %d test frames (160000 rays each, 16 samples/ray, "
+                               "L=10) per GPU per step in ONE launch of the fused sample+encode+ResMLP forward (as "
+                               "driver.render_path walks the test poses); seeded weights, pose_spherical poses"
+                               % FRAMES_PER_STEP,
+                   "rays_per_step_per_gpu": FRAMES_PER_STEP * H * W,
+                   "parallelism": "frames sharded across %d rank(s), no collective" % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_fp32_mfma": PEAK_FP32_MFMA,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
                      "peak_note": peak_note,
                      "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
-                                     "bytes per launch = 160000 rays x 12 B out + the packed weight stream (25.1 MB of "
-                                     "fp16 pairs / 37.6 MB of bf16 triples / 24.3 MB fp32)" % traffic_src,
+                                     "bytes per launch = %d x 160000 rays x 12 B out + the packed weight stream (25.1 MB of "
+                                     "fp16 pairs / 37.6 MB of bf16 triples / 24.3 MB fp32)" % (traffic_src, FRAMES_PER_STEP),
                      "kernel": ("r2l_fwd2_kernel<POSE> (+ the idle range-guard launch of r2l_fwd3_kernel)" if fwd2 else
                                 ("r2l_fwd3_kernel<POSE>" if fwd3 else "r2l_fwd_kernel<MODE_POSE>")),
                      "kernel_ms": kernel_ms,
+                     "rays_per_launch": FRAMES_PER_STEP * H * W,
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }
 
@@ -336,12 +390,14 @@ def main():
         # the same frame on the bf16x3 kernel (six bf16 products per fp32 product: fp32-exact products), for reference
         os.environ["R2L_NO_FWD2"] = "1"
         try:
-            dt3, k3 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
+            with leg_clock("render_bf16x3"):
+                dt3, k3 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
         finally:
             del os.environ["R2L_NO_FWD2"]
         n3 = max(3, a.steps // 4)
-        a3 = H * W * FWD_FLOP_PER_RAY / (k3 * 1e-3) / 1e12
-        out["render_bf16x3"] = {"value": H * W * n3 / dt3, "unit": "rays/s", "ms_per_step": dt3 / n3 * 1e3,
+        a3 = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (k3 * 1e-3) / 1e12
+        out["render_bf16x3"] = {"value": FRAMES_PER_STEP * H * W * n3 / dt3, "unit": "rays/s", "ms_per_step": dt3 / n3 * 1e3,
+                                "ms_per_frame": dt3 / n3 * 1e3 / FRAMES_PER_STEP,
                                 "roofline": {"bound": "mfma", "achieved": a3, "peak": PEAK_BF16_MFMA / 6., "unit": "TFLOP/s",
                                              "frac": a3 / (PEAK_BF16_MFMA / 6.), "kernel": "r2l_fwd3_kernel<POSE>",
                                              "kernel_ms": k3}}
@@ -349,12 +405,14 @@ def main():
         # the same frame on the exact-fp32 MFMA kernel (r2l_forward.hip), for reference: the C side reads the switch per call
         os.environ["R2L_NO_FWD3"] = "1"
         try:
-            dt32, k32 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
+            with leg_clock("render_fp32_mfma"):
+                dt32, k32 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
         finally:
             del os.environ["R2L_NO_FWD3"]
         n32 = max(3, a.steps // 4)
-        a32 = H * W * FWD_FLOP_PER_RAY / (k32 * 1e-3) / 1e12
-        out["render_fp32_mfma"] = {"value": H * W * n32 / dt32, "unit": "rays/s", "ms_per_step": dt32 / n32 * 1e3,
+        a32 = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (k32 * 1e-3) / 1e12
+        out["render_fp32_mfma"] = {"value": FRAMES_PER_STEP * H * W * n32 / dt32, "unit": "rays/s", "ms_per_step": dt32 / n32 * 1e3,
+                                   "ms_per_frame": dt32 / n32 * 1e3 / FRAMES_PER_STEP,
                                    "roofline": {"bound": "mfma", "achieved": a32, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                                                 "frac": a32 / PEAK_FP32_MFMA, "kernel": "r2l_fwd_kernel<MODE_POSE>",
                                                 "kernel_ms": k32}}
@@ -370,42 +428,61 @@ def main():
         except ImportError:
             train_mod = None
     if train_mod is not None:
-        out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                       PEAK_FP32_MFMA)
+        with leg_clock("train"):
+            out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                           PEAK_FP32_MFMA)
         if distributed:
             # strong-scaling leg: the single-GPU batch (98 304 rays) split over the ranks, same global batch and the same
             # optimisation schedule as N = 1; the bucketed all-reduce has to hide under 1/N of the dW kernels here
             per = max(32, (a.train_rays // world + 31) // 32 * 32)
-            out["train_strong"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                                  PEAK_FP32_MFMA, n_rays=per)
+            with leg_clock("train_strong"):
+                out["train_strong"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                                      PEAK_FP32_MFMA, n_rays=per)
             out["train_strong"]["scaling"] = "strong"
             out["train_strong"]["global_rays_per_step"] = per * world
         # BASELINE configs[2] read literally ("N_rand=4096" as 4096 rays per step; at N GPUs configs[3]: 4096 rays per GPU)
-        out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                            PEAK_FP32_MFMA, n_rays=4096)
+        with leg_clock("train_4096"):
+            out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                                PEAK_FP32_MFMA, n_rays=4096)
+        if distributed:
+            # the same steps with the segmented dX chain switched off (staged backward: the whole chain, then the buckets), to
+            # tell what cutting the chain buys once a node measures it
+            with leg_clock("train_4096_uncut_chain"):
+                out["train_4096_uncut_chain"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed,
+                                                                TRAIN_FLOP_PER_RAY, PEAK_FP32_MFMA, n_rays=4096, chain_segments=1)
+        if rank == 0 and world == 1:
+            # exact weight gradients (r2l_config.dw_mode = R2L_DW_EXACT): hi + mid operands, three products in the dW GEMMs
+            with leg_clock("train_exact_dw"):
+                out["train_exact_dw"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                                        PEAK_FP32_MFMA, dw_mode="exact")
         # reference leg: the same step with every GEMM on six bf16 products per fp32 product (fp32-exact products)
         if rank == 0 and world == 1 and not any(k in os.environ for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2")):
             for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
                 os.environ[k] = "1"
             try:
-                out["train_bf16x3"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                                      PEAK_FP32_MFMA)
+                with leg_clock("train_bf16x3"):
+                    out["train_bf16x3"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed,
+                                                          TRAIN_FLOP_PER_RAY, PEAK_FP32_MFMA)
             finally:
                 for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
                     del os.environ[k]
 
     if not a.no_teacher:
-        out["teacher"] = teacher_leg(device, world, rank, distributed)
+        with leg_clock("teacher"):
+            out["teacher"] = teacher_leg(device, world, rank, distributed)
     # the CPU baseline goes LAST: torch's intra-op pool keeps its 16-64 threads spinning for a while after the oracle's GEMMs,
     # which slows the host thread that launches the (launch-bound, ~0.8 ms) 4096-ray steps: 0.83 -> 1.46 ms per step measured
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        t_cb = time.perf_counter()
         cb, rgb_cpu, rows = cpu_baseline(sd)
+        LEG_WALL["cpu_baseline"] = time.perf_counter() - t_cb
         out["cpu_baseline"] = cb
         # parity spot check of the benchmarked kernel against the CPU baseline output (same pose, same seeded weights: the GPU
         # frame was rendered before the training legs moved them)
         out["parity_max_abs_err_vs_cpu"] = (rgb_gpu_check[rows] - rgb_cpu).abs().max().item()
     if distributed and shared_gpu_test:
         out["shared_gpu_test"] = "ranks share ONE GPU over gloo (R2L_BENCH_SHARED_GPU_TEST=1): a walk through the N > 1 code, not a measurement"
+    out["leg_wall_s"] = {k: round(v, 3) for k, v in LEG_WALL.items()}  # rank 0's host wall per leg, warm-up and set-up included
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -52,6 +52,7 @@ class GradAllReducer:
         self.pg = process_group
         self.bucket = bucket_floats  # blocking form: 0 = one call on the whole buffer
         self._works = []
+        self.trace = None  # enable_trace(): [(floats, submit event, wait-passed event)] of the buckets of the last step
 
     def world(self):
         if dist.is_available() and dist.is_initialized():
@@ -80,15 +81,32 @@ class GradAllReducer:
         """Start the all-reduce of a finished, contiguous range of the flat gradient (a view).  The kernels that wrote
         it must already be enqueued on the current stream.  (op: SUM; MAX for the step-validity word of segmented steps.)"""
         if self.world() > 1:
+            if self.trace is not None and bucket.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()  # on the submitting stream: the bucket's gradient kernels are enqueued in front of it
+                self.trace.append([bucket.numel(), ev, None])
             self._works.append(dist.all_reduce(bucket, op=op or dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def enable_trace(self):
+        """bench.py at N > 1: device timestamps of every bucket of the next step — when its all-reduce was handed over
+        (submit, on the stream that produced the bucket) and when the compute stream got past the wait for it (finish)."""
+        self.trace = []
+
+    def trace_ms(self, t0):
+        """[(floats, submit ms, wait-passed ms)] relative to the event t0 (call after a synchronize)."""
+        return [(n, t0.elapsed_time(a), t0.elapsed_time(b) if b is not None else None) for n, a, b in (self.trace or [])]
 
     def pending(self):
         return len(self._works)
 
     def finish(self):
         """Everything submitted is summed once this returns (GPU: once the current stream gets there; no host block)."""
-        for w in self._works:
+        for i, w in enumerate(self._works):
             w.wait()
+            if self.trace is not None and i < len(self.trace) and torch.cuda.is_available():
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()  # the compute stream is past this bucket's exchange
+                self.trace[len(self.trace) - len(self._works) + i][2] = ev
         self._works = []
 
 

@@ -294,7 +294,7 @@ def lr_schedule(step, lrate, lrate_decay, warmup_lr=""):
 # ---------------------------------------------------------------------------------------------------------------
 # hook used by bench.py
 # ---------------------------------------------------------------------------------------------------------------
-def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak, n_rays=None):
+def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak, n_rays=None, dw_mode=None, chain_segments=None):
     """Training leg of bench.py: K fused steps of `a.train_rays` rays per GPU (synthetic [o,d,rgb] rows as in the
     `.npy` shards, main.py:1305-1311), RCCL all-reduce when world > 1."""
     n = a.train_rays if n_rays is None else n_rays
@@ -302,7 +302,7 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
     o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(device)
     d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(device)
     tgt = torch.rand(n, 3, generator=g).to(device)
-    tr = R2LTrainer(net, ps)
+    tr = R2LTrainer(net, ps, dw_mode=dw_mode or "auto", chain_segments=chain_segments)
     steps = max(2, min(a.steps, 10))
     warm = max(1, min(a.warmup, 2))
 
@@ -323,7 +323,12 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
     path = "fp32 MFMA"
     extra = {}
     fwd_f, dx_f, dw_f, head_f = 11789824. - 516096., 2 * 86 * 256 * 256., 2 * 86 * 256 * 256., 2 * 1008 * 256.
-    if fwd3 and big and not off:
+    exact = tr.eng.cfg.dw_mode == _lib.DW_MODE["exact"] or (tr.eng.cfg.dw_mode == 0 and os.environ.get("R2L_DW_EXACT", "0").strip("0"))
+    if fwd3 and big and not off and exact:
+        peak = 2500.0 / 3.
+        path = ("fp16 trio with EXACT weight gradients: forward, dX chain, dW body and head dW with 3 fp16 MFMA products per fp32 "
+                "product (hi + mid operands everywhere); range-guarded, bf16x3 trio behind it")
+    elif fwd3 and big and not off:
         mfma_flops = 3 * (fwd_f + head_f) + 3 * dx_f + 1 * dw_f + (2500.0 / peak_fp32) * head_f
         peak = 2500.0 * flop_per_ray / mfma_flops
         path = ("fp16 trio: forward and dX chain with 3 fp16 MFMA products per fp32 product (two-way operand splits), dW body "
@@ -357,6 +362,19 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
         extra["grad_allreduce_alone_ms"] = (time.perf_counter() - t0) / 5 * 1e3
         extra["grad_allreduce_bytes"] = buf.numel() * 4
         extra["allreduce_buckets"] = tr.n_buckets
+        extra["chain_segments"] = tr.chain_segments if tr.lib.r2l_chain_segments_ok_cfg(int(n), tr.eng.n_block, tr.eng._cfg()) else 1
+        # one more step with device timestamps per bucket: when its all-reduce was handed over and when the compute stream
+        # got past the wait for it (exposed = what lies between the last gradient kernel and Adam), relative to the step start
+        tr.reducer.enable_trace()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        train_step(steps + warm)
+        e1.record()
+        torch.cuda.synchronize(device)
+        extra["bucket_timeline_ms"] = [{"floats": nf, "submit": round(ts, 4), "wait_passed": None if tw is None else round(tw, 4)}
+                                       for nf, ts, tw in tr.reducer.trace_ms(e0)]
+        extra["bucket_timeline_step_ms"] = e0.elapsed_time(e1)
+        tr.reducer.trace = None
     return {"value": n * steps * world / dt, "unit": "rays/s", "steps": steps, "warmup": warm,
             "ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": n,
             "workload": "distillation step (fwd + bwd + Adam + weight re-pack), %d rays/GPU/step, perturb=1; "
