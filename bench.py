@@ -386,6 +386,18 @@ def main():
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }
 
+    if rank == 0 and world == 1:
+        # the same kernel launched ONE frame at a time (round 1 / 2's step: 1250 workgroups = 4.88 rounds of the 256 CUs per
+        # launch), for comparison across rounds; box-to-box spread of the 16-bit kernels is +-3 % (power-capped clocks)
+        def one_frame_step(i):
+            with torch.no_grad():
+                frames["rgb"] = net.render_pose(poses[i % len(poses)], ps)
+        with leg_clock("render_one_frame_per_launch"):
+            dt1, k1 = timed(one_frame_step, a.steps, a.warmup, distributed, device)
+        a1 = H * W * FWD_FLOP_PER_RAY / (k1 * 1e-3) / 1e12
+        out["render_one_frame_per_launch"] = {"value": H * W * a.steps / dt1, "unit": "rays/s", "ms_per_frame": dt1 / a.steps * 1e3,
+                                              "roofline": {"bound": "mfma", "achieved": a1, "peak": peak, "unit": "TFLOP/s",
+                                                           "frac": a1 / peak, "kernel_ms": k1}}
     if fwd2 and rank == 0 and world == 1:
         # the same frame on the bf16x3 kernel (six bf16 products per fp32 product: fp32-exact products), for reference
         os.environ["R2L_NO_FWD2"] = "1"
