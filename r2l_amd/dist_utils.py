@@ -133,15 +133,20 @@ def parameters_in_sync(flat, process_group=None):
 
 class NativeGradAllReducer:
     """The C-ABI form of the exchange (include/r2l_hip.h r2l_allreduce_*: RCCL dlopen'ed by libr2l_hip.so, no
-    torch.distributed) — what a non-PyTorch host binds.  Same submit/finish surface as GradAllReducer; the collective is
-    enqueued on the current stream, so `finish` has nothing to wait for."""
+    torch.distributed) — what a non-PyTorch host binds.  Same submit/finish surface as GradAllReducer, and the same overlap:
+    a bucket's all-reduce goes to the reducer's OWN stream behind an event recorded on the stream that produced the bucket
+    (hipEventRecord / hipStreamWaitEvent in a C host), so it runs beside the gradient kernels enqueued next; `finish` makes
+    the current stream wait for the events recorded behind every collective (no host block).  overlap=False: everything on
+    the current stream (the serial form)."""
 
-    def __init__(self, unique_id, world, rank):
+    def __init__(self, unique_id, world, rank, overlap=True):
         import ctypes
         from . import _lib
         self._lib, self._ctypes = _lib, ctypes
         self.lib = _lib.load()
         self._world, self.rank = int(world), int(rank)
+        self._comm_stream = torch.cuda.Stream() if overlap else None
+        self._done = []
         self._h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _lib.check(self.lib.r2l_allreduce_init(ctypes.cast(buf, ctypes.c_void_p), self._world, self.rank,
@@ -162,19 +167,34 @@ class NativeGradAllReducer:
     def grad_scale(self):
         return 1.0 / self._world
 
-    def submit(self, bucket):
+    def submit(self, bucket, op=None):
         ct = self._ctypes
+        if op is not None:
+            raise NotImplementedError("the C-ABI exchange is a SUM of floats (include/r2l_hip.h r2l_grad_allreduce)")
+        stream = torch.cuda.current_stream()
+        if self._comm_stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(stream)                    # the bucket's gradient kernels are enqueued in front of this
+            self._comm_stream.wait_event(ready)
+            stream = self._comm_stream
         self._lib.check(self.lib.r2l_grad_allreduce(self._h, ct.c_void_p(bucket.data_ptr()), bucket.numel(),
-                                                    ct.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                        "r2l_grad_allreduce")
+                                                    ct.c_void_p(stream.cuda_stream)), "r2l_grad_allreduce")
+        if self._comm_stream is not None:
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+            self._done.append(done)
 
-    allreduce = submit
+    def allreduce(self, flat):
+        self.submit(flat)
+        self.finish()
 
     def pending(self):
-        return 0
+        return len(self._done)
 
     def finish(self):
-        pass
+        for ev in self._done:
+            torch.cuda.current_stream().wait_event(ev)
+        self._done = []
 
     def close(self):
         if self._h:

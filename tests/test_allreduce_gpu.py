@@ -32,6 +32,45 @@ def test_native_allreduce_single_rank_round_trip():
     red.close()
 
 
+def test_native_allreduce_overlapped_with_the_staged_backward():
+    """The C-ABI exchange in its OVERLAPPED form (own stream, event behind the producer, event behind the collective) driven by
+    the real staged backward of the trainer: every bucket's all-reduce runs on the reducer's stream beside the weight-gradient
+    kernels of the next bucket; gradients and the Adam update equal the serial one-call step bit for bit (one rank: SUM =
+    identity, so any ordering mistake between the streams shows as a torn or stale bucket)."""
+    from model.nerf_raybased import PointSampler
+    from oracle import r2l_oracle as O
+    from r2l_amd.dist_utils import NativeGradAllReducer
+    from r2l_amd.train_step import R2LTrainer
+    from tests.test_forward_gpu import build_model
+    sd = O.make_state_dict(n_block=43, seed=3)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    n = 20000
+    g = torch.Generator().manual_seed(2)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+
+    def run(native):
+        tr = R2LTrainer(build_model(sd, 43), ps)
+        tr.force_staged, tr.n_buckets = True, 4
+        if native:
+            tr.reducer = NativeGradAllReducer(NativeGradAllReducer.make_unique_id(), 1, 0)
+        for i in range(3):
+            tr.forward_backward(o, d, tgt)
+            if native:
+                assert tr.reducer.pending() == 5  # 4 body buckets + the head, in flight on the reducer's stream
+            tr.allreduce_grads()
+            tr.adam(1e-4)
+        torch.cuda.synchronize()
+        out = tr.grads.clone(), tr.eng.flat.clone()
+        if native:
+            tr.reducer.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_native_allreduce_reports_errors():
     from r2l_amd import _lib
     lib = _lib.load()
