@@ -30,12 +30,15 @@
 #include "r2l_dw.h"
 
 #define DW16_OP_BYTES 16384
-// EXACT (r2l_config.dw_mode = R2L_DW_EXACT): the tile's image is [G hi | A hi | G mid | A mid] (64 KiB, two tiles in flight
-// instead of four), 48 MFMAs per 16 rays instead of 16: mid*hi + hi*mid + hi*hi, small terms first — the three-product
-// scheme of the chains (r2l_f2.h), so dW carries fp32-grade products for twice the stash traffic (still HBM-bound).
+// EXACT (r2l_config.dw_mode = R2L_DW_EXACT): hi AND mid halves of both operands, 48 MFMAs per 16 rays instead of 16:
+// mid*hi + hi*mid + hi*hi, small terms first — the three-product scheme of the chains (r2l_f2.h), so dW carries fp32-grade
+// products for twice the stash traffic (still HBM-bound).  The ring unit is then a HALF tile (one k-step = 16 rays) of
+// [G hi | A hi | G mid | A mid] = 32 KiB, four units deep like the default kernel's four tiles (a DMA instruction moves 16
+// rays of two stage pieces either way), one barrier per k-step: the same 96 KiB in flight per CU and the same continuous
+// stream.  (First version: whole tiles of 64 KiB, two deep, vmcnt(0) per tile: 4.5 TB/s instead of 5.9.)
 template <bool EXACT> struct Dw16Cfg {
-    static constexpr int NB = EXACT ? 2 : 4;
-    static constexpr unsigned STAGE_BYTES = EXACT ? 65536u : 32768u;
+    static constexpr int NB = 4;
+    static constexpr unsigned STAGE_BYTES = 32768u;
 };
 
 typedef short dw16_s16x4 __attribute__((ext_vector_type(4)));
@@ -137,38 +140,36 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         const u32x4 ars = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)aa),
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(aa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
-        // tile s of the segment -> ring buffer s & 3: 8 pieces per wave.  Tiles past the end are clamped to the last one
-        // (harmless reloads into a dead buffer: every step issues exactly 8 loads, which keeps the vmcnt waits uniform)
-        auto issue = [&](int s) {
-            const int sc = s < ntiles ? s : ntiles - 1;
-            const unsigned so = (unsigned)sc * (unsigned)DW16_OP_BYTES + wsrc;
-            const unsigned ld = wdst + (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES;
+        if constexpr (EXACT) {
+            // unit q = (tile q >> 1, k-step q & 1) -> ring buffer q & 3: [G hi | A hi | G mid | A mid], 8 KiB each (8 feature
+            // tiles T x 1 KiB: T*64 + rq*16 + g*8 + row*2 + h in 16-byte units, rq = ray quad 0..3); 8 loads per wave and unit.
+            // Units past the end are clamped to the last one (harmless reloads: the vmcnt waits stay uniform).
+            const int nunits = 2 * ntiles;
+            auto issue = [&](int q) {
+                const int qc = q < nunits ? q : nunits - 1;
+                const unsigned so = (unsigned)(qc >> 1) * (unsigned)DW16_OP_BYTES + wsrc + (unsigned)(qc & 1) * 256u;
+                const unsigned ld = img_lds + (unsigned)(q & (DW16_NB - 1)) * DW16_STAGE_BYTES + (unsigned)wave * 2048u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned po = (unsigned)((i >> 1) * 2048 + (i & 1) * 256);
-                f3_dma16(grs, dvoff, so + po, ld + (unsigned)i * 1024u);
-                f3_dma16(ars, dvoff, so + po, ld + DW16_OP_BYTES + (unsigned)i * 1024u);
-                if (EXACT) {
-                    f3_dma16(grs, dvoff, so + po + a.mid_off, ld + 2 * DW16_OP_BYTES + (unsigned)i * 1024u);
-                    f3_dma16(ars, dvoff, so + po + a.mid_off, ld + 3 * DW16_OP_BYTES + (unsigned)i * 1024u);
+                for (int pr = 0; pr < 2; ++pr) {  // the wave's two piece pairs (pieces 4w + 2pr, 4w + 2pr + 1), 16 rays of each
+                    const unsigned po = so + (unsigned)pr * 2048u, lp = ld + (unsigned)pr * 1024u;
+                    f3_dma16(grs, dvoff, po, lp);
+                    f3_dma16(ars, dvoff, po, lp + 8192u);
+                    f3_dma16(grs, dvoff, po + a.mid_off, lp + 16384u);
+                    f3_dma16(ars, dvoff, po + a.mid_off, lp + 24576u);
                 }
-            }
-        };
-        auto read = [&](Dw16Frags<EXACT>& R, int s, int ks) {
-            const unsigned bo = (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES + (unsigned)ks * 1024u;
-            const unsigned gp = gl + bo, ap = al + bo;
+            };
+            const unsigned gq = img_lds + rl + (unsigned)wo * 4096u, aq = img_lds + 8192u + rl + (unsigned)wi * 4096u;
+            auto read = [&](Dw16Frags<EXACT>& R, int q) {
+                const unsigned bo = (unsigned)(q & (DW16_NB - 1)) * DW16_STAGE_BYTES;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                R.g[e] = dw16_frag(gp, (unsigned)e * 2048u);
-                R.x[e] = dw16_frag(ap, (unsigned)e * 2048u);
-                if (EXACT) {
-                    R.gm[e] = dw16_frag(gp, 2 * DW16_OP_BYTES + (unsigned)e * 2048u);
-                    R.xm[e] = dw16_frag(ap, 2 * DW16_OP_BYTES + (unsigned)e * 2048u);
+                for (int e = 0; e < 4; ++e) {
+                    R.g[e] = dw16_frag(gq + bo, (unsigned)e * 1024u);
+                    R.x[e] = dw16_frag(aq + bo, (unsigned)e * 1024u);
+                    R.gm[e] = dw16_frag(gq + bo, 16384u + (unsigned)e * 1024u);
+                    R.xm[e] = dw16_frag(aq + bo, 16384u + (unsigned)e * 1024u);
                 }
-            }
-        };
-        auto mma = [&](const Dw16Frags<EXACT>& R) {
-            if (EXACT) {  // small terms first
+            };
+            auto mma = [&](const Dw16Frags<EXACT>& R) {  // small terms first
 #pragma unroll
                 for (int eo = 0; eo < 4; ++eo)
 #pragma unroll
@@ -179,45 +180,125 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
 #pragma unroll
                     for (int ei = 0; ei < 4; ++ei)
                         acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.xm[ei], acc[eo][ei], 0, 0, 0);
-            }
 #pragma unroll
-            for (int eo = 0; eo < 4; ++eo)
+                for (int eo = 0; eo < 4; ++eo)
 #pragma unroll
-                for (int ei = 0; ei < 4; ++ei)
-                    acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
-            if (wi == 0) {  // db: the 8 rays of a gradient fragment added up on the VALU, exactly, in fp32
+                    for (int ei = 0; ei < 4; ++ei)
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+                if (wi == 0) {  // db: hi and mid halves of the 8 rays of a gradient fragment, added up exactly in fp32
 #pragma unroll
-                for (int eo = 0; eo < 4; ++eo) {
-                    const u32x4 w = __builtin_bit_cast(u32x4, R.g[eo]);
+                    for (int eo = 0; eo < 4; ++eo) {
+                        const u32x4 w = __builtin_bit_cast(u32x4, R.g[eo]), wm = __builtin_bit_cast(u32x4, R.gm[eo]);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(w[d], dw16_add_lo(w[d], bsum[eo]));
-                    if (EXACT) {
-                        const u32x4 wm = __builtin_bit_cast(u32x4, R.gm[eo]);
+                        for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(w[d], dw16_add_lo(w[d], bsum[eo]));
 #pragma unroll
                         for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(wm[d], dw16_add_lo(wm[d], bsum[eo]));
                     }
                 }
-            }
-        };
-        Dw16Frags<EXACT> R0, R1;
-        // prologue: tiles 0 .. NB-1 requested, tile 0 published (latency exposed once per segment)
+            };
+            Dw16Frags<EXACT> R0, R1;
 #pragma unroll
-        for (int s = 0; s < DW16_NB; ++s) issue(s);
-        if (EXACT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // 2 tiles x 16 loads per wave
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // 4 tiles x 8
-        __syncthreads();
-        read(R0, 0, 0);
-        for (int s = 0; s < ntiles; ++s) {
-            read(R1, s, 1);
-            mma(R0);
-            // tile s+1 landed (its 8 loads have the 16 of tiles s+2, s+3 behind them; EXACT: nothing behind its 16); behind the
-            // barrier everybody's share is visible and nobody reads the image of tile s any more (its fragments are in registers)
-            if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            for (int q = 0; q < DW16_NB; ++q) issue(q);
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // unit 0 landed (3 x 8 loads behind it)
             __syncthreads();
-            issue(s + DW16_NB);
-            read(R0, s + 1, 0);
-            mma(R1);
+            read(R0, 0);
+            for (int q = 0; q < nunits; q += 2) {
+                // unit q+1 landed (the 16 loads of units q+2, q+3 behind it); behind the barrier everybody's share is visible and
+                // nobody reads unit q's buffer any more (its fragments are in registers): it goes to the DMA of unit q+4
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                __syncthreads();
+                issue(q + DW16_NB);
+                read(R1, q + 1);
+                mma(R0);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                __syncthreads();
+                issue(q + 1 + DW16_NB);
+                read(R0, q + 2);
+                mma(R1);
+            }
+        } else {
+            // tile s of the segment -> ring buffer s & 3: 8 pieces per wave.  Tiles past the end are clamped to the last one
+            // (harmless reloads into a dead buffer: every step issues exactly 8 loads, which keeps the vmcnt waits uniform)
+            auto issue = [&](int s) {
+                const int sc = s < ntiles ? s : ntiles - 1;
+                const unsigned so = (unsigned)sc * (unsigned)DW16_OP_BYTES + wsrc;
+                const unsigned ld = wdst + (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES;
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned po = (unsigned)((i >> 1) * 2048 + (i & 1) * 256);
+                    f3_dma16(grs, dvoff, so + po, ld + (unsigned)i * 1024u);
+                    f3_dma16(ars, dvoff, so + po, ld + DW16_OP_BYTES + (unsigned)i * 1024u);
+                    if (EXACT) {
+                        f3_dma16(grs, dvoff, so + po + a.mid_off, ld + 2 * DW16_OP_BYTES + (unsigned)i * 1024u);
+                        f3_dma16(ars, dvoff, so + po + a.mid_off, ld + 3 * DW16_OP_BYTES + (unsigned)i * 1024u);
+                    }
+                }
+            };
+            auto read = [&](Dw16Frags<EXACT>& R, int s, int ks) {
+                const unsigned bo = (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES + (unsigned)ks * 1024u;
+                const unsigned gp = gl + bo, ap = al + bo;
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    R.g[e] = dw16_frag(gp, (unsigned)e * 2048u);
+                    R.x[e] = dw16_frag(ap, (unsigned)e * 2048u);
+                    if (EXACT) {
+                        R.gm[e] = dw16_frag(gp, 2 * DW16_OP_BYTES + (unsigned)e * 2048u);
+                        R.xm[e] = dw16_frag(ap, 2 * DW16_OP_BYTES + (unsigned)e * 2048u);
+                    }
+                }
+            };
+            auto mma = [&](const Dw16Frags<EXACT>& R) {
+                if (EXACT) {  // small terms first
+    #pragma unroll
+                    for (int eo = 0; eo < 4; ++eo)
+    #pragma unroll
+                        for (int ei = 0; ei < 4; ++ei)
+                            acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.gm[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+    #pragma unroll
+                    for (int eo = 0; eo < 4; ++eo)
+    #pragma unroll
+                        for (int ei = 0; ei < 4; ++ei)
+                            acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.xm[ei], acc[eo][ei], 0, 0, 0);
+                }
+    #pragma unroll
+                for (int eo = 0; eo < 4; ++eo)
+    #pragma unroll
+                    for (int ei = 0; ei < 4; ++ei)
+                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+                if (wi == 0) {  // db: the 8 rays of a gradient fragment added up on the VALU, exactly, in fp32
+    #pragma unroll
+                    for (int eo = 0; eo < 4; ++eo) {
+                        const u32x4 w = __builtin_bit_cast(u32x4, R.g[eo]);
+    #pragma unroll
+                        for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(w[d], dw16_add_lo(w[d], bsum[eo]));
+                        if (EXACT) {
+                            const u32x4 wm = __builtin_bit_cast(u32x4, R.gm[eo]);
+    #pragma unroll
+                            for (int d = 0; d < 4; ++d) bsum[eo] = dw16_add_hi(wm[d], dw16_add_lo(wm[d], bsum[eo]));
+                        }
+                    }
+                }
+            };
+            Dw16Frags<EXACT> R0, R1;
+            // prologue: tiles 0 .. NB-1 requested, tile 0 published (latency exposed once per segment)
+    #pragma unroll
+            for (int s = 0; s < DW16_NB; ++s) issue(s);
+            if (EXACT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // 2 tiles x 16 loads per wave
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // 4 tiles x 8
+            __syncthreads();
+            read(R0, 0, 0);
+            for (int s = 0; s < ntiles; ++s) {
+                read(R1, s, 1);
+                mma(R0);
+                // tile s+1 landed (its 8 loads have the 16 of tiles s+2, s+3 behind them; EXACT: nothing behind its 16); behind the
+                // barrier everybody's share is visible and nobody reads the image of tile s any more (its fragments are in registers)
+                if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                __syncthreads();
+                issue(s + DW16_NB);
+                read(R0, s + 1, 0);
+                mma(R1);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the images are dead (and the clamped reloads landed) before the next segment refills them
