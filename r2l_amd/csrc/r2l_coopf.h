@@ -80,6 +80,9 @@ struct FcStream {
     u32x4 rs;       // descriptor of the stage stream
     unsigned voff;  // lane*16 + wave*2048: tile 2w of split 0; + 1024: tile 2w+1; + 8192: split 1
     unsigned g;     // next stage to LOAD
+#ifdef FC_LATE_MODE  // diagnostic builds (tools/coopf_coresidency.py): the late workgroup of a CU runs a thinned-out body
+    bool late;
+#endif
 };
 
 template <int IMM>
@@ -91,7 +94,11 @@ __device__ __forceinline__ void fc_load(u32x4& dst, u32x4 rs, unsigned voff, uns
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs), "s"(soff), "n"(IMM));
 }
 __device__ __forceinline__ void fc_issue(u32x4 (&a)[4], FcStream& p) {
+#if defined(FC_LATE_MODE) && FC_LATE_MODE == 2  // the late workgroup loads no weights (one stage over and over: L1 hits)
+    const unsigned so = p.late ? 0u : p.g * (unsigned)F2_STAGE_BYTES;
+#else
     const unsigned so = p.g * (unsigned)F2_STAGE_BYTES;
+#endif
     fc_load<0>(a[0], p.rs, p.voff, so);
     fc_load<1024>(a[1], p.rs, p.voff, so);
     fc_load<0>(a[2], p.rs, p.voff + 8192u, so);
@@ -125,6 +132,12 @@ __device__ __forceinline__ void fc_stage(f32x16 (&acc)[NT][2], FcRing<R>& W, FcS
     fc_wait<R>(W.a[SLOT]);
     const f16x8 h0 = __builtin_bit_cast(f16x8, W.a[SLOT][0]), h1 = __builtin_bit_cast(f16x8, W.a[SLOT][1]);
     const f16x8 m0 = __builtin_bit_cast(f16x8, W.a[SLOT][2]), m1 = __builtin_bit_cast(f16x8, W.a[SLOT][3]);
+#if defined(FC_LATE_MODE) && FC_LATE_MODE == 1  // the late workgroup issues no MFMAs
+    if (p.late) {
+        fc_issue(W.a[SLOT], p);
+        return;
+    }
+#endif
     if (BIAS) {
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) {

@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
         P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         P.voff = (unsigned)lane * 16u + (unsigned)wave * 2048u;
+#ifdef FC_LATE_MODE
+        P.late = blockIdx.x >= 256;
+#endif
         P.g = (unsigned)(a.n_block - 1 - a.b_start) * 34u;  // 34 stages per block: [zero, 16 of W2^T, zero, 16 of W1^T]
     }
 #pragma unroll

@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
     __shared__ float red[4][NT * 32][3];
 
     if (__builtin_nontemporal_load(a.status) != 0u) return;  // these weights left fp16's range before: the bf16x3 kernel behind
+#ifdef FC_SKEW  // diagnostic builds: the second workgroup of every CU starts FC_SKEW x ~4 us late (which neighbour phase arms the fault?)
+    if (blockIdx.x >= 256)
+        for (int i = 0; i < FC_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n_tiles = (a.N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
@@ -97,6 +101,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         P.rs = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu, 0xffffffffu, 0x00020000u};
         P.voff = (unsigned)lane * 16u + (unsigned)wave * 2048u;
+#ifdef FC_LATE_MODE
+        P.late = blockIdx.x >= 256;
+#endif
         P.g = 0u;
     }
 #pragma unroll

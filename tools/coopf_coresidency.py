@@ -46,8 +46,9 @@ for share in ("-",):
                 if where is None:
                     dd = (r[0] - ref[0]).abs().amax(1)
                     idx = (dd > 0).nonzero().flatten()
-                    where = "rgb differs on %d rays (first %s), max %.3g, channels %s; grads equal: %s" % (
-                        idx.numel(), idx[:4].tolist(), dd.max().item(),
+                    tiles = torch.unique(idx // 32)
+                    where = "rgb differs on %d rays (first %s; tiles < 256: %d, >= 256: %d), max %.3g, channels %s; grads equal: %s" % (
+                        idx.numel(), idx[:4].tolist(), int((tiles < 256).sum()), int((tiles >= 256).sum()), dd.max().item(),
                         ((r[0] - ref[0]).abs().amax(0) > 0).tolist(), torch.equal(r[-1], ref[-1]) if mode == "train" else "-")
         print("N %d  %s %-6s one tile per workgroup vs two: %d of 10 launches differ%s" % (
             n, share, mode, bad, ("  [" + where + "]") if where else ""))
