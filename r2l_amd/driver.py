@@ -158,7 +158,10 @@ class _FrameWriter:
     non-blocking into a pinned buffer, and a small thread pool waits for the copy and encodes (zlib releases the GIL).
     At 13 ms per rendered frame, encoding two 400x400 PNGs inline (~2 x 15 ms) would triple the wall time."""
 
-    def __init__(self, device, workers=8, slots=8):  # (measured with the 4.4 ms forward: 4 workers 11.1, 8: 6.5, 12: 6.5 ms/frame)
+    # (measured with the 4.4 ms forward, one frame per launch: 4 workers 11.1, 8: 6.5, 12: 6.5 ms/frame.  With 9 frames per launch
+    # 18 images arrive at once: the pinned staging slots must cover two groups, or save() blocks on the encoders before the next
+    # group's render is launched — 8 slots: 11.0 ms/frame)
+    def __init__(self, device, workers=8, slots=4 * POSES_PER_LAUNCH + 4):
         from concurrent.futures import ThreadPoolExecutor
         self.device, self.pool, self.pending = device, ThreadPoolExecutor(max_workers=workers), []
         self.slots, self.bufs = slots, {}
@@ -229,7 +232,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     rgbs, sq_err, psnrs, ssims, events = [], [], [], [], []
     if savedir is not None:
         os.makedirs(savedir, exist_ok=True)  # every rank writes its own frames: none may rely on rank 0's mkdir
-    writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "8"))) if savedir is not None else None
+    writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "12"))) if savedir is not None else None
     on_gpu = device.type == "cuda"
     t_loop = time.time()
     def account(i, rgb):
