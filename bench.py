@@ -282,6 +282,9 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-teacher", action="store_true")
+    ap.add_argument("--one-frame-leg", action="store_true",
+                    help="also time the render kernel ONE frame per launch (the step of rounds 1 / 2), for comparison; off by "
+                         "default so that the kernel-trace of this command holds one population of render launches")
     a = ap.parse_args()
 
     plan = plan_launch(a.gpus, os.environ, torch.cuda.device_count())
@@ -386,7 +389,7 @@ def main():
                      "flop_per_ray": FWD_FLOP_PER_RAY},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and a.one_frame_leg:
         # the same kernel launched ONE frame at a time (round 1 / 2's step: 1250 workgroups = 4.88 rounds of the 256 CUs per
         # launch), for comparison across rounds; box-to-box spread of the 16-bit kernels is +-3 % (power-capped clocks)
         def one_frame_step(i):

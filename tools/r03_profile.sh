@@ -6,6 +6,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/r03
 rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 3 --one-frame-leg --no-cpu-baseline --no-teacher --no-train > $OUT/bench_one_frame_leg.json 2>/dev/null
 cd /tmp
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $REPO/bench.py $ARGS > $OUT/kt.log 2>&1
