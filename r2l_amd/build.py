@@ -42,7 +42,9 @@ def _digest(path):
 # ISA audit.  On gfx950 a packed-fp32 VALU op whose LOW lane takes the HIGH dword of src1 (`v_pk_fma_f32 ... op_sel:[0,1,0]`)
 # was caught dropping its low-lane result in lanes 48-63 when a second wave shared the SIMD (csrc/r2l_coopf.h,
 # profiles/r03_coresidency.md).  hipcc forms these from plain scalar code (SLP vectoriser), so every object's device assembly
-# is checked and the build fails if one appears (src1 / src2 low-lane selects; the src0 form is bit-checked in many kernels).
+# is checked and the build fails if one appears.  tools/pk_opsel_mfma_probe.hip classifies the forms beside MFMA-issuing
+# neighbours: only the src1 select of the packed MULTIPLIES (v_pk_mul_f32, v_pk_fma_f32) goes wrong; src0 / src2 selects, the
+# op_sel_hi forms and v_pk_add_f32 are clean.  The rule below is kept a little wider (src1 or src2, add included).
 _PK_F32 = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b.*\bop_sel:\[([01]),([01])(?:,([01]))?\]")
 
 
