@@ -34,7 +34,8 @@ def init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
+        # (R2L_DIST_BACKEND=gloo: two ranks on ONE GPU in tests — RCCL refuses a device twice, gloo moves CUDA tensors through the host)
+        dist.init_process_group(os.environ.get("R2L_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo"))
     return rank, world, device
 
 
@@ -458,4 +459,10 @@ def main(argv=None):
                              best_psnr, best_psnr_step)
             logger.info('Iter %d Save checkpoint: "%s".' % (i, path))
     loader.close()
+    if world > 1 and os.environ.get("R2L_CHECK_SYNC"):  # tests: the replicas must have stayed bit-identical
+        from .dist_utils import parameters_in_sync
+        ok = parameters_in_sync(trainer.eng.flat)
+        logger.info("replicas in sync after %d iterations: %s (skipped steps: %d)" % (args.N_iters, ok, trainer.skipped_steps))
+        if not ok:
+            raise RuntimeError("data-parallel replicas diverged")
     return {"trainer": trainer, "logger": logger, "model": model}

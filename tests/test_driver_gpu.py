@@ -52,6 +52,45 @@ def test_create_data_then_train(tmp_path, monkeypatch):
     assert res3["rgbs"].shape == (2, 64, 64, 3) and np.isfinite(res3["misc"]["test_psnr"].item())
 
 
+def test_cli_training_two_ranks_uneven_shards(tmp_path):
+    """The CLI under torchrun with TWO ranks on this one GPU (gloo: RCCL refuses a device twice) and --N_rand 3: rank 0 takes two
+    shard files per step, rank 1 one, gradients weighted by ray share (driver.train, dist_utils.split_shards), hard-ray pools
+    per rank, small steps on the segmented dX chain; the replicas must end bit-identical and rank 0 writes the checkpoint."""
+    import subprocess
+    import sys
+    from r2l_amd import create_data
+    from r2l_amd.checkpoint import load_ckpt
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=128)
+    csd, fsd = O.make_teacher_state_dicts(5, 2, alpha_bias=0.5)
+    torch.save({"network_fn_state_dict": csd, "network_fine_state_dict": fsd}, str(tmp_path / "teacher.tar"))
+    kd = str(tmp_path / "pseudo")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        create_data.main(["--create_data", "rand", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene,
+                          "--teacher_ckpt", str(tmp_path / "teacher.tar"), "--n_pose_kd", "6", "--create_data_chunk", "3",
+                          "--datadir_kd", scene + ":" + kd, "--experiment_name", "cd"])
+    finally:
+        os.chdir(cwd)
+    assert len(os.listdir(kd)) == 6
+    env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
+    env.update(MASTER_ADDR="127.0.0.1", R2L_DIST_BACKEND="gloo", R2L_CHECK_SYNC="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "main.py"), "--model_name", "R2L", "--config",
+           os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene, "--n_sample_per_ray", "16", "--netwidth", "256",
+           "--netdepth", "6", "--use_residual", "--trial.ON", "--trial.body_arch", "resmlp", "--testskip", "1", "--datadir_kd", kd,
+           "--data_mode", "rays", "--N_rand", "3", "--hard_ratio", "0.2", "--hard_mul", "2", "--warmup_lr", "0.0001,200",
+           "--i_print", "2", "--i_testset", "100", "--i_weights", "8", "--N_iters", "8", "--experiment_name", "dp2"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert "[2, 1] shard files per rank and step" in out and "replicas in sync after 8 iterations: True (skipped steps: 0)" in out
+    ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "ckpt.tar"]
+    assert len(ckpts) == 1 and load_ckpt(ckpts[0])["global_step"] == 8
+
+
 @pytest.fixture(scope="module")
 def trained_student():
     """A W256 D88 student distilled for 1000 fused steps from a seeded teacher (no released checkpoint exists offline):
