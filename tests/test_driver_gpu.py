@@ -91,6 +91,39 @@ def test_cli_training_two_ranks_uneven_shards(tmp_path):
     assert len(ckpts) == 1 and load_ckpt(ckpts[0])["global_step"] == 8
 
 
+def test_create_data_two_ranks_then_continue(tmp_path):
+    """utils/create_data.py under torchrun with two ranks on this GPU (gloo): poses shard i % world, rank-disjoint shard index
+    ranges with gaps between them; a second (single-process) run into the kept directory continues behind the LARGEST index
+    (counting files would overwrite the last rank's shards)."""
+    import subprocess
+    import sys
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=128)  # half_res -> 64x64 = 4096 rays per pose = one shard per pose
+    csd, fsd = O.make_teacher_state_dicts(5, 2, alpha_bias=0.5)
+    torch.save({"network_fn_state_dict": csd, "network_fine_state_dict": fsd}, str(tmp_path / "teacher.tar"))
+    kd = str(tmp_path / "pseudo")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
+    env.update(MASTER_ADDR="127.0.0.1", R2L_DIST_BACKEND="gloo")
+    args = ["--create_data", "rand", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene, "--teacher_ckpt",
+            str(tmp_path / "teacher.tar"), "--create_data_chunk", "2", "--datadir_kd", scene + ":" + kd, "--experiment_name", "cd"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29643", os.path.join(ROOT, "utils", "create_data.py")] + args +
+                       ["--n_pose_kd", "5"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    idx = sorted(int(f[5:-4]) for f in os.listdir(kd))
+    # rank 0: poses 2, 4 -> data_0, data_1; rank 1: poses 1, 3, 5 -> behind the range sized for the larger share (2 flushes x 2)
+    assert idx == [0, 1, 4, 5, 6], idx
+    first = {i: np.load(os.path.join(kd, "data_%d.npy" % i)) for i in idx}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "utils", "create_data.py")] + args + ["--n_pose_kd", "2"], env=env,
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    idx2 = sorted(int(f[5:-4]) for f in os.listdir(kd))
+    assert idx2 == [0, 1, 4, 5, 6, 7, 8], idx2
+    for i in idx:  # nothing of the first run was overwritten
+        assert np.array_equal(first[i], np.load(os.path.join(kd, "data_%d.npy" % i)))
+
+
 @pytest.fixture(scope="module")
 def trained_student():
     """A W256 D88 student distilled for 1000 fused steps from a seeded teacher (no released checkpoint exists offline):
