@@ -14,7 +14,9 @@ import torch.nn as nn
 
 def parse_expid_iter(path):
     """'.../name_SERVER142-20210704-150540/weights/200000.tar' -> ('SERVER142-20210704-150540', '200000')."""
-    if "SERVER" in path:
+    # (the reference indexes path.split('_SERVER')[1] whenever 'SERVER' occurs anywhere in the path and dies with an IndexError
+    # on e.g. /data/SERVER3/ckpt.tar; here such paths fall through to 'Unknown')
+    if "_SERVER" in path:
         return "SERVER" + path.split("_SERVER")[1].split("/")[0], path.split("/")[-1].split(".tar")[0]
     return "Unknown", "Unknown"
 

@@ -9,6 +9,8 @@ import torch
 from oracle import r2l_oracle as O
 from tests.test_driver_cpu import ROOT, make_scene
 
+from tests.test_forward_gpu import build_model  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -89,6 +91,51 @@ def test_cli_training_two_ranks_uneven_shards(tmp_path):
     assert "[2, 1] shard files per rank and step" in out and "replicas in sync after 8 iterations: True (skipped steps: 0)" in out
     ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "ckpt.tar"]
     assert len(ckpts) == 1 and load_ckpt(ckpts[0])["global_step"] == 8
+
+
+def test_cli_render_two_ranks(tmp_path):
+    """`main.py --render_only` with two ranks on this GPU (gloo): the test views (--render_test: metrics all-reduced, every rank
+    writes its own frames) and the novel-pose video (5 poses over 2 ranks: frames gathered to rank 0 and re-interleaved; with 3
+    ranks' worth of poses one rank may hold none — ADVICE r2) come out as from one process."""
+    import subprocess
+    import sys
+    from r2l_amd import driver
+    from r2l_amd.checkpoint import save_ckpt
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=128)
+    sd = O.make_state_dict(n_block=2, seed=1)
+    ckpt = str(tmp_path / "SERVER-20260101-000000_iter7" / "weights" / "ckpt.tar")
+    save_ckpt(ckpt, 7, build_model(sd, 2).cpu(), {"state": {}, "param_groups": []}, 0., 0)
+    common = ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene,
+              "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "6", "--use_residual", "--trial.ON",
+              "--trial.body_arch", "resmlp", "--testskip", "1", "--pretrained_ckpt", ckpt, "--render_only", "--n_pose_video", "5"]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        one_test = driver.main(common + ["--render_test", "--experiment_name", "one_test"])
+        one_video = driver.main(common + ["--experiment_name", "one_video"])
+    finally:
+        os.chdir(cwd)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
+    env.update(MASTER_ADDR="127.0.0.1", R2L_DIST_BACKEND="gloo")
+    run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29645", os.path.join(ROOT, "main.py")] + common
+    r = subprocess.run(run + ["--render_test", "--experiment_name", "two_test"], env=env, cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    want = "[TEST] TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" % (one_test["misc"]["test_psnr"].item(),
+                                                                  one_test["misc"]["test_psnr_v2"].item(),
+                                                                  one_test["misc"]["test_ssim"].item())
+    assert want in out, (want, [l for l in out.splitlines() if "[TEST]" in l])
+    r = subprocess.run(run + ["--experiment_name", "two_video"], env=env, cwd=str(tmp_path), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    avis = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith(".avi"))
+    assert len(avis) == 2  # one from the single process, one from rank 0 of the pair
+    a, b = (open(f, "rb").read() for f in avis)
+    assert a == b and len(a) > 1000  # the same five frames in the same order
 
 
 def test_create_data_two_ranks_then_continue(tmp_path):
