@@ -462,7 +462,7 @@ def main(argv=None):
     if world > 1 and os.environ.get("R2L_CHECK_SYNC"):  # tests: the replicas must have stayed bit-identical
         from .dist_utils import parameters_in_sync
         ok = parameters_in_sync(trainer.eng.flat)
-        logger.info("replicas in sync after %d iterations: %s (skipped steps: %d)" % (args.N_iters, ok, trainer.skipped_steps))
+        logger.info("replicas in sync after %d iterations: %s (skipped steps: %d)" % (args.N_iters, ok, trainer.drain()))
         if not ok:
             raise RuntimeError("data-parallel replicas diverged")
     return {"trainer": trainer, "logger": logger, "model": model}

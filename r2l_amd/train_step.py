@@ -7,6 +7,7 @@ becomes four HIP stages on flat fp32 buffers (include/r2l_hip.h): fused forward 
 r2l_backward (dX chain, dW GEMMs, head/tail gradients) -> [one RCCL all-reduce of the flat 23.67 MB gradient when
 world_size > 1] -> fused Adam -> re-pack of the MFMA weight streams.  No autograd graph, no anomaly mode.
 """
+import collections
 import ctypes
 import math
 
@@ -19,6 +20,8 @@ import torch.distributed as dist
 from . import _lib
 from .dist_utils import GradAllReducer, bucket_plan, sync_parameters
 from .engine import N_SAMPLE, W, _ptr, _stream, get_engine
+
+STATUS_LAG = 4  # a segmented step's validity word is looked at exactly this many steps later (on every rank alike)
 
 
 class R2LTrainer:
@@ -51,7 +54,7 @@ class R2LTrainer:
         # the weight gradients of a finished segment — and their all-reduce — on a second stream beside the next segment
         # (include/r2l_hip.h R2L_BWD_CHAIN with a layer range).  Such steps run WITHOUT the bf16x3 fallback kernels: a step
         # whose chain raised the range-guard word is skipped on the device (r2l_adam_step_guarded, on every rank: MAX over
-        # ranks), noticed here one step later without a host sync, and the trainer goes back to the uncut form for good.
+        # ranks), read here STATUS_LAG steps later (no stall; the same step on every rank), and the trainer goes back to the uncut form for good.
         # Gradients are bit-identical to the staged form.  On one GPU it only adds launches (4096 rays: 0.78 ms one call, 0.85
         # in 3 segments, 0.96 staged in 4 buckets; profiles/r03_staged_backward.txt), so the default is 1 (off) there and 3 at
         # world > 1, where it replaces the staged form for the steps it applies to (argument, or R2L_CHAIN_SEGMENTS=n;
@@ -62,8 +65,9 @@ class R2LTrainer:
         self.skipped_steps = 0
         self._side = None
         self._status_dev = None
-        self._status_host = None
-        self._status_event = None
+        self._status_host = None  # pinned ring of validity words, one slot per segmented step still in flight
+        self._status_pending = collections.deque()  # (event behind the copy, ring slot), oldest first
+        self._status_slot = 0
         self._guard = None  # device word handed to the guarded Adam of the current step, or None
         if self.reducer.world() > 1 and self.n_buckets > 0 and self.eng.cfg.reserve_cus == 0:
             # the weight-gradient kernels are persistent workgroups that fill every CU: leave a few to the RCCL kernels that
@@ -147,8 +151,7 @@ class R2LTrainer:
                 _stream())
         self._guard = None
         self._check_skipped()
-        if (self.chain_segments > 1 and zero_grad and not self.segments_disabled and
-                self.lib.r2l_chain_segments_ok_cfg(int(n), eng.n_block, eng._cfg())):
+        if self.chain_segments > 1 and zero_grad and not self.segments_disabled and self._segments_ok(n, n_global):
             self._segmented_backward(args)
         elif (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
             # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
@@ -169,13 +172,23 @@ class R2LTrainer:
         return rgb
 
     # ---- segmented dX chain (small steps) -----------------------------------------------------------------------------------
+    def _segments_ok(self, n, n_global):
+        """Does this step take the segmented form?  The answer must be the same on every rank (the forms submit different
+        collectives), so with uneven shares (n_global given) it is asked for both share sizes that occur."""
+        ok, nb, cfg = self.lib.r2l_chain_segments_ok_cfg, self.eng.n_block, self.eng._cfg()
+        if n_global is None or self.world() == 1:
+            return bool(ok(int(n), nb, cfg))
+        lo = int(n_global) // self.world()
+        hi = -(-int(n_global) // self.world())
+        return lo > 0 and bool(ok(lo, nb, cfg)) and bool(ok(hi, nb, cfg))
+
     def _segmented_backward(self, args):
         eng, part, cfg, NF = self.eng, self.lib.r2l_backward_part_cfg, self.eng._cfg(), _lib.BWD_NOFALLBACK
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=eng.device)
             self._status_dev = torch.zeros(1, dtype=torch.int32, device=eng.device)
-            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_host = torch.zeros(STATUS_LAG, dtype=torch.int32).pin_memory()
             word = ctypes.cast(self.lib.r2l_backward_status_word(_ptr(self.wstream_bwd), eng.n_block), ctypes.c_void_p).value
             off = (word - self.wstream_bwd.data_ptr()) // 4
             self._status_src = self.wstream_bwd[off:off + 1].view(torch.int32)  # the chain's range-guard word
@@ -205,18 +218,30 @@ class R2LTrainer:
         main.wait_event(done)
         self._guard = self._status_dev
 
-    def _check_skipped(self):
-        """Did an earlier segmented step turn out invalid (its update was skipped on the device)?  Looks at a word copied to
-        pinned memory behind that step's Adam; never waits for the GPU."""
-        if self._status_event is not None and self._status_event.query():
-            self._status_event = None
-            if int(self._status_host[0]) != 0:
+    def _check_skipped(self, wait=False):
+        """Did an earlier segmented step turn out invalid (its update was skipped on the device)?  Every such step copies its
+        validity word into its own slot of a pinned ring behind its Adam, and the word of step i is read at the start of step
+        i + STATUS_LAG — by then it has long landed, so the host, which runs a few steps ahead of the device, does not stall —
+        or in drain().  A fixed lag rather than "whenever the copy has landed": the word is the same on every rank (MAX
+        all-reduce), and reading it at the same step makes every rank leave the segmented form at the same step, which the
+        collectives need (the two forms submit different bucket sequences)."""
+        pend = self._status_pending
+        while pend and (wait or len(pend) >= STATUS_LAG):
+            ev, slot = pend.popleft()
+            ev.synchronize()
+            if int(self._status_host[slot]) != 0:
                 self.skipped_steps += 1
-                self.segments_disabled = True
-                import logging
-                logging.getLogger("r2l_amd").warning(
-                    "a segmented training step needed the bf16x3 fallback (fp16 range guard): its update was skipped on every "
-                    "rank; continuing with the uncut backward (chain_segments off)")
+                if not self.segments_disabled:
+                    self.segments_disabled = True
+                    import logging
+                    logging.getLogger("r2l_amd").warning(
+                        "a segmented training step needed the bf16x3 fallback (fp16 range guard): its update was skipped on "
+                        "every rank; continuing with the uncut backward (chain_segments off)")
+
+    def drain(self):
+        """Waits for the validity words of all segmented steps in flight; returns the number of skipped steps so far."""
+        self._check_skipped(wait=True)
+        return self.skipped_steps
 
     def world(self):
         return self.reducer.world()
@@ -237,9 +262,12 @@ class R2LTrainer:
                                            eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
                                            self.reducer.grad_scale(), _ptr(self._guard), _stream()), "r2l_adam_step")
         if self._guard is not None:  # segmented step: its validity word goes to the host behind the update (checked next step)
-            self._status_host.copy_(self._guard, non_blocking=True)
-            self._status_event = torch.cuda.Event()
-            self._status_event.record()
+            slot = self._status_slot
+            self._status_slot = (slot + 1) % STATUS_LAG
+            self._status_host[slot:slot + 1].copy_(self._guard, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._status_pending.append((ev, slot))
             self._guard = None
         eng.mark_dirty()
 

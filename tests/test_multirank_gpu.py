@@ -66,7 +66,7 @@ for step in (1, 2, 3):
     dist.all_reduce(lo)
     assert abs(lo.item() - loss.item()) < 2e-6, (step, lo.item(), loss.item())
     assert parameters_in_sync(tr.eng.flat), step
-assert tr.skipped_steps == 0 and not tr.segments_disabled
+assert tr.drain() == 0 and not tr.segments_disabled
 new = m.state_dict()
 worst, cos = 0., 1.
 for k in ref:

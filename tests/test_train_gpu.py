@@ -300,7 +300,7 @@ def test_segmented_chain_equals_uncut(chain_variant, n, monkeypatch):
         for i in range(3):
             tr.step(o, d, tgt, lr_schedule(i + 1, 5e-4, 500, "0.0001,200"), perturb=1., t_rand=u)
         torch.cuda.synchronize()
-        assert tr.skipped_steps == 0 and not tr.segments_disabled
+        assert tr.drain() == 0 and not tr.segments_disabled
         return g1, gx0, l1, tr.eng.flat.clone()
 
     one = run(1, False)
@@ -316,8 +316,8 @@ def test_segmented_chain_equals_uncut(chain_variant, n, monkeypatch):
 def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, monkeypatch):
     """A segmented step runs without the bf16x3 fallback kernels: when the step belongs to them (here: a head scaled until
     |x_0| ~ 1e5 leaves fp16's range, so the forward falls back and every chain segment raises the status word) the update is
-    skipped ON THE DEVICE — parameters and Adam moments untouched —, the trainer notices one step later without a host sync
-    and goes back to the uncut backward, whose fallback handles the same batch."""
+    skipped ON THE DEVICE — parameters and Adam moments untouched —, the trainer reads the step's validity word a fixed number
+    of steps later and goes back to the uncut backward, whose fallback handles the same batch."""
     if chain_variant != "coopf":
         pytest.skip("one comparison")
     from model.nerf_raybased import PointSampler
@@ -344,10 +344,23 @@ def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, m
     tr.step(o, d, tgt, 1e-4)
     torch.cuda.synchronize()
     assert torch.equal(tr.eng.flat, p0) and torch.equal(tr.exp_avg, m0)  # skipped on the device
-    tr.step(o, d, tgt, 1e-4)  # the trainer has seen the word by now: this one runs uncut, with the fallback kernels
+    assert tr.drain() == 1 and tr.segments_disabled
+    tr.step(o, d, tgt, 1e-4)  # this one runs uncut, with the fallback kernels
     torch.cuda.synchronize()
-    assert tr.skipped_steps == 1 and tr.segments_disabled
     assert not torch.equal(tr.eng.flat, p0) and torch.isfinite(tr.eng.flat).all()
+    # the training loop never synchronises: the host runs steps ahead of the device, and the word of step i is read at the start
+    # of step i + STATUS_LAG (the same step on every rank, so that all ranks leave the segmented form together); every skipped
+    # step is counted (each has its own slot of the pinned ring)
+    from r2l_amd.train_step import STATUS_LAG
+    tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    p0 = tr.eng.flat.clone()
+    for i in range(STATUS_LAG):
+        tr.step(o, d, tgt, 1e-4)
+        assert not tr.segments_disabled
+    assert torch.equal(tr.eng.flat, p0)
+    tr.step(o, d, tgt, 1e-4)  # reads step 1's word first: uncut from here on
+    assert tr.segments_disabled and tr.skipped_steps == 1
+    assert tr.drain() == STATUS_LAG and not torch.equal(tr.eng.flat, p0)
 
 
 def test_generic_mode_backward_after_forward_rays():
