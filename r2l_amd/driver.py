@@ -420,7 +420,7 @@ def main(argv=None):
         n_global = None
         if uneven:  # this step's rays over all ranks: shard rows + what each rank's hard-ray pool appends (deterministic)
             rows = [q * loader.rows_per_file for q in shards]
-            n_global = sum(r + (pool.extra_rays(r, i - start - 1) if pool is not None else 0) for r in rows)
+            n_global = [r + (pool.extra_rays(r, i - start - 1) if pool is not None else 0) for r in rows]
         rgb, loss_out = trainer.step(rays_o, rays_d, target, lr, perturb=args.perturb, n_global=n_global)
         if pool is not None:
             pool.update(rgb, rays_o, rays_d, target, batch_size)

@@ -125,9 +125,13 @@ class R2LTrainer:
     # ---- one optimisation step --------------------------------------------------------------------------------------
     def forward_backward(self, rays_o, rays_d, target, perturb=0., t_rand=None, zero_grad=True, n_global=None):
         """Forward + backward on this rank's rays; leaves d(loss)/d(params) in self.grads. Returns rgb [N,3].
-        n_global: rays of ALL ranks in this step when the ranks' shares differ (--N_rand not divisible by the world size):
-        the gradient is then scaled so that the all-reduced sum, divided by world in Adam, is the reference's single global
-        mean (main.py:1377); None = equal shares (n_global = world * N)."""
+        n_global: when the ranks' shares differ (--N_rand not divisible by the world size), the ray counts of ALL ranks in this
+        step (a sequence, the same on every rank; or just their sum): the gradient is then scaled so that the all-reduced sum,
+        divided by world in Adam, is the reference's single global mean (main.py:1377); None = equal shares
+        (n_global = world * N).
+        Segmented form (chain_segments > 1, small steps): no fallback kernels run, so self.grads is meaningful only if the
+        step's validity word is 0 — step() hands the word to the guarded Adam; a caller that reads self.grads itself asks
+        gradients_valid() first."""
         eng = self.eng
         n = rays_o.shape[0]
         eng.ensure_packed(n)
@@ -144,6 +148,10 @@ class R2LTrainer:
         rgb = eng.forward_rays(rays_o, rays_d, self.ps.z_vals, perturb, t_rand, save=(self.save_x, self.save_t))
         if zero_grad:
             self.grads.zero_()
+        shares = None
+        if n_global is not None and not isinstance(n_global, int):
+            shares = [int(q) for q in n_global]
+            n_global = sum(shares)
         grad_scale = 2.0 * self.lw_rgb / (3.0 * n) if n_global is None else 2.0 * self.lw_rgb * self.world() / (3.0 * n_global)
         args = (_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target), None,
                 _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat), eng.n_block, grad_scale,
@@ -151,7 +159,8 @@ class R2LTrainer:
                 _stream())
         self._guard = None
         self._check_skipped()
-        if self.chain_segments > 1 and zero_grad and not self.segments_disabled and self._segments_ok(n, n_global):
+        if (self.chain_segments > 1 and zero_grad and not self.segments_disabled and
+                self._segments_ok(n, n_global is not None, shares)):
             self._segmented_backward(args)
         elif (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
             # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
@@ -172,15 +181,14 @@ class R2LTrainer:
         return rgb
 
     # ---- segmented dX chain (small steps) -----------------------------------------------------------------------------------
-    def _segments_ok(self, n, n_global):
-        """Does this step take the segmented form?  The answer must be the same on every rank (the forms submit different
-        collectives), so with uneven shares (n_global given) it is asked for both share sizes that occur."""
+    def _segments_ok(self, n, uneven, shares):
+        """Does this step take the segmented form?  The answer must be the same on every rank (the two forms submit different
+        collectives), so with uneven shares it is asked for every share size that occurs — and is "no" when only their sum
+        is known."""
         ok, nb, cfg = self.lib.r2l_chain_segments_ok_cfg, self.eng.n_block, self.eng._cfg()
-        if n_global is None or self.world() == 1:
+        if not uneven or self.world() == 1:
             return bool(ok(int(n), nb, cfg))
-        lo = int(n_global) // self.world()
-        hi = -(-int(n_global) // self.world())
-        return lo > 0 and bool(ok(lo, nb, cfg)) and bool(ok(hi, nb, cfg))
+        return shares is not None and all(q > 0 and bool(ok(q, nb, cfg)) for q in set(shares))
 
     def _segmented_backward(self, args):
         eng, part, cfg, NF = self.eng, self.lib.r2l_backward_part_cfg, self.eng._cfg(), _lib.BWD_NOFALLBACK
@@ -237,6 +245,12 @@ class R2LTrainer:
                     logging.getLogger("r2l_amd").warning(
                         "a segmented training step needed the bf16x3 fallback (fp16 range guard): its update was skipped on "
                         "every rank; continuing with the uncut backward (chain_segments off)")
+
+    def gradients_valid(self):
+        """After forward_backward: False iff this was a segmented step whose chain raised the fp16 range guard (self.grads is
+        then not a gradient; the uncut form — chain_segments = 1 — recomputes such steps on the bf16x3 kernels).  Waits for
+        the device."""
+        return self._guard is None or int(self._guard.item()) == 0
 
     def drain(self):
         """Waits for the validity words of all segmented steps in flight; returns the number of skipped steps so far."""

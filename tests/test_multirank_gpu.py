@@ -51,7 +51,8 @@ for step in (1, 2, 3):
     loss, _, gr = O.r2l_loss_and_grads(ref, emb, tgt)   # ONE process, the full batch
     for k in ref:
         ref[k], mo[k], vo[k] = O.adam_step(ref[k], gr[k], mo[k], vo[k], step, lr)
-    tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda(), n_global=n if uneven else None)
+    tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda(),
+                        n_global=[cut[1] - cut[0], cut[2] - cut[1]] if uneven else None)  # every rank's ray count
     if variant == "coopf":
         # small steps of the default trio at world > 1: the dX chain in 3 segments, each segment's weight gradients and
         # all-reduce on a second stream beside the next segment; + the head bucket + the step-validity word (MAX)

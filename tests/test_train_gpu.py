@@ -330,6 +330,8 @@ def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, m
     d = torch.randn(n, 3, generator=g).cuda()
     tgt = torch.rand(n, 3, generator=g).cuda()
     tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    tr.forward_backward(o, d, tgt)
+    assert tr.gradients_valid()
     tr.step(o, d, tgt, 1e-4)
     torch.cuda.synchronize()
     assert not torch.equal(tr.eng.flat.cpu(), torch.cat([v.reshape(-1) for v in sd.values()]))  # a clean segmented step updates
@@ -341,6 +343,8 @@ def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, m
             sd[k] = sd[k] * 1.0e-5
     tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
     p0, m0 = tr.eng.flat.clone(), tr.exp_avg.clone()
+    tr.forward_backward(o, d, tgt)
+    assert not tr.gradients_valid()  # what a caller that reads tr.grads itself has to ask
     tr.step(o, d, tgt, 1e-4)
     torch.cuda.synchronize()
     assert torch.equal(tr.eng.flat, p0) and torch.equal(tr.exp_avg, m0)  # skipped on the device
