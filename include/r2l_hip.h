@@ -22,6 +22,8 @@ const char* r2l_last_error(void);
  * point).  AUTO fields still honour the R2L_* environment switches of README.md (test / A-B overrides); a non-zero field
  * wins over the environment.  A forward with a stash and the backward that consumes it must be given the same config, and
  * so must the r2l_*_layout_for_cfg queries that decide which weight-stream layout to pack for them.
+ * A field outside its enum / range (or a non-zero reserved word) is an error: launch entry points return
+ * hipErrorInvalidValue (r2l_last_error says which field), the host-side *_for_cfg / *_ok_cfg queries return -1.
  * (The reference has no counterpart: its dtype / device choices are torch globals; this replaces `setenv` for hosts that
  * are not this repo's Python.) */
 enum { R2L_PRECISION_AUTO = 0,
@@ -35,7 +37,7 @@ enum { R2L_TILING_AUTO = 0,
        R2L_TILING_COOPF = 4          /* fp16x2 cooperative kernels (r2l_coopf_*), coop_tiles ray tiles per workgroup       */ };
 enum { R2L_DW_AUTO = 0,
        R2L_DW_FP16 = 1,              /* fp16 trio: weight-gradient GEMMs on the operands' fp16 hi halves, 1 product        */
-       R2L_DW_EXACT = 2              /* fp16 trio: ray-side operand as hi + mid (22 bits), 2 products: fp32-grade dW       */ };
+       R2L_DW_EXACT = 2              /* fp16 trio: both operands as hi + mid (22 bits), 3 products: fp32-grade dW          */ };
 typedef struct r2l_config {
     int precision;    /* R2L_PRECISION_*                                                                                  */
     int tiling;       /* R2L_TILING_*                                                                                     */

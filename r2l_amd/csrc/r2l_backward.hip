@@ -1115,7 +1115,7 @@ extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_TRIO_SLOT(R2L_P
 // May the dX chain of an N-ray step be cut into block segments (R2L_BWD_CHAIN with a layer range)?  1 when the step takes the
 // cooperative fp16 chains (small launches of the default trio), else 0.
 extern "C" int r2l_chain_segments_ok_cfg(int64_t N, int n_block, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_QUERY(cfg);
     return (N > 0 && r2l_chain_variant(N) == R2L_VARIANT_MAIN && r2l_use_fwd3() && r2l_use_trio16() && r2l_use_coopf(N, n_block)) ? 1 : 0;
 }
 // Device word that the fp16 dX chain raises when a step needs the bf16x3 fallback (range guard, or the forward fell back):
@@ -1157,7 +1157,7 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
                                      const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre,
                                      float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
                                      void* stream_, int parts, int layer_lo, int layer_hi, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_ENTER(cfg);
     if (N <= 0) return 0;
     if (layer_lo < 0) layer_lo = 0;
     if (layer_hi > 2 * n_block) layer_hi = 2 * n_block;

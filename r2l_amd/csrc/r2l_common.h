@@ -436,6 +436,30 @@ struct R2LCfgScope {
     explicit R2LCfgScope(const r2l_config* c) : saved(g_r2l_cfg) { if (c) g_r2l_cfg = *c; }
     ~R2LCfgScope() { g_r2l_cfg = saved; }
 };
+// What is wrong with a caller's r2l_config, or nullptr.  Every *_cfg entry point checks before it does anything else:
+// launch entry points fail with hipErrorInvalidValue (R2L_CFG_ENTER), the host-side queries return -1 (R2L_CFG_QUERY).
+static inline const char* r2l_cfg_check(const r2l_config* c) {
+    if (c == nullptr) return nullptr;
+    if (c->precision < 0 || c->precision > R2L_PRECISION_FP32_MFMA) return "r2l_config.precision: not an R2L_PRECISION_* value";
+    if (c->tiling < 0 || c->tiling > R2L_TILING_COOPF) return "r2l_config.tiling: not an R2L_TILING_* value";
+    if (c->coop_tiles < 0 || c->coop_tiles > 2) return "r2l_config.coop_tiles: 0 (auto), 1 or 2";
+    if (c->reserve_cus < -1) return "r2l_config.reserve_cus: -1 (none), 0 (auto) or a CU count";
+    if (c->dw_mode < 0 || c->dw_mode > R2L_DW_EXACT) return "r2l_config.dw_mode: not an R2L_DW_* value";
+    if (c->reserved[0] || c->reserved[1] || c->reserved[2]) return "r2l_config.reserved: must be 0";
+    return nullptr;
+}
+#define R2L_CFG_ENTER(cfg)                                \
+    if (const char* r2l_why_ = r2l_cfg_check(cfg)) {      \
+        r2l_set_error_msg(r2l_why_);                      \
+        return (int)hipErrorInvalidValue;                 \
+    }                                                     \
+    R2LCfgScope scope(cfg)
+#define R2L_CFG_QUERY(cfg)                                \
+    if (const char* r2l_why_ = r2l_cfg_check(cfg)) {      \
+        r2l_set_error_msg(r2l_why_);                      \
+        return -1;                                        \
+    }                                                     \
+    R2LCfgScope scope(cfg)
 static inline bool r2l_env_on(const char* name) {
     const char* e = getenv(name);
     return e && e[0] && e[0] != '0';

@@ -390,7 +390,7 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
 // which chain kernels a fp16-trio launch of N rays takes: 0 = one wave per tile (r2l_fwd2 / r2l_bwd2), 1 / 2 = cooperative with
 // that many ray tiles per workgroup (host-side decision, no device work; include/r2l_hip.h)
 extern "C" int r2l_coop_tiles_for_cfg(int64_t N, int n_block, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_QUERY(cfg);
     if (!r2l_use_coopf(N, n_block)) return 0;
     return r2l_coopf_two_tiles((N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS) ? 2 : 1;
 }

@@ -261,7 +261,7 @@ extern "C" int r2l_forward_rays(const float* rays_o, const float* rays_d, const 
 extern "C" int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                                     const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
                                     float* save_t, int64_t N, void* stream, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_ENTER(cfg);
     R2LFwdArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.wstream = wstream; a.params = params; a.n_block = n_block;
@@ -304,7 +304,7 @@ static int forward_pose_impl(const float* c2w_host12, int64_t n_frames, int H, i
 extern "C" int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float focal, const float* ztab,
                                     const float* wstream, const float* params, int n_block, float* rgb, void* stream,
                                     const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_ENTER(cfg);
     return forward_pose_impl(c2w_host12, 1, H, W, focal, ztab, wstream, params, n_block, rgb, stream);
 }
 
@@ -313,7 +313,7 @@ extern "C" int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float
 extern "C" int r2l_forward_poses_cfg(const float* c2w_dev, int K, int H, int W, float focal, const float* ztab,
                                      const float* wstream, const float* params, int n_block, float* rgb, void* stream,
                                      const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_ENTER(cfg);
     if (K <= 0) return 0;
     const int64_t N = (int64_t)K * H * W;
     if (c2w_dev == nullptr || r2l_chain_variant(N) != R2L_VARIANT_MAIN || r2l_use_coopf(N, n_block)) {

@@ -135,7 +135,7 @@ extern "C" int64_t r2l_bwd_stream_floats(int n_block) {
 // layout: 32 (main + coop kernels), 16 (coop16 kernels) or 0 (both).  A caller that knows which chain variant its next
 // launches use (r2l_variant_for) can skip the other half of the stream: 10 us each, 3 % of a 4096-ray step.
 extern "C" int r2l_variant_for_cfg(int64_t N, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_QUERY(cfg);
     return r2l_chain_variant(N);
 }
 extern "C" int r2l_variant_for(int64_t N) { return r2l_variant_for_cfg(N, nullptr); }
@@ -144,7 +144,7 @@ extern "C" int r2l_variant_for(int64_t N) { return r2l_variant_for_cfg(N, nullpt
 // r2l_fwd2.hip, with the bf16x3 stream as its fallback: forward-only launches)
 extern "C" int r2l_forward_layout_for(int64_t N, int with_stash) { return r2l_forward_layout_for_cfg(N, with_stash, nullptr); }
 extern "C" int r2l_forward_layout_for_cfg(int64_t N, int with_stash, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_QUERY(cfg);
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
     if (v == R2L_VARIANT_MAIN && (with_stash ? r2l_use_trio16() : r2l_use_fwd2())) return 2;
@@ -155,7 +155,7 @@ extern "C" int r2l_forward_layout_for_cfg(int64_t N, int with_stash, const r2l_c
 // chain with the bf16x3 stream behind it as range-guard fallback: r2l_pack_backward_layout(2) fills both)
 extern "C" int r2l_backward_layout_for(int64_t N) { return r2l_backward_layout_for_cfg(N, nullptr); }
 extern "C" int r2l_backward_layout_for_cfg(int64_t N, const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_QUERY(cfg);
     const int v = r2l_chain_variant(N);
     if (v == R2L_VARIANT_COOP16) return 16;
     if (v == R2L_VARIANT_MAIN && r2l_use_fwd3()) return r2l_use_trio16() ? 2 : 3;

@@ -351,7 +351,7 @@ extern "C" int r2l_teacher_mlp(const float* rays_o, const float* rays_d, const f
 extern "C" int r2l_teacher_mlp_cfg(const float* rays_o, const float* rays_d, const float* viewdirs, const float* z,
                                    const float* wstream, const float* params, float* raw, int64_t R, int S, void* stream,
                                    const r2l_config* cfg) {
-    R2LCfgScope scope(cfg);
+    R2L_CFG_ENTER(cfg);
     TeacherArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.z = z; a.wstream = wstream; a.params = params;
     a.raw = raw; a.n_pts = R * (int64_t)S; a.S = S;

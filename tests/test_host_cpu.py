@@ -68,6 +68,35 @@ def test_explicit_config_dispatch(monkeypatch):
     assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_variant_for(98304) == 1
 
 
+def test_invalid_config_is_rejected():
+    """A field outside its enum / range, or a non-zero reserved word: the queries return -1, the launch entry points fail
+    with hipErrorInvalidValue before touching anything (so this runs without a GPU), r2l_last_error names the field."""
+    import ctypes
+    from r2l_amd import _lib
+    lib = _lib.load()
+    bad = []
+    for field, value in (("precision", 4), ("precision", -1), ("tiling", 5), ("coop_tiles", 3), ("reserve_cus", -2),
+                         ("dw_mode", 3)):
+        c = _lib.make_config()
+        setattr(c, field, value)
+        bad.append((field, c))
+    c = _lib.make_config()
+    c.reserved[1] = 7
+    bad.append(("reserved", c))
+    for field, c in bad:
+        r = ctypes.byref(c)
+        assert lib.r2l_variant_for_cfg(4096, r) == -1 and lib.r2l_forward_layout_for_cfg(4096, 1, r) == -1, field
+        assert lib.r2l_backward_layout_for_cfg(4096, r) == -1 and lib.r2l_coop_tiles_for_cfg(4096, 43, r) == -1, field
+        assert lib.r2l_chain_segments_ok_cfg(4096, 43, r) == -1, field
+        rc = lib.r2l_forward_rays_cfg(None, None, None, None, None, None, 43, None, None, None, 4096, None, r)
+        assert rc == 1 and field in lib.r2l_last_error().decode(), (field, rc, lib.r2l_last_error())  # hipErrorInvalidValue
+        assert lib.r2l_forward_pose_cfg(None, 4, 4, 1., None, None, None, 43, None, None, r) == 1
+        assert lib.r2l_forward_poses_cfg(None, 1, 4, 4, 1., None, None, None, 43, None, None, r) == 1
+        assert lib.r2l_teacher_mlp_cfg(None, None, None, None, None, None, None, 4, 4, None, r) == 1
+    ok = _lib.make_config(reserve_cus=-1, coop_tiles=2, dw_mode="exact")
+    assert lib.r2l_variant_for_cfg(4096, ctypes.byref(ok)) >= 0
+
+
 def test_dispatch_and_buffer_size_helpers(monkeypatch):
     """Host-side decisions of the library (no device work): which kernel family / stream layout an N-ray launch takes under
     the environment switches, and the caller-side buffer sizes that go with them."""
