@@ -48,6 +48,11 @@ typedef struct r2l_config {
     int reserved[3];  /* must be 0                                                                                        */
 } r2l_config;
 
+/* Errors: every entry point returning int gives 0 on success, else a hipError_t value (hipErrorInvalidValue = 1 for a NULL
+ * required pointer, a size / n_block (0 .. 1024) / layout / parts argument out of range, or a bad r2l_config — checked before
+ * anything is launched) or R2L_ERR_RCCL_BASE + ncclResult_t; r2l_last_error() holds the text for the calling thread.  N == 0
+ * (R == 0, K == 0) is a successful no-op. */
+
 /* ---- parameter layout ------------------------------------------------------------------------------------------
  * `params` is ONE flat fp32 buffer holding NeRF_v3_2's tensors in state_dict order (model/nerf_raybased.py:500-537):
  *   head.0.weight[256,1008] head.0.bias[256] { body.b.body.0.weight[256,256] .bias[256] body.b.body.2.weight .bias }

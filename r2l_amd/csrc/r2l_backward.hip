@@ -1158,7 +1158,14 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
                                      float* gx, float* gt, float* sqerr_partial, float* grads, float* dw_slab, int64_t N,
                                      void* stream_, int parts, int layer_lo, int layer_hi, const r2l_config* cfg) {
     R2L_CFG_ENTER(cfg);
+    R2L_REQUIRE(N >= 0 && n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_backward_part: N / n_block out of range");
     if (N <= 0) return 0;
+    R2L_REQUIRE((parts & ~(R2L_BWD_ALL | R2L_BWD_NOFALLBACK)) == 0 && (parts & R2L_BWD_ALL) != 0,
+                "r2l_backward_part: parts is an OR of R2L_BWD_CHAIN / BODY / HEAD / TAIL (+ R2L_BWD_NOFALLBACK)");
+    R2L_REQUIRE(rgb && (target || drgb) && save_x && (save_t || n_block == 0) && wstream_bwd && params && dpre && gx &&
+                    (gt || n_block == 0) && grads,
+                "r2l_backward_part: a required pointer is NULL");
+    R2L_REQUIRE(emb != nullptr || (rays_o && rays_d && ztab), "r2l_backward_part: needs emb, or rays_o / rays_d / ztab to recompute it");
     if (layer_lo < 0) layer_lo = 0;
     if (layer_hi > 2 * n_block) layer_hi = 2 * n_block;
     // R2L_BWD_CHAIN with a proper sub-range of the layers: ONE SEGMENT of the dX chain (include/r2l_hip.h)

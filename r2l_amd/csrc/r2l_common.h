@@ -448,6 +448,15 @@ static inline const char* r2l_cfg_check(const r2l_config* c) {
     if (c->reserved[0] || c->reserved[1] || c->reserved[2]) return "r2l_config.reserved: must be 0";
     return nullptr;
 }
+// argument checks of the C ABI: a bad pointer / size is an error code here, not a memory fault on the device
+#define R2L_REQUIRE(cond, msg)                            \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            r2l_set_error_msg(msg);                       \
+            return (int)hipErrorInvalidValue;             \
+        }                                                 \
+    } while (0)
+#define R2L_MAX_BLOCKS 1024  // body blocks of a student net: the kernels address a weight stream (~0.57 MB per block) with 32-bit offsets
 #define R2L_CFG_ENTER(cfg)                                \
     if (const char* r2l_why_ = r2l_cfg_check(cfg)) {      \
         r2l_set_error_msg(r2l_why_);                      \

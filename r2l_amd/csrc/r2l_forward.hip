@@ -262,6 +262,10 @@ extern "C" int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, co
                                     const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
                                     float* save_t, int64_t N, void* stream, const r2l_config* cfg) {
     R2L_CFG_ENTER(cfg);
+    R2L_REQUIRE(N >= 0 && n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_forward_rays: N / n_block out of range");
+    if (N == 0) return 0;
+    R2L_REQUIRE(rays_o && rays_d && ztab && wstream && params && rgb, "r2l_forward_rays: a required pointer is NULL");
+    R2L_REQUIRE((save_x == nullptr) == (save_t == nullptr) || n_block == 0, "r2l_forward_rays: save_x and save_t go together");
     R2LFwdArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
     a.wstream = wstream; a.params = params; a.n_block = n_block;
@@ -305,6 +309,8 @@ extern "C" int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float
                                     const float* wstream, const float* params, int n_block, float* rgb, void* stream,
                                     const r2l_config* cfg) {
     R2L_CFG_ENTER(cfg);
+    R2L_REQUIRE(H > 0 && W > 0 && focal != 0.f && n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_forward_pose: H / W / focal / n_block out of range");
+    R2L_REQUIRE(c2w_host12 && ztab && wstream && params && rgb, "r2l_forward_pose: a required pointer is NULL");
     return forward_pose_impl(c2w_host12, 1, H, W, focal, ztab, wstream, params, n_block, rgb, stream);
 }
 
@@ -315,6 +321,8 @@ extern "C" int r2l_forward_poses_cfg(const float* c2w_dev, int K, int H, int W, 
                                      const r2l_config* cfg) {
     R2L_CFG_ENTER(cfg);
     if (K <= 0) return 0;
+    R2L_REQUIRE(H > 0 && W > 0 && focal != 0.f && n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_forward_poses: H / W / focal / n_block out of range");
+    R2L_REQUIRE(ztab && wstream && params && rgb, "r2l_forward_poses: a required pointer is NULL");
     const int64_t N = (int64_t)K * H * W;
     if (c2w_dev == nullptr || r2l_chain_variant(N) != R2L_VARIANT_MAIN || r2l_use_coopf(N, n_block)) {
         r2l_set_error_msg("r2l_forward_poses: needs a device pose table and a one-wave-per-tile tiling (cooperative tilings: "
@@ -365,6 +373,10 @@ static int forward_pose_impl(const float* c2w_host12, int64_t n_frames, int H, i
 
 extern "C" int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,
                                float* save_x, float* save_t, int64_t N, void* stream) {
+    R2L_REQUIRE(N >= 0 && n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_forward_emb: N / n_block out of range");
+    if (N == 0) return 0;
+    R2L_REQUIRE(emb && wstream && params && rgb, "r2l_forward_emb: a required pointer is NULL");
+    R2L_REQUIRE((save_x == nullptr) == (save_t == nullptr) || n_block == 0, "r2l_forward_emb: save_x and save_t go together");
     R2LFwdArgs a{};
     a.emb = emb; a.wstream = wstream; a.params = params; a.n_block = n_block;
     a.rgb = rgb; a.save_x = save_x; a.save_t = save_t; a.N = N;

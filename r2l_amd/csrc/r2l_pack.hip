@@ -162,6 +162,9 @@ extern "C" int r2l_backward_layout_for_cfg(int64_t N, const r2l_config* cfg) {
     return 32;
 }
 extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* wstream, int layout, void* stream) {
+    R2L_REQUIRE(params && wstream, "r2l_pack_forward_layout: params / wstream is NULL");
+    R2L_REQUIRE(n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_pack_forward_layout: n_block out of range");
+    R2L_REQUIRE(layout == 0 || layout == 32 || layout == 16 || layout == 3 || layout == 2, "r2l_pack_forward_layout: layout is 0, 32, 16, 3 or 2");
     if (layout == 0 || layout == 32) {
         hipLaunchKernelGGL(r2l_pack_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
         R2L_CHECK(hipGetLastError());
@@ -186,6 +189,9 @@ extern "C" int r2l_pack_forward_layout(const float* params, int n_block, float* 
     return 0;
 }
 extern "C" int r2l_pack_backward_layout(const float* params, int n_block, float* wstream, int layout, void* stream) {
+    R2L_REQUIRE(params && wstream, "r2l_pack_backward_layout: params / wstream is NULL");
+    R2L_REQUIRE(n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_pack_backward_layout: n_block out of range");
+    R2L_REQUIRE(layout == 0 || layout == 32 || layout == 16 || layout == 3 || layout == 2, "r2l_pack_backward_layout: layout is 0, 32, 16, 3 or 2");
     if (layout == 0 || layout == 32) {
         hipLaunchKernelGGL(r2l_pack_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
         R2L_CHECK(hipGetLastError());
@@ -211,6 +217,8 @@ extern "C" int r2l_pack_backward_layout(const float* params, int n_block, float*
 }
 
 extern "C" int r2l_pack_forward(const float* params, int n_block, float* wstream, void* stream) {
+    R2L_REQUIRE(params && wstream, "r2l_pack_forward: params / wstream is NULL");
+    R2L_REQUIRE(n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_pack_forward: n_block out of range");
     hipLaunchKernelGGL(r2l_pack_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
     R2L_CHECK(hipGetLastError());
     hipLaunchKernelGGL(r2l_pack_fwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,
@@ -225,6 +233,8 @@ extern "C" int r2l_pack_forward(const float* params, int n_block, float* wstream
 }
 
 extern "C" int r2l_pack_backward(const float* params, int n_block, float* wstream, void* stream) {
+    R2L_REQUIRE(params && wstream, "r2l_pack_backward: params / wstream is NULL");
+    R2L_REQUIRE(n_block >= 0 && n_block <= R2L_MAX_BLOCKS, "r2l_pack_backward: n_block out of range");
     hipLaunchKernelGGL(r2l_pack_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, wstream, n_block);
     R2L_CHECK(hipGetLastError());
     hipLaunchKernelGGL(r2l_pack_bwd16_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params,

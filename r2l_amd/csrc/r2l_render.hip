@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* _
 extern "C" int r2l_stratified_z(const float* near, const float* far, int nf_stride, const float* ttab,
                                 const float* t_rand, float* z_out, int64_t R, int S, void* stream) {
     if (R <= 0) return 0;
+    R2L_REQUIRE(near && far && ttab && z_out && S >= 1, "r2l_stratified_z: NULL pointer or S < 1");
     int64_t blocks = (R * S + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(r2l_stratified_z_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, near, far,
@@ -237,6 +238,7 @@ extern "C" int r2l_raw2outputs(const float* raw, const float* z, const float* ra
                                int64_t R, int S, void* stream) {
     if (R <= 0) return 0;
     if (S < 1 || S > 64 * MAX_CH) { r2l_set_error("r2l_raw2outputs: S out of range [1,256]", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
+    R2L_REQUIRE(raw && z && rays_d && rgb_map && disp_map && acc_map && depth_map, "r2l_raw2outputs: a required pointer is NULL (only noise and weights are optional)");
     hipLaunchKernelGGL(r2l_raw2outputs_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z,
                        rays_d, noise, white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map, R, S);
     R2L_CHECK(hipGetLastError());
@@ -251,6 +253,7 @@ extern "C" int r2l_sample_pdf_sort(const float* z, const float* weights, const f
         r2l_set_error("r2l_sample_pdf_sort: need 3<=S<=64, 1<=NI<=192, S+NI<=256", hipErrorInvalidValue);
         return (int)hipErrorInvalidValue;
     }
+    R2L_REQUIRE(z && weights && u && z_samples && z_all && u_stride >= 0, "r2l_sample_pdf_sort: a required pointer is NULL (only z_std is optional) or u_stride < 0");
     hipLaunchKernelGGL(r2l_sample_pdf_sort_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z,
                        weights, u, u_stride, z_samples, z_all, z_std, R, S, NI);
     R2L_CHECK(hipGetLastError());

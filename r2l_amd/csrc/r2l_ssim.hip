@@ -87,6 +87,7 @@ int r2l_ssim(const float* img1, const float* img2, int H, int W, int C, const fl
         r2l_set_error_msg("r2l_ssim: bad image shape");
         return 1;
     }
+    R2L_REQUIRE(img1 && img2 && partial && out, "r2l_ssim: a required pointer is NULL");
     SsimWindow win;
     if (window_host) {
         for (int i = 0; i < SS_WIN * SS_WIN; ++i) win.w[i] = window_host[i];

@@ -337,6 +337,7 @@ extern "C" int64_t r2l_teacher_stream_floats(void) {
 }
 
 extern "C" int r2l_pack_teacher(const float* params, float* wstream, void* stream) {
+    R2L_REQUIRE(params && wstream, "r2l_pack_teacher: tparams / wstream is NULL");
     hipLaunchKernelGGL(r2l_pack_teacher_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, params, wstream);
     R2L_CHECK(hipGetLastError());
     const int rc = r2l_teacher3_pack(params, wstream + t_stream32_floats(), (hipStream_t)stream);
@@ -352,6 +353,9 @@ extern "C" int r2l_teacher_mlp_cfg(const float* rays_o, const float* rays_d, con
                                    const float* wstream, const float* params, float* raw, int64_t R, int S, void* stream,
                                    const r2l_config* cfg) {
     R2L_CFG_ENTER(cfg);
+    R2L_REQUIRE(R >= 0 && S >= 0, "r2l_teacher_mlp: negative R / S");
+    if (R == 0 || S == 0) return 0;
+    R2L_REQUIRE(rays_o && rays_d && viewdirs && z && wstream && params && raw, "r2l_teacher_mlp: a required pointer is NULL");
     TeacherArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.z = z; a.wstream = wstream; a.params = params;
     a.raw = raw; a.n_pts = R * (int64_t)S; a.S = S;

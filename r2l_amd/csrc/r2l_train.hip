@@ -29,6 +29,8 @@ extern "C" int r2l_adam_step_guarded(float* params, const float* grads, float* e
                                      float beta1, float beta2, float eps, int step, float grad_scale, const unsigned* skip_if,
                                      void* stream) {
     if (n <= 0) return 0;
+    R2L_REQUIRE(params && grads && exp_avg && exp_avg_sq, "r2l_adam_step: a buffer is NULL");
+    R2L_REQUIRE(step >= 1, "r2l_adam_step: step counts from 1");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(r2l_adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
@@ -58,6 +60,7 @@ __global__ void r2l_loss_finish_kernel(const float* __restrict__ partial, int64_
 
 extern "C" int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_denom, float* out2,
                                void* stream) {
+    R2L_REQUIRE(out2 && (sqerr_partial || n_partial <= 0) && n_partial >= 0, "r2l_loss_finish: NULL buffer / negative count");
     hipLaunchKernelGGL(r2l_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sqerr_partial, n_partial,
                        inv_denom, out2);
     R2L_CHECK(hipGetLastError());

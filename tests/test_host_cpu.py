@@ -97,6 +97,51 @@ def test_invalid_config_is_rejected():
     assert lib.r2l_variant_for_cfg(4096, ctypes.byref(ok)) >= 0
 
 
+def test_bad_arguments_are_error_codes_not_device_faults():
+    """NULL required pointers and out-of-range sizes are rejected with hipErrorInvalidValue before anything is launched (so
+    this needs no GPU); empty inputs are successful no-ops."""
+    from r2l_amd import _lib
+    lib = _lib.load()
+    INVALID = 1
+    one = ctypes.c_void_p(64)  # any non-NULL value: the checks below fail before it is ever dereferenced
+    assert lib.r2l_forward_rays(None, None, None, None, None, None, 43, None, None, None, 0, None) == 0  # N = 0
+    assert lib.r2l_forward_rays(None, one, None, one, one, one, 43, one, None, None, 32, None) == INVALID
+    assert b"r2l_forward_rays" in lib.r2l_last_error()
+    assert lib.r2l_forward_rays(one, one, None, one, one, one, 43, one, one, None, 32, None) == INVALID  # save_x without save_t
+    assert lib.r2l_forward_rays(one, one, None, one, one, one, -1, one, None, None, 32, None) == INVALID
+    assert lib.r2l_forward_rays(one, one, None, one, one, one, 43, one, None, None, -5, None) == INVALID
+    assert lib.r2l_forward_pose(one, 0, 400, 555., one, one, one, 43, one, None) == INVALID
+    assert lib.r2l_forward_pose(None, 400, 400, 555., one, one, one, 43, one, None) == INVALID
+    assert lib.r2l_forward_poses_cfg(one, 0, 400, 400, 555., one, one, one, 43, one, None, None) == 0  # K = 0
+    assert lib.r2l_forward_poses_cfg(one, 2, 400, 400, 555., None, one, one, 43, one, None, None) == INVALID
+    assert lib.r2l_forward_emb(None, one, one, 43, one, None, None, 32, None) == INVALID
+    assert lib.r2l_pack_forward(None, 43, one, None) == INVALID and lib.r2l_pack_backward(one, 43, None, None) == INVALID
+    assert lib.r2l_pack_forward_layout(one, 43, one, 5, None) == INVALID and lib.r2l_pack_backward_layout(one, 5000, one, 2, None) == INVALID
+    args = [one] * 12 + [43, 1e-5] + [one] * 6 + [4096, None]
+    assert lib.r2l_backward_part(*args, 0, 0, 86) == INVALID and lib.r2l_backward_part(*args, 64, 0, 86) == INVALID  # parts
+    bad = list(args)
+    bad[5] = None  # rgb
+    assert lib.r2l_backward_part(*bad, 15, 0, 86) == INVALID
+    bad = list(args)
+    bad[4] = bad[0] = None  # neither emb nor rays
+    assert lib.r2l_backward_part(*bad, 15, 0, 86) == INVALID
+    bad = list(args)
+    bad[20] = 0  # N = 0
+    assert lib.r2l_backward_part(*bad, 15, 0, 86) == 0
+    assert lib.r2l_adam_step(None, one, one, one, 10, 1e-3, .9, .999, 1e-8, 1, 1., None) == INVALID
+    assert lib.r2l_adam_step(one, one, one, one, 10, 1e-3, .9, .999, 1e-8, 0, 1., None) == INVALID  # step counts from 1
+    assert lib.r2l_adam_step(None, None, None, None, 0, 1e-3, .9, .999, 1e-8, 1, 1., None) == 0
+    assert lib.r2l_loss_finish(one, 3, 1., None, None) == INVALID
+    assert lib.r2l_pack_teacher(None, one, None) == INVALID
+    assert lib.r2l_teacher_mlp(one, one, one, one, one, one, None, 4, 64, None) == INVALID
+    assert lib.r2l_teacher_mlp(None, None, None, None, None, None, None, 0, 64, None) == 0
+    assert lib.r2l_stratified_z(None, one, 1, one, None, one, 4, 64, None) == INVALID
+    assert lib.r2l_raw2outputs(one, one, one, None, 1, one, one, one, None, None, 4, 64, None) == INVALID  # depth_map
+    assert lib.r2l_raw2outputs(one, one, one, None, 1, one, one, one, None, one, 4, 300, None) == INVALID
+    assert lib.r2l_sample_pdf_sort(one, one, None, 0, one, one, None, 4, 64, 128, None) == INVALID  # u
+    assert lib.r2l_ssim(one, None, 8, 8, 3, None, one, one, None) == INVALID
+
+
 def test_dispatch_and_buffer_size_helpers(monkeypatch):
     """Host-side decisions of the library (no device work): which kernel family / stream layout an N-ray launch takes under
     the environment switches, and the caller-side buffer sizes that go with them."""
