@@ -1105,6 +1105,10 @@ __global__ __launch_bounds__(1024) void r2l_gscale_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
+// the 16 status words behind the fp16 dX stream: cleared at the start of every step
+__global__ void r2l_status_clear_kernel(unsigned* status) {
+    if (threadIdx.x < 16) status[threadIdx.x] = 0u;
+}
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 // (+ 16 floats of status words behind the partials)
@@ -1238,7 +1242,10 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         }
         if (trio16) {
             if (!chain_seg || layer_hi == 2 * n_block) {  // (the first segment opens the step)
-                R2L_CHECK(hipMemsetAsync(bwd_status, 0, 64, stream));
+                // (a kernel, not hipMemsetAsync: a memset node captured into a hipGraph wrote a stale 16-byte pattern instead
+                // of zeros on replay — ROCm 7.0 —, which sent every replayed step to the fallback kernels)
+                hipLaunchKernelGGL(r2l_status_clear_kernel, dim3(1), dim3(64), 0, stream, bwd_status);
+                R2L_CHECK(hipGetLastError());
                 if (scale_dev != nullptr) {
                     hipLaunchKernelGGL(r2l_gscale_kernel, dim3(1), dim3(1024), 0, stream, drgb, 3 * N, const_cast<float*>(scale_dev));
                     R2L_CHECK(hipGetLastError());

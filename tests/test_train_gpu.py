@@ -544,3 +544,43 @@ def test_mid_size_step_on_cooperative_chains(chain_variant, monkeypatch):
     assert abs(auto[0][0].item() - main[0][0].item()) < 1e-6
     assert (auto[1] - main[1]).abs().max().item() < 2e-6 and (auto[3] - main[3]).abs().max().item() < 2e-6
     assert torch.nn.functional.cosine_similarity(auto[2], main[2], dim=0).item() > 0.9999
+
+
+def test_forward_backward_is_graph_capturable(chain_variant):
+    """INTEGRATION.md "graph-capturable": forward + stash + backward enqueue kernels and async memsets only (no host sync, no
+    allocation inside the library), so a hipGraph captured around them replays to bit-identical gradients — also after the
+    inputs behind the captured pointers change."""
+    if chain_variant not in ("main", "coopf", "main-exact"):
+        pytest.skip("three families")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=5, seed=9)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    n = 4096 if chain_variant == "coopf" else 40000
+    g = torch.Generator().manual_seed(4)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+    u = torch.rand(n, 16, generator=g).cuda()
+    tr = R2LTrainer(build_model(sd, 5), ps, dw_mode="exact" if chain_variant.endswith("exact") else None)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up on the capture stream: lazy packs, buffer growth, occupancy queries
+        tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager, loss = tr.grads.clone(), tr.loss_out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    tr.grads.fill_(7.)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grads, eager) and torch.equal(tr.loss_out, loss)
+    tgt.copy_(torch.rand(n, 3, generator=g))  # new targets behind the same pointer
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = tr.grads.clone()
+    tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grads, replayed) and not torch.equal(replayed, eager)
