@@ -7,7 +7,12 @@
 #define T2_W 256
 #define T2_XYZ 63
 #define T2_DIR 27
-#define T2_STAGES 164
+// 145 stages of the 256-wide layers + the views layer (128 outputs = four of a stage's eight tile slots): its bias stage and
+// nine DOUBLE stages, each holding TWO k-blocks (tile slots 0-3: tiles 0-3 of k-block 2j, slots 4-7: tiles 0-3 of k-block
+// 2j + 1; eight feature pairs, then the two direction blocks) — both halves of such a stage accumulate into tiles 0-3, the
+// second with its own B operand.  (Round 2 ran the layer as 19 ordinary stages whose slots 4-7 held zeros: 5.5 % of the
+// launch's matrix work.)
+#define T2_STAGES 155
 
 struct T2Off {
     int64_t w[8], b[8], views_w, views_b, feat_w, feat_b, alpha_w, alpha_b, rgb_w, rgb_b, total;
@@ -83,9 +88,10 @@ __global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsig
             const int r = g - 145;
             views = true;
             if (r == 0) { kind = 0; boff = off.views_b; }
-            else if (r <= 16) { kind = 3; kb = r - 1; }
-            else { kind = 4; kb = r - 17; }
+            else if (r <= 8) { kind = 3; kb = 2 * (r - 1) + (tile >> 2); }  // double stage: k-blocks 2j (slots 0-3), 2j+1 (4-7)
+            else { kind = 4; kb = tile >> 2; }
         }
+        const int ov = 32 * (tile & 3) + i;  // output row of a views-layer double stage
         float w = 0.f;
         bool have = false;
         if (kind == 0) {
@@ -103,10 +109,11 @@ __global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsig
         } else if (kind == 3) {
             const int T = kb >> 1, r = kb & 1;
             const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
-            if (tile < 4) { w = params[off.views_w + (int64_t)o * (T2_W + T2_DIR) + in]; have = true; }
+            w = params[off.views_w + (int64_t)ov * (T2_W + T2_DIR) + in];
+            have = true;
         } else if (kind == 4) {
             const int col = t2_emb_col(8 * kb + s, h, 2);
-            if (tile < 4 && col >= 0) { w = params[off.views_w + (int64_t)o * (T2_W + T2_DIR) + T2_W + col]; have = true; }
+            if (col >= 0) { w = params[off.views_w + (int64_t)ov * (T2_W + T2_DIR) + T2_W + col]; have = true; }
         }
         unsigned short v0 = 0, v1 = 0;
         if (have) {
@@ -182,6 +189,81 @@ struct T2Select {
         for (int s = 0; s < 4; ++s) v[s] = first ? v[s] : w[s];
     }
 };
+
+// ---- double stages (views layer) ---------------------------------------------------------------------------------------
+// F2Side (r2l_f2.h) with TWO gatherers: the four B values of the next stage's k-block A in steps 0-3 and of its k-block B in
+// steps 2-5 (gather, hi, residual, mid each).
+template <bool BIAS_A, class GA, class GB>
+struct T2SideV {
+    F2A4& a;
+    const unsigned char* lb;
+    int half;
+    GA ga;
+    GB gb;
+    bool want_b;
+    F3Dma dma;
+    float& amax;
+    float xa[4], xb[4];
+    unsigned uha[2], uma[2], uhb[2], umb[2];
+    typedef F2Side<false, F3None> S;
+    __device__ __forceinline__ void loads(int i) {
+#pragma unroll
+        for (int k = 2 * i; k < 2 * i + 2; ++k) {
+            if (k >= (BIAS_A ? 4 : 8)) continue;
+            const int tt = BIAS_A ? k : k / 2, sp = BIAS_A ? 0 : k % 2;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(lb + (sp * 8 + 4 * half + tt) * 1024);
+            if (sp == 0) a.h[tt] = v;
+            else a.m[tt] = v;
+        }
+    }
+    static __device__ __forceinline__ void track(float& amax, const float (&x)[4]) {
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+    }
+    static __device__ __forceinline__ void residual(float (&x)[4], const unsigned (&u)[2]) {
+        x[0] = f2_res_lo(u[0], x[0]); x[1] = f2_res_hi(u[0], x[1]);
+        x[2] = f2_res_lo(u[1], x[2]); x[3] = f2_res_hi(u[1], x[3]);
+    }
+    __device__ __forceinline__ void step(int i) {
+        loads(i);
+        if (dma.on && i < 4) {
+            if (i == 0) f2_dma_base(dma.la);
+            f2_dma_piece_i(i, dma.rs, dma.voff, dma.so);
+        }
+        if (!want_b) return;
+        if (i == 0) { ga(xa); track(amax, xa); }
+        else if (i == 1) { uha[0] = S::pk(xa[0], xa[1]); uha[1] = S::pk(xa[2], xa[3]); }
+        else if (i == 2) residual(xa, uha);
+        else if (i == 3) { uma[0] = S::pk(xa[0], xa[1]); uma[1] = S::pk(xa[2], xa[3]); }
+        if (i == 2) { gb(xb); track(amax, xb); }
+        else if (i == 3) { uhb[0] = S::pk(xb[0], xb[1]); uhb[1] = S::pk(xb[2], xb[3]); }
+        else if (i == 4) residual(xb, uhb);
+        else if (i == 5) { umb[0] = S::pk(xb[0], xb[1]); umb[1] = S::pk(xb[2], xb[3]); }
+    }
+};
+// One stage whose successor is a double stage (or the padding, BIAS_NEXT): acc (+)= stage k, and the B operands of BOTH
+// k-blocks of stage k+1 are gathered (P.sb <- k-block A from galo / gahi, sb2 <- k-block B from gblo / gbhi).
+// VCUR: stage k is itself a double stage — its second half multiplies tile slots 4-7 by sb2 into tiles 0-3.
+template <bool BIAS_K, bool ZERO_K, bool VCUR, bool BIAS_NEXT, class GAlo, class GBlo, class GAhi, class GBhi>
+__device__ __forceinline__ void t2_vstage(f32x16 (&acc)[R2L_NT], F2Pipe& P, F2Split& sb2, GAlo galo, GBlo gblo, GAhi gahi,
+                                          GBhi gbhi) {
+    static_assert(!(BIAS_K && VCUR), "a bias stage is an ordinary stage");
+    T2SideV<BIAS_K, GAlo, GBlo> sa{P.a2, P.lb, 1, galo, gblo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax};
+    f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    P.sync_next();
+    T2SideV<BIAS_NEXT, GAhi, GBhi> sb{P.a1, P.lb, 0, gahi, gbhi, !BIAS_NEXT, P.request(), P.amax};
+    f2_mfma_half<BIAS_K, ZERO_K>(acc, VCUR ? 0 : 1, P.a2, VCUR ? sb2 : P.sb, sb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (BIAS_NEXT) {
+        P.sb = P.ones;
+    } else {
+        P.sb.h = __builtin_bit_cast(f16x8, u32x4{sa.uha[0], sa.uha[1], sb.uha[0], sb.uha[1]});
+        P.sb.m = __builtin_bit_cast(f16x8, u32x4{sa.uma[0], sa.uma[1], sb.uma[0], sb.uma[1]});
+        sb2.h = __builtin_bit_cast(f16x8, u32x4{sa.uhb[0], sa.uhb[1], sb.uhb[0], sb.uhb[1]});
+        sb2.m = __builtin_bit_cast(f16x8, u32x4{sa.umb[0], sa.umb[1], sb.umb[0], sb.umb[1]});
+    }
+}
 
 __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
@@ -295,15 +377,18 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
     }
 
     // ---- views layer: v[128] = Wv [feature, dir-embedding] + bv in tiles 0-3 of t (ReLU applied by the rgb head) ---------
+    // bias stage, then nine double stages (two k-blocks each: feature pairs (2j, 2j+1) = fragment registers 0-7 / 8-15 of
+    // tile j, then the two direction blocks); every stage gathers both B operands of its successor
     typedef F3Take4<false> Id4;
-    f2_stage<true, true, false>(t, P, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 4, nullptr, 0});
+    F2Split sb2 = P.ones;
+    t2_vstage<true, true, false, false>(t, P, sb2, Id4{x[0], 0, nullptr, 0}, Id4{x[0], 8, nullptr, 0}, Id4{x[0], 4, nullptr, 0},
+                                        Id4{x[0], 12, nullptr, 0});
 #pragma unroll
-    for (int kb = 0; kb < 15; ++kb)
-        f2_stage<false, false, false>(t, P, Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
-                                      Id4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
-    f2_stage<false, false, false>(t, P, Dir4{vd, h, 0}, Dir4{vd, h, 4});
-    f2_stage<false, false, false>(t, P, Dir4{vd, h, 8}, Dir4{vd, h, 12});
-    f2_stage<false, false, true>(t, P, F3None{}, F3None{});  // next: stream padding
+    for (int j = 1; j < 8; ++j)
+        t2_vstage<false, false, true, false>(t, P, sb2, Id4{x[j], 0, nullptr, 0}, Id4{x[j], 8, nullptr, 0},
+                                             Id4{x[j], 4, nullptr, 0}, Id4{x[j], 12, nullptr, 0});
+    t2_vstage<false, false, true, false>(t, P, sb2, Dir4{vd, h, 0}, Dir4{vd, h, 8}, Dir4{vd, h, 4}, Dir4{vd, h, 12});
+    t2_vstage<false, false, true, true>(t, P, sb2, F3None{}, F3None{}, F3None{}, F3None{});  // next: stream padding
 
     // rgb = Wrgb relu(v) + b
     float acc3[3] = {0.f, 0.f, 0.f};
