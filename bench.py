@@ -34,6 +34,11 @@ FWD_FLOP_PER_RAY = 2 * (1008 * 256 + 86 * 256 * 256 + 256 * 3)  # 11 789 824 (BA
 TRAIN_FLOP_PER_RAY = 2 * (3 * 5894912 - 258048)  # 34 853 376: fwd + dX + dW, no dX for the head
 PEAK_FP32_MFMA = 157.3  # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md chip table (exact-fp32 MFMA)
 PEAK_BF16_MFMA = 2500.0  # TFLOP/s dense bf16 MFMA (same guide; the sparsity-inflated headline figure is not used)
+# What an MFMA-ONLY stream sustains on this chip with random operand mantissas (tools/mfma_power_probe.hip, every SIMD issuing
+# nothing but v_mfma_f32_32x32x16 on register operands; profiles/r03_mfma_power_probe.txt): the datasheet rate is reached on
+# zero operands only, the power cap holds random data to these product rates.  Reported beside `peak`, never instead of it.
+SUSTAINED_FP16_MFMA_ONLY = 1770.0  # TFLOP/s of fp16 products
+SUSTAINED_BF16_MFMA_ONLY = 1920.0
 H = W = 400
 FOCAL = 555.5555155968841
 FRAMES_PER_STEP = 9  # driver.POSES_PER_LAUNCH: test frames per render launch
@@ -377,6 +382,11 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_fp32_mfma": PEAK_FP32_MFMA,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
+                     "frac_of_measured_mfma_only_rate": (achieved * 3. / SUSTAINED_FP16_MFMA_ONLY if fwd2 else
+                                                         (achieved * 6. / SUSTAINED_BF16_MFMA_ONLY if fwd3 else None)),
+                     "measured_mfma_only_rate_note": "an MFMA-only stream with random operand mantissas sustains 1.77 PF/s of fp16 / "
+                                                     "1.92 PF/s of bf16 products on this chip under its power cap (2.48 on zero operands): "
+                                                     "profiles/r03_mfma_power_probe.txt, tools/mfma_power_probe.hip",
                      "peak_note": peak_note,
                      "traffic": traffic,
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
