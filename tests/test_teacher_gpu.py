@@ -320,3 +320,54 @@ def test_teacher_range_guard_falls_back(mlp_path, monkeypatch):
     assert torch.equal(raw1, raw3) and torch.equal(raw2, raw3)
     # with 1e5-sized activations the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 layer behind it
     assert (raw1[:64] - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("variant", ["black_bkgd", "coarse_only", "one_net", "retraw", "jitter_fixed"])
+def test_render_rays_option_variants_vs_cpu_mirror(mlp_path, variant):
+    """The reference's render_rays options off the create_data defaults (create_data.py:405-544: white_bkgd=False,
+    N_importance=0, network_fine=None -> the coarse net evaluates the fine pass, retraw=True, perturb=1 with given uniforms): the
+    HIP kernels against the torch-op branch of the SAME mirror on CPU tensors, which tests/test_render_cpu.py pins to the
+    reference's goldens."""
+    from model.nerf_raybased import NeRF
+    from r2l_amd.render import get_embedder, render_rays, run_network
+    sds = O.make_teacher_state_dicts(11, 2, alpha_bias=0.5)
+    cpu_nets = []
+    for sd in sds:
+        m = NeRF(D=8, W=256, input_ch=63, output_ch=4, skips=[4], input_ch_views=27, use_viewdirs=True)
+        m.load_state_dict(sd)
+        cpu_nets.append(m)
+    gpu_nets = [make_teacher(sd) for sd in sds]
+    e10, _ = get_embedder(10)
+    e4, _ = get_embedder(4)
+    qfn = lambda pts, vd, fn: run_network(pts, vd, fn, embed_fn=e10, embeddirs_fn=e4)
+    rb = scene_rays(257, 0)  # (ragged: not a multiple of the kernels' tiles)
+    kw = dict(N_importance=128, white_bkgd=True, perturb=0.)
+    fine = [cpu_nets[1], gpu_nets[1]]
+    if variant == "black_bkgd":
+        kw["white_bkgd"] = False
+    elif variant == "coarse_only":
+        kw["N_importance"] = 0
+    elif variant == "one_net":
+        fine = [None, None]
+    elif variant == "retraw":
+        kw["retraw"] = True
+    elif variant == "jitter_fixed":
+        kw.update(perturb=1., pytest=True)  # np.random.seed(0) uniforms on both sides (create_data.py:477-480, helpers:301-309)
+    with torch.no_grad():
+        ref = render_rays(rb, cpu_nets[0], qfn, 64, network_fine=fine[0], **kw)
+        out = render_rays(rb.cuda(), gpu_nets[0], None, 64, network_fine=fine[1], **kw)
+        if variant == "black_bkgd":  # (lindisp sampling — LLFF scenes — is outside the accelerated path: loud on either device)
+            for dev_rb, net, q in ((rb, cpu_nets[0], qfn), (rb.cuda(), gpu_nets[0], None)):
+                with pytest.raises(NotImplementedError):
+                    render_rays(dev_rb, net, q, 64, lindisp=True)
+    assert set(out) == set(ref), (sorted(out), sorted(ref))
+    for k in ref:
+        a, b = out[k].cpu(), ref[k]
+        assert a.shape == b.shape, k
+        if k == "z_std" and kw["perturb"] == 0.:
+            continue  # det=True: the last sample has two admissible values (test_sample_pdf_sort_golden checks membership)
+        nan = torch.isnan(b)
+        assert torch.equal(torch.isnan(a), nan), k
+        bar = 2e-3 if k == "raw" else (5e-4 if k.startswith("disp") else 1e-4)  # raw sigma ~ 30: fp32 noise of a 256-term sum; disp = 1 / depth
+        err = (a[~nan] - b[~nan]).abs().max().item() if (~nan).any() else 0.
+        assert err < bar, (variant, k, err)
