@@ -103,3 +103,40 @@ def test_training_step_of_393216_rays_is_the_sum_of_its_chunks(dw_mode):
     worst = max(rel_err(a[name], b[name]) for name in sd)
     print("393 216 rays vs 4 chunks: worst per-tensor relative L2", worst)
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("n", [8192, 8193, 16384, 16385, 32768, 32769, 49152, 49153])
+def test_dispatch_thresholds_forward_and_gradient(n, monkeypatch):
+    """AUTO dispatch at the ray counts where the library changes kernel family (one tile per cooperative workgroup -> two at
+    8192 / 8193 rays, cooperative -> one wave per tile at 16 384 / 16 385, the 32 769 .. 49 152 window of the two-tile kernels):
+    the launch on either side of every threshold agrees with the oracle (first and last 128 rays) and its gradient with the
+    one-wave-per-tile family pinned by r2l_config."""
+    for k in ("R2L_FORCE_VARIANT", "R2L_COOPF_TILES", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
+        monkeypatch.delenv(k, raising=False)
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    from tests.test_train_gpu import rel_err, split_flat
+    nb = 3
+    sd = O.make_state_dict(n_block=nb, seed=6)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    g = torch.Generator().manual_seed(n)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda()
+    u = torch.rand(n, 16, generator=g).cuda()
+    m = build_model(sd, nb)
+    tr = R2LTrainer(m, ps)
+    tiles = tr.lib.r2l_coop_tiles_for_cfg(n, nb, tr.eng._cfg())
+    assert tiles == {8192: 1, 8193: 2, 16384: 2, 16385: 0, 32768: 0, 32769: 2, 49152: 2, 49153: 0}[n]
+    rgb = tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    auto = tr.grads.clone()
+    pick = torch.cat([torch.arange(128), torch.arange(n - 128, n)])
+    emb = O.positional_embed(O.sample_train(o[pick].cpu(), d[pick].cpu(), O.z_vals(16, 2., 6.), 1., t_rand=u[pick].cpu()), 10)
+    assert (rgb[pick.cuda()].cpu() - O.r2l_forward(sd, emb)).abs().max().item() < 1e-4
+    pinned = R2LTrainer(build_model(sd, nb), ps)
+    pinned.eng.set_config(tiling="main")
+    rgb2 = pinned.forward_backward(o, d, tgt, perturb=1., t_rand=u)
+    assert (rgb2 - rgb).abs().max().item() < 2e-6
+    a, b = split_flat(auto.cpu(), sd), split_flat(pinned.grads.cpu(), sd)
+    worst = max(rel_err(a[k], b[k]) for k in sd)
+    assert worst < 2e-4, worst  # two fp16x2 families: same products, different summation order over rays
