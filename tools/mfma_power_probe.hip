@@ -75,6 +75,33 @@ int main() {
     hipEventCreate(&e1);
     const char* classes[4] = {"zeros", "one bit per value (1.0 / 2^-12)", "random, |x| ~ 1 (hi-like)", "random, |x| ~ 2^-12 (mid-like)"};
     const int long_run = getenv("PROBE_LONG") ? atoi(getenv("PROBE_LONG")) : 1;  // x the ~25 ms base duration
+    if (getenv("PROBE_ONE")) {  // PROBE_ONE="<bf16 0|1> <class 0..3> <rotating 0|1> <mantissa bits kept>": one case, for tools/mfma_power_trace.py
+        int bf = 0, cls = 2, rot = 1, keep = 10;
+        sscanf(getenv("PROBE_ONE"), "%d %d %d %d", &bf, &cls, &rot, &keep);
+        srand(7);
+        const unsigned short mask = (unsigned short)(0xffffu << (10 - keep));
+        for (int i = 0; i < n16; ++i) {
+            float v = 0.f;
+            const float sgn = (rand() & 1) ? 1.f : -1.f, r = 0.5f + 0.5f * (float)rand() / (float)RAND_MAX;
+            if (cls == 1) v = ((i / (256 * 8)) >= 8) ? 1.0f : 0.000244140625f;
+            if (cls == 2) v = sgn * 2.f * r;
+            if (cls == 3) v = sgn * r * 0.000244140625f;
+            host[i] = bf ? f2b(v) : (unsigned short)(f2h(v) & mask);
+        }
+        hipMemcpy(dev, host, n16 * 2, hipMemcpyHostToDevice);
+        const int iters = 60000 * long_run;
+        hipEventRecord(e0);
+        if (bf && rot) hipLaunchKernelGGL((stream_kernel<true, true>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
+        else if (bf) hipLaunchKernelGGL((stream_kernel<true, false>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
+        else if (rot) hipLaunchKernelGGL((stream_kernel<false, true>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
+        else hipLaunchKernelGGL((stream_kernel<false, false>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%.2f ms %.3f PF/s\n", ms, (double)wgs * 4 * iters * 32.0 * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e15);
+        return 0;
+    }
     printf("%-6s %-9s %-36s %10s %12s\n", "type", "operands", "operand data", "ms", "PF/s");
     for (int rot = 0; rot < 2; ++rot)
     for (int bf = 0; bf < 2; ++bf)
