@@ -218,7 +218,7 @@ int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_den
  * tparams: flat fp32 state_dict-order buffer of NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
  * (model/nerf_raybased.py:357-375, built at utils/create_data.py:251-265): pts_linears.{0..7}, views_linears.0,
  * feature_linear, alpha_linear, rgb_linear. */
-int64_t r2l_teacher_param_count(void);     /* 593 924 */
+int64_t r2l_teacher_param_count(void);     /* 595 844 */
 int64_t r2l_teacher_stream_floats(void);
 int r2l_pack_teacher(const float* tparams, float* wstream, void* stream);
 

@@ -488,3 +488,22 @@ def test_missing_library_fails_loudly(tmp_path):
             "try:\n    _lib.load()\nexcept RuntimeError as e:\n    print('RAISED', e)\n" % (ROOT, str(tmp_path / "nope.so")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "RAISED" in r.stdout and "no non-HIP fallback" in r.stdout, r.stdout + r.stderr
+
+
+def test_c99_host_compiles_links_and_runs(tmp_path):
+    """include/r2l_hip.h is a C header (not only C++): a C99 host (tests/chost/host.c, -pedantic -Werror) compiles against it,
+    links to libr2l_hip.so and runs its host-side entry points — sizes, dispatch queries with an r2l_config, argument checks —
+    without a GPU."""
+    import shutil
+    from r2l_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    _lib.load()
+    exe = str(tmp_path / "chost")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "chost", "host.c"), "-o", exe, "-L", libdir, "-lr2l_hip", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C99 host ok" in r.stdout, r.stdout + r.stderr
