@@ -5,7 +5,7 @@ autograd).  The build's own training loop does not go through autograd (r2l_amd/
 import torch
 
 from . import _lib
-from .engine import W, _ptr, _stream, get_engine
+from .engine import _ptr, _stream, get_engine
 
 
 class R2LEmbFunction(torch.autograd.Function):
@@ -16,9 +16,9 @@ class R2LEmbFunction(torch.autograd.Function):
         emb2 = emb.reshape(-1, emb.shape[-1]).contiguous().float()
         n, nb = emb2.shape[0], eng.n_block
         f = dict(dtype=torch.float32, device=emb2.device)
-        npad = int(eng.lib.r2l_padded_rows(n))
-        save_x = torch.empty((nb + 1) * npad * W, **f)
-        save_t = torch.empty(max(nb, 1) * npad * W, **f)
+        slot = int(eng.lib.r2l_stash_slot_floats(n))  # include/r2l_hip.h: (n_block + 1) / n_block slots of this many floats
+        save_x = torch.empty((nb + 1) * slot, **f)
+        save_t = torch.empty(max(nb, 1) * slot, **f)
         rgb = eng.forward_emb(emb2, save=(save_x, save_t))
         ctx.module, ctx.n = module, n
         ctx.lead = emb.shape[:-1]
@@ -35,9 +35,9 @@ class R2LEmbFunction(torch.autograd.Function):
         wbwd = torch.empty(lib.r2l_bwd_stream_floats(nb), **f)
         _lib.check(lib.r2l_pack_backward(_ptr(eng.flat), nb, _ptr(wbwd), _stream()), "r2l_pack_backward")
         grads = torch.zeros(eng.n_param, **f)
-        npad = int(lib.r2l_padded_rows(n))
-        gx = torch.empty((nb + 1) * npad * W, **f)
-        gt = torch.empty(max(nb, 1) * npad * W, **f)
+        slot = int(lib.r2l_stash_slot_floats(n))
+        gx = torch.empty((nb + 1) * slot, **f)
+        gt = torch.empty(max(nb, 1) * slot, **f)
         dpre = torch.empty(n * 3, **f)
         slab = torch.empty(int(lib.r2l_dw_slab_floats()), **f)
         drgb = grad_rgb.reshape(-1, 3).contiguous().float()

@@ -38,3 +38,20 @@ def test_ssim_vs_oracle_fullsize(shape):
     one, zero = torch.ones(H, W, C), torch.zeros(H, W, C)
     assert abs(metrics.ssim(one.cuda(), one.cuda()).item() - 1.0) < 1e-6
     assert abs(metrics.ssim(one.cuda(), zero.cuda()).item() - O.ssim(one, zero).item()) < 1e-6
+
+
+def test_ssim_window_computed_by_the_library():
+    """r2l_ssim(window_host = NULL): the library builds the 11x11 Gaussian itself (include/r2l_hip.h) — same value as with the
+    window the Python layer passes (ssim_torch.py:11-25)."""
+    import ctypes
+    from r2l_amd import _lib, metrics
+    L = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    a = torch.rand(57, 83, 3, generator=g).cuda()
+    b = (a + 0.05 * torch.randn(57, 83, 3, generator=g).cuda()).clamp(0, 1)
+    want = metrics.ssim(a, b).item()
+    partial = torch.empty(L.r2l_ssim_partial_count(57, 83, 3), device="cuda")
+    out = torch.empty(1, device="cuda")
+    _lib.check(L.r2l_ssim(a.data_ptr(), b.data_ptr(), 57, 83, 3, None, partial.data_ptr(), out.data_ptr(),
+                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "r2l_ssim")
+    assert abs(out.item() - want) < 1e-6, (out.item(), want)
