@@ -507,3 +507,40 @@ def test_c99_host_compiles_links_and_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C99 host ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (dev container only)")
+def test_checkpoint_written_here_loads_in_the_reference(tmp_path):
+    """"checkpoints written here load in the reference".  save_ckpt's .tar (pickled network_fn + state dict +
+    Adam-format optimizer state) is opened in a SEPARATE process whose sys.path holds only the reference: the pickle resolves to
+    the reference's own model.nerf_raybased.NeRF_v3_2, the forward matches bit for bit, torch.optim.Adam takes the state."""
+    import argparse
+    from model.nerf_raybased import NeRF_v3_2
+    from r2l_amd.checkpoint import save_ckpt
+    trial = argparse.Namespace(ON=True, body_arch="resmlp", inact="relu", outact="none", res_scale=1., n_learnable=2,
+                               n_block=-1, near=-1, far=-1)
+    args = argparse.Namespace(netdepth=8, netwidth=256, layerwise_netwidths="", act="relu", linear_tail=False,
+                              use_residual=True, trial=trial)
+    torch.manual_seed(0)
+    m = NeRF_v3_2(args, 1008, 3)
+    x = torch.randn(5, 1008)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    m(x).sum().backward()
+    opt.step()
+    save_ckpt(str(tmp_path / "ckpt.tar"), 7, m, opt.state_dict(), 1.0, 3)
+    torch.save({"x": x, "y": m(x).detach()}, str(tmp_path / "io.pt"))
+    code = ("import sys; sys.path.insert(0, '/root/reference')\n"
+            "import torch, model.nerf_raybased as rm\n"
+            "assert rm.__file__.startswith('/root/reference')\n"
+            "ck = torch.load(%r, weights_only=False, map_location='cpu')\n"
+            "m = ck['network_fn']\n"
+            "assert type(m) is rm.NeRF_v3_2 and ck['global_step'] == 7\n"
+            "m.load_state_dict(ck['network_fn_state_dict'])\n"
+            "io = torch.load(%r)\n"
+            "assert torch.equal(m(io['x']), io['y'])\n"
+            "opt = torch.optim.Adam(m.parameters(), lr=5e-4)\n"
+            "opt.load_state_dict(ck['optimizer_state_dict'])\n"
+            "assert len(opt.state_dict()['state']) == 16\n"
+            "print('REFERENCE LOADED IT')\n" % (str(tmp_path / "ckpt.tar"), str(tmp_path / "io.pt")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert "REFERENCE LOADED IT" in r.stdout, r.stdout + r.stderr
