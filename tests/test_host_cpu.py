@@ -544,3 +544,25 @@ def test_checkpoint_written_here_loads_in_the_reference(tmp_path):
             "print('REFERENCE LOADED IT')\n" % (str(tmp_path / "ckpt.tar"), str(tmp_path / "io.pt")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert "REFERENCE LOADED IT" in r.stdout, r.stdout + r.stderr
+
+
+def test_checkpoint_helpers_error_behaviour():
+    """helpers:333-382 / main.py:1088-1094: load_weights_v2 insists that model and state dict agree on the DataParallel 'module.'
+    prefix (NotImplementedError otherwise, as the reference), undataparallel strips exactly one prefix, parse_expid_iter reads the
+    experiment id out of a smilelogging path and answers 'Unknown' elsewhere."""
+    from collections import OrderedDict
+    from r2l_amd.checkpoint import load_weights_v2, parse_expid_iter, undataparallel
+    net = torch.nn.Sequential(torch.nn.Linear(3, 2))
+    sd = net.state_dict()
+    load_weights_v2(net, {"k": sd}, "k")
+    with pytest.raises(NotImplementedError):
+        load_weights_v2(net, {"k": OrderedDict(("module." + k, v) for k, v in sd.items())}, "k")
+    wrapped = torch.nn.Sequential(OrderedDict(module=net))  # named_modules() now starts with 'module.'
+    with pytest.raises(NotImplementedError):
+        load_weights_v2(wrapped, {"k": sd}, "k")
+    load_weights_v2(wrapped, {"k": OrderedDict(("module." + k, v) for k, v in sd.items())}, "k")
+    assert list(undataparallel(OrderedDict(("module." + k, v) for k, v in sd.items()))) == list(sd)
+    assert undataparallel(wrapped) is net
+    assert parse_expid_iter("Experiments/R2L__lego_SERVER142-20210704-150540/weights/ckpt_200000.tar") == \
+        ("SERVER142-20210704-150540", "ckpt_200000")
+    assert parse_expid_iter("/data/SERVER3/ckpt.tar") == ("Unknown", "Unknown") == parse_expid_iter("ckpt.tar")
