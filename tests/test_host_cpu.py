@@ -566,3 +566,15 @@ def test_checkpoint_helpers_error_behaviour():
     assert parse_expid_iter("Experiments/R2L__lego_SERVER142-20210704-150540/weights/ckpt_200000.tar") == \
         ("SERVER142-20210704-150540", "ckpt_200000")
     assert parse_expid_iter("/data/SERVER3/ckpt.tar") == ("Unknown", "Unknown") == parse_expid_iter("ckpt.tar")
+
+
+@pytest.mark.parametrize("flags", [["--plucker"], ["--learn_depth", "1"], ["--shuffle_input"], ["--convert_to_onnx"],
+                                   ["--given_render_path_rays", "x.pt"], ["--dataset_type", "llff"]])
+def test_out_of_scope_variants_fail_loudly(flags):
+    """Reference variants outside the accelerated path parse — the reference's command lines keep working up to
+    that point — and then raise NotImplementedError; they are never silently ignored."""
+    from r2l_amd.options import parse_args, validate_accelerated
+    base = ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt")]
+    validate_accelerated(parse_args(base))
+    with pytest.raises(NotImplementedError):
+        validate_accelerated(parse_args(base + flags))
