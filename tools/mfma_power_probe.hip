@@ -51,6 +51,43 @@ __global__ __launch_bounds__(256, 1) void stream_kernel(const u32x4* __restrict_
     if (s == 12345.678f) sink[0] = s;
 }
 
+// the same stream with the A operands re-read from LDS at the render kernel's ratio: 2 x ds_read_b128 (hi, mid) per 3 MFMAs
+// (PROBE_LDS=1 with PROBE_ONE): what the LDS -> register traffic of the weights costs in sustained rate
+__global__ __launch_bounds__(256, 1) void stream_lds_kernel(const u32x4* __restrict__ ops, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[6 * 1024];  // 96 KiB of operand data (random fp16 bit patterns)
+    for (int i = threadIdx.x; i < 6 * 1024; i += 256) lds[i] = ops[(i % 8) * 256 + (i * 7 + threadIdx.x) % 256];
+    __syncthreads();
+    const u32x4 ub_h = ops[8 * 256 + threadIdx.x], ub_m = ops[9 * 256 + threadIdx.x];
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[t][c] = 0.f;
+    const int lane = threadIdx.x & 63;
+    // software pipeline: the 16 A quads of iteration i + 1 are read while the 24 MFMAs of iteration i run (ping-pong sets)
+    u32x4 a0[16], a1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a0[q] = lds[q * 64 + lane];
+#define LDS_STEP(CUR, NXT, BASE)                                                                                              \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                                           \
+        NXT[2 * t] = lds[(BASE) + t * 128 + lane];                                                         \
+        NXT[2 * t + 1] = lds[(BASE) + t * 128 + 64 + lane];                                                \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, CUR[2 * t + 1]), __builtin_bit_cast(f16x8, ub_h), acc[t], 0, 0, 0); \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, CUR[2 * t]), __builtin_bit_cast(f16x8, ub_m), acc[t], 0, 0, 0);     \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, CUR[2 * t]), __builtin_bit_cast(f16x8, ub_h), acc[t], 0, 0, 0);     \
+    }
+    for (int i = 0; i < iters; i += 2) {
+        const int b1 = ((i + 1) & 3) * 1536, b2 = ((i + 2) & 3) * 1536;
+        LDS_STEP(a0, a1, b1)
+        LDS_STEP(a1, a0, b2)
+    }
+#undef LDS_STEP
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += acc[t][5];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 static unsigned short f2h(float f) {  // round-to-nearest fp16 bits (normal range only; enough for the probe)
     _Float16 h = (_Float16)f;
     unsigned short u;
@@ -90,8 +127,11 @@ int main() {
         }
         hipMemcpy(dev, host, n16 * 2, hipMemcpyHostToDevice);
         const int iters = 60000 * long_run;
+        const bool lds_fed = getenv("PROBE_LDS") != nullptr;
+        const int it2 = lds_fed ? iters * 32 / 24 : iters;  // (24 MFMAs per iteration instead of 32)
         hipEventRecord(e0);
-        if (bf && rot) hipLaunchKernelGGL((stream_kernel<true, true>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
+        if (lds_fed) hipLaunchKernelGGL(stream_lds_kernel, dim3(wgs), dim3(threads), 0, 0, dev, sink, it2);
+        else if (bf && rot) hipLaunchKernelGGL((stream_kernel<true, true>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
         else if (bf) hipLaunchKernelGGL((stream_kernel<true, false>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
         else if (rot) hipLaunchKernelGGL((stream_kernel<false, true>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
         else hipLaunchKernelGGL((stream_kernel<false, false>), dim3(wgs), dim3(threads), 0, 0, dev, sink, iters);
@@ -99,7 +139,8 @@ int main() {
         hipEventSynchronize(e1);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
-        printf("%.2f ms %.3f PF/s\n", ms, (double)wgs * 4 * iters * 32.0 * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e15);
+        const double nm = lds_fed ? (double)it2 * 24.0 : (double)iters * 32.0;
+        printf("%.2f ms %.3f PF/s\n", ms, (double)wgs * 4 * nm * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e15);
         return 0;
     }
     printf("%-6s %-9s %-36s %10s %12s\n", "type", "operands", "operand data", "ms", "PF/s");
