@@ -39,6 +39,7 @@ PEAK_BF16_MFMA = 2500.0  # TFLOP/s dense bf16 MFMA (same guide; the sparsity-inf
 # zero operands only, the power cap holds random data to these product rates.  Reported beside `peak`, never instead of it.
 SUSTAINED_FP16_MFMA_ONLY = 1770.0  # TFLOP/s of fp16 products
 SUSTAINED_BF16_MFMA_ONLY = 1920.0
+SUSTAINED_FP16_MFMA_LDS_FED = 1570.0  # the same fp16 stream with its A operands re-read from LDS at the render kernel's ratio
 H = W = 400
 FOCAL = 555.5555155968841
 FRAMES_PER_STEP = 9  # driver.POSES_PER_LAUNCH: test frames per render launch
@@ -384,8 +385,10 @@ def main():
                      "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
                      "frac_of_measured_mfma_only_rate": (achieved * 3. / SUSTAINED_FP16_MFMA_ONLY if fwd2 else
                                                          (achieved * 6. / SUSTAINED_BF16_MFMA_ONLY if fwd3 else None)),
+                     "frac_of_measured_lds_fed_mfma_rate": (achieved * 3. / SUSTAINED_FP16_MFMA_LDS_FED if fwd2 else None),
                      "measured_mfma_only_rate_note": "an MFMA-only stream with random operand mantissas sustains 1.77 PF/s of fp16 / "
-                                                     "1.92 PF/s of bf16 products on this chip under its power cap (2.48 on zero operands): "
+                                                     "1.92 PF/s of bf16 products on this chip under its power cap (2.48 on zero operands; 1.57 when the fp16 stream's A operands are "
+                                                     "re-read from LDS at this kernel's ratio): "
                                                      "profiles/r03_mfma_power_probe.txt, tools/mfma_power_probe.hip",
                      "peak_note": peak_note,
                      "traffic": traffic,
