@@ -56,6 +56,10 @@ def rays(n, gen):
 
 
 def main(iters=1500, n=16384):
+    if os.environ.get("R2L_EQ_FAMILIES"):  # e.g. "0,3": a subset of the families (long runs)
+        keep = [int(v) for v in os.environ["R2L_EQ_FAMILIES"].split(",")]
+        for k in [k for i, k in enumerate(list(FAMILIES)) if i not in keep]:
+            del FAMILIES[k]
     ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
     sd = O.make_state_dict(43, seed=0)
     gen = torch.Generator(device="cuda").manual_seed(123)
