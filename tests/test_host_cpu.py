@@ -578,3 +578,23 @@ def test_out_of_scope_variants_fail_loudly(flags):
     validate_accelerated(parse_args(base))
     with pytest.raises(NotImplementedError):
         validate_accelerated(parse_args(base + flags))
+
+
+def test_logger_layout_round_trips_through_parse_expid_iter(tmp_path, monkeypatch):
+    """Experiments/<name>_SERVER<id>-<time>/{weights, gen_img, log} (smilelogging/logger.py:234-288) — the layout the reference's
+    `--render_only` reads the experiment id back from (main.py:1088-1094): a checkpoint path under weights/ gives the ExpID."""
+    import argparse
+    from r2l_amd.checkpoint import parse_expid_iter
+    from r2l_amd.logger import Logger
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("R2L_SERVER_ID", "142")
+    lg = Logger(argparse.Namespace(experiment_name="R2L__lego", debug=False, trial=argparse.Namespace(ON=True)), rank=0)
+    assert re.fullmatch(r"SERVER142-\d{8}-\d{6}", lg.ExpID)
+    for d in (lg.weights_path, lg.gen_img_path, lg.log_path):
+        assert os.path.isdir(d) and d.startswith(os.path.join("Experiments", "R2L__lego_" + lg.ExpID))
+    lg.info("hello")
+    assert "hello" in open(os.path.join(lg.log_path, "log.txt")).read()
+    assert os.path.exists(os.path.join(lg.log_path, "args.yaml"))
+    assert parse_expid_iter(os.path.join(lg.weights_path, "ckpt_1000.tar")) == (lg.ExpID, "ckpt_1000")
+    other = Logger(argparse.Namespace(experiment_name="x", debug=True), rank=1)  # other ranks: same attributes, no files
+    assert other.exp_path.startswith("Debug_Dir") and not os.path.exists(other.exp_path)
