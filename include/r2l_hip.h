@@ -118,6 +118,27 @@ int r2l_forward_pose_cfg(const float* c2w_host12, int H, int W, float focal, con
 int r2l_forward_poses_cfg(const float* c2w_dev, int K, int H, int W, float focal, const float* ztab, const float* wstream,
                           const float* params, int n_block, float* rgb, void* stream, const r2l_config* cfg);
 
+/* ---- range control of the fp16 kernels (precision FP16X2, the default) -----------------------------------------------------
+ * fp16 ends at 65504; the reference's fp32 activations (model/nerf_raybased.py:461-465: an un-normalised 88-layer residual
+ * stream) are not bounded a priori.  The library keeps them in range by itself, on the device: the forward weight stream is
+ * packed for a power-of-two activation scale s (head weights and all biases divided by s — a ReLU net is positively
+ * homogeneous, so every activation is divided by s and nothing else changes; the kernels multiply by s where values leave
+ * the chain: exact), every launch records its largest |activation|, and r2l_pack_forward* picks s for the next launches from
+ * it (s = 1 while activations stay below 8192: bit-identical to an unscaled stream).  A launch that nevertheless meets a
+ * value >= 32768 is redone by the bf16x3 kernel launched behind it (no host involvement, results still exact products), the
+ * stream is re-packed for a larger s by that fallback, and the NEXT launch is back on the fp16 kernels.  The training
+ * backward does the same with the power-of-two scale of its gradient chain, step to step (r2l_backward_status_words).
+ * Hosts only need to (a) zero-fill `wstream` / `wstream_bwd` once after allocating them (stale contents of a previous
+ * instance would be taken for history: harmless, but runs are then not reproducible bit for bit) and (b) may read the
+ * telemetry below, e.g. to log head-room.  Words (uint32 / float bit patterns) of the forward area:
+ *   [0] guard flag of the launch in flight   [1] largest |activation| / s since the scale was last chosen (float)
+ *   [2] s (float)   [3] 1 / s   [5] launches that fell back to the bf16x3 kernel   [6] largest |activation| (unscaled) of the
+ *   previous epoch (float)   [7] times s changed;   others: private.
+ * of the backward area: [0] flag: this step ran on the bf16x3 kernels   [4] gradient scale (float)   [8] largest |chain value|
+ *   x scale of this step (float)   [10] steps that fell back   [11] largest unscaled |chain value| of the last clean step. */
+const unsigned* r2l_forward_status_words(const float* wstream, int n_block);
+const unsigned* r2l_backward_status_words(const float* wstream_bwd, int n_block);
+
 /* rgb[N,3] = NeRF_v3_2.forward(emb[N,1008])  — the module-boundary form (model/nerf_raybased.py:539-544) for callers
  * that still run their own sampler/embedder. */
 int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,

@@ -71,6 +71,8 @@ SIGNATURES = {
     "r2l_adam_step_guarded": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p]),
     "r2l_chain_segments_ok_cfg": (_i, [_l, _i, _cfgp]),
     "r2l_backward_status_word": (_p, [_p, _i]),
+    "r2l_forward_status_words": (_p, [_p, _i]),
+    "r2l_backward_status_words": (_p, [_p, _i]),
     "r2l_loss_finish": (_i, [_p, _l, _f, _p, _p]),
     "r2l_teacher_param_count": (_l, []),
     "r2l_teacher_stream_floats": (_l, []),

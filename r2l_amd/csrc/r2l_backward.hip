@@ -1105,9 +1105,70 @@ __global__ __launch_bounds__(1024) void r2l_gscale_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
-// the 16 status words behind the fp16 dX stream: cleared at the start of every step
-__global__ void r2l_status_clear_kernel(unsigned* status) {
-    if (threadIdx.x < 16) status[threadIdx.x] = 0u;
+// The 16 status words behind the fp16 dX stream (r2l_common.h B2S_*), at the start of every step of the fp16 trio: FLAG and
+// AMAX cleared, and — MSE mode — the power of two the step's dX chain runs on written to GSCALE / GINV:
+//   * first step (or after a step that fell back, or a zero gradient): the a-priori rule of rounds 1 - 3, 2^(8 - e) for
+//     grad_scale = m * 2^e (the seed is then <= 64 |rgb - target|), corrected by the size of the tail weights the seed goes
+//     through: x 2^(-3 - e_w) for max |W_tail| = m * 2^e_w (the default init's 1/16 gives 1);
+//   * afterwards the scale is KEPT while the last clean step's largest |chain value| (times grad_scale / its grad_scale: batch
+//     sizes may change) lies in [2^-2, 2^13] scaled — a factor 4 below the guard (R2L_F2_RANGE) and, at the low end, still
+//     2^-23 of the largest value in absolute fp16 (hi + mid) resolution — and re-centred to 2^8 when it leaves that band.
+//     So nets whose gradients live where the a-priori rule expects them (default init, the trained nets measured so far) run
+//     bit for bit as in round 3, and a net whose gradients drift (or start) elsewhere follows on the next step instead of
+//     falling back (overflow) or silently losing bits (underflow) from then on.
+// Powers of two commute with fp32 rounding: whatever the scale, the bf16x3 fallback run on it is bit-identical after unscaling.
+// (A kernel, not hipMemsetAsync: a memset node captured into a hipGraph wrote a stale pattern on replay, ROCm 7.0; the history
+// is device state, so captured steps adapt on replay as eager ones do.)  generic mode (mse == 0): GSCALE is r2l_gscale_kernel's.
+__global__ __launch_bounds__(64) void r2l_bwd_prepare_kernel(unsigned* status, const float* __restrict__ tail_w, float grad_scale,
+                                                             int mse) {
+    float wm = 0.f;
+    if (mse)
+        for (int i = threadIdx.x; i < 3 * R2L_W; i += 64) wm = fmaxf(wm, fabsf(tail_w[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off));
+    if (threadIdx.x != 0) return;
+    const float gs = fabsf(grad_scale);
+    const bool valid = status[B2S_MAGIC] == F2_MAGIC;
+    const bool clean = valid && status[B2S_FLAG] == 0u;
+    const float a = clean ? __builtin_bit_cast(float, status[B2S_AMAX]) : 0.f;
+    const float g_prev = valid ? __builtin_bit_cast(float, status[B2S_GSCALE]) : 0.f;
+    const float gs_prev = valid ? __builtin_bit_cast(float, status[B2S_GS]) : 0.f;
+    int ex_prev = 0;
+    const bool g_ok = g_prev > 0.f && g_prev < 3.0e38f && frexpf(g_prev, &ex_prev) == 0.5f;  // a power of two: 2^(ex_prev - 1)
+    float peak = valid ? __builtin_bit_cast(float, status[B2S_PEAK]) : 0.f;
+    unsigned trips = valid ? status[B2S_TRIPS] : 0u;
+    if (valid && status[B2S_FLAG] != 0u) ++trips;
+    if (clean && g_ok && a > 0.f && a < 3.0e38f) peak = a / g_prev;  // unscaled amax of the last clean step
+    else if (!clean) peak = 0.f;                                      // (a step that fell back says nothing reliable)
+    if (mse) {
+        int ex = 0;
+        const float est = (peak > 0.f && gs_prev > 0.f && gs > 0.f && g_ok) ? peak * (gs / gs_prev) : 0.f;
+        if (est > 0.f && est < 3.0e38f) {
+            const float scaled = est * g_prev;
+            if (scaled >= 0.25f && scaled <= 8192.f) {
+                ex = ex_prev - 1;
+            } else {
+                (void)frexpf(est, &ex);
+                ex = 8 - ex;
+            }
+        } else if (gs > 0.f) {
+            int e = 0, ew = -3;
+            (void)frexpf(gs, &e);
+            if (wm > 0.f && wm < 3.0e38f) (void)frexpf(wm, &ew);
+            ex = (8 - e) + (-3 - ew);
+        }
+        ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+        status[B2S_GSCALE] = __builtin_bit_cast(unsigned, ldexpf(1.0f, ex));
+        status[B2S_GINV] = __builtin_bit_cast(unsigned, ldexpf(1.0f, -ex));
+        status[B2S_GS] = __builtin_bit_cast(unsigned, gs);
+    } else {
+        status[B2S_GS] = 0u;
+    }
+    status[B2S_PEAK] = __builtin_bit_cast(unsigned, peak);
+    status[B2S_TRIPS] = trips;
+    status[B2S_MAGIC] = F2_MAGIC;
+    status[B2S_AMAX] = 0u;
+    status[B2S_FLAG] = 0u;
 }
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
@@ -1128,6 +1189,11 @@ extern "C" const unsigned* r2l_backward_status_word(const float* wstream_bwd, in
     const float* w3 = wstream_bwd + r2l_bwd32_stream_floats(n_block) + r2l_bwd16_stream_floats(n_block);
     const float* w2 = w3 + r2l_bwd3_stream_floats(n_block);
     return reinterpret_cast<const unsigned*>(w2 + r2l_bwd2_status_offset(n_block));
+}
+
+extern "C" const unsigned* r2l_backward_status_words(const float* wstream_bwd, int n_block) {
+    if (wstream_bwd == nullptr || n_block < 0 || n_block > R2L_MAX_BLOCKS) return nullptr;
+    return r2l_backward_status_word(wstream_bwd, n_block);
 }
 
 extern "C" int r2l_backward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
@@ -1220,7 +1286,9 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
     unsigned* bwd_status = reinterpret_cast<unsigned*>(const_cast<float*>(w2) + r2l_bwd2_status_offset(n_block));
     // generic mode (dL/drgb from the caller, no known scale): {gscale, 1 / gscale} are chosen on the device from max |drgb| and
     // live in words 4, 5 of the status area; every kernel of the step reads them there
-    const float* scale_dev = (trio16 && target == nullptr) ? reinterpret_cast<const float*>(bwd_status + 4) : nullptr;
+    // (round 4: MSE mode as well — the step's scale is chosen on the device from the previous step's largest chain value,
+    // r2l_bwd_prepare_kernel; the host-side gscale below remains the bf16x3-only trio's)
+    const float* scale_dev = trio16 ? reinterpret_cast<const float*>(bwd_status + B2S_GSCALE) : nullptr;
     if (!(parts & R2L_BWD_CHAIN)) {
     } else if (variant == R2L_VARIANT_COOP16) {
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
@@ -1244,9 +1312,10 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             if (!chain_seg || layer_hi == 2 * n_block) {  // (the first segment opens the step)
                 // (a kernel, not hipMemsetAsync: a memset node captured into a hipGraph wrote a stale 16-byte pattern instead
                 // of zeros on replay — ROCm 7.0 —, which sent every replayed step to the fallback kernels)
-                hipLaunchKernelGGL(r2l_status_clear_kernel, dim3(1), dim3(64), 0, stream, bwd_status);
+                hipLaunchKernelGGL(r2l_bwd_prepare_kernel, dim3(1), dim3(64), 0, stream, bwd_status, params + b_off_tail_w(n_block),
+                                   grad_scale, target != nullptr ? 1 : 0);
                 R2L_CHECK(hipGetLastError());
-                if (scale_dev != nullptr) {
+                if (target == nullptr) {
                     hipLaunchKernelGGL(r2l_gscale_kernel, dim3(1), dim3(1024), 0, stream, drgb, 3 * N, const_cast<float*>(scale_dev));
                     R2L_CHECK(hipGetLastError());
                 }
@@ -1307,8 +1376,10 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         if (trio16) {
             // (exact mode: the chains of this step stashed the mid halves too — the same config / environment as the forward)
             a.mid_off = r2l_dw_exact() ? (unsigned)R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) : 0u;
+            a.act_scale = save_x + R2L_STASH_FMT_WORD(n_block, R2L_PAD_ROWS(N)) + 1;  // the scale the forward stashed x, relu(t) at
             const int rc = r2l_dw16_launch(a, wgs, bwd_status, stream);
             a.mid_off = 0u;
+            a.act_scale = nullptr;
             if (rc) return rc;
             a.run_if = bwd_status;
             if (!no_fallback) hipLaunchKernelGGL(r2l_dw_body3c_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd2_kernel(const B2Args a) {
                                      F2Hst{mid, gtr, hvoff, 1024u * 15u + a.stash_mid});
     }
 
-    if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+    f2_report_amax<B2S_AMAX>(a.status, P.amax, lane);  // AMAX (the next step's scale is chosen from it), FLAG if out of range
 
     // ---- head: dL/d(head pre-activation) = (g + dy) * (x_0 > 0) -> gx[0] ---------------------------------------------------------
     {

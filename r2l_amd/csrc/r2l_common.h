@@ -383,6 +383,10 @@ __host__ __device__ static inline int64_t r2l_fwd2_status_offset(int n_block) {
     return (r2l_fwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (16384 / 4);
 }
 __host__ __device__ static inline int64_t r2l_fwd2_stream_floats(int n_block) { return r2l_fwd2_status_offset(n_block) + 16; }
+// the 16 status words (range control of the fp16x2 forward: r2l_f2.h)
+enum { F2S_FLAG = 0, F2S_AMAX = 1, F2S_SCALE = 2, F2S_INV = 3, F2S_MAGIC = 4, F2S_TRIPS = 5, F2S_PEAK = 6, F2S_RESCALES = 7,
+       F2S_DONE = 8, F2S_GO = 9 };
+#define F2_MAGIC 0x52324c34u
 __host__ __device__ static inline int64_t r2l_bwd3_stages(int n_block) { return 34 * (int64_t)n_block; }
 __host__ __device__ static inline int64_t r2l_bwd3_stream_floats(int n_block) {
     return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
@@ -392,6 +396,12 @@ __host__ __device__ static inline int64_t r2l_bwd2_status_offset(int n_block) {
     return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (16384 / 4);
 }
 __host__ __device__ static inline int64_t r2l_bwd2_stream_floats(int n_block) { return r2l_bwd2_status_offset(n_block) + 16; }
+// the 16 status words of a training step's backward (fp16 trio).  FLAG: this step belongs to the bf16x3 kernels (range guard of
+// the dX chain, or the forward already fell back); GSCALE / GINV: the power of two the chain runs on and its inverse — every
+// kernel of the step reads them here; AMAX: largest |B value| of the step's chain (scaled units, float bits); MAGIC / PEAK / GS:
+// history for the next step's scale (r2l_bwd_prepare_kernel, r2l_backward.hip): unscaled gradient amax and grad_scale of the
+// last clean step; TRIPS: steps that fell back (telemetry)
+enum { B2S_FLAG = 0, B2S_GSCALE = 4, B2S_GINV = 5, B2S_AMAX = 8, B2S_MAGIC = 9, B2S_TRIPS = 10, B2S_PEAK = 11, B2S_GS = 12 };
 // run_if: nullptr, or a device word — the pack returns at once while it is 0 (the bf16x3 stream as range-guard fallback of the
 // fp16 kernels is packed right in front of the fallback launch, and only when that launch will really run)
 int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if = nullptr);
@@ -489,6 +499,11 @@ int r2l_fwd2_forward(const float* rays_o, const float* rays_d, const float* t_ra
                      const float* c2w_host12, int H, int W, float focal, const float* wstream2, const float* params,
                      int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
 int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if = nullptr);
+// Behind every fp16x2 forward launch: returns at once (GO = 0) unless that launch raised FLAG; else packs the bf16x3 stream,
+// re-packs the scale-dependent stages of the fp16x2 stream for the next activation scale and commits it (GO = 1, FLAG = 0
+// unless the scale is exhausted): the r2l_fwd3_forward behind it (run_if = status + F2S_GO) redoes this launch, the next
+// launch is back on the fp16 kernels (r2l_f2.h: range control)
+int r2l_fwd2_fallback_pack(const float* params, int n_block, float* wstream3, float* wstream2, hipStream_t stream);
 // run_if: nullptr, or a device word — the launch returns at once while it is 0 (fallback behind r2l_fwd2_forward)
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,

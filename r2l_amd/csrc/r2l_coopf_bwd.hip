@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+    f2_report_amax<B2S_AMAX>(a.status, amax, lane);  // AMAX (the next step's scale is chosen from it), FLAG if out of range
 
     if (!final) {  // the chain continues in the next launch
 #pragma unroll

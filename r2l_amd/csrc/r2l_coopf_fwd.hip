@@ -205,8 +205,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         ht[rt] = SAVE ? reinterpret_cast<u32x4*>(a.save_t) + tile[rt] * R2L_H16_TILE_UNITS + lane + 256 * wave : nullptr;
         mwp[rt] = SAVE ? reinterpret_cast<unsigned*>(a.save_t + R2L_MASK_OFFSET(Np) + tile[rt] * 256 + lane * 4) + wave : nullptr;
     }
-    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
-        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
+    // the activation scale this stream was packed for (r2l_f2.h range control): what the chain holds is x / act_s
+    const float act_s = __builtin_bit_cast(float, a.status[F2S_SCALE]);
+    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0) {  // stash format word: fp16 stage pieces (a fallback launch overwrites it),
+        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;  // and the scale of the stashed x, relu(t)
+        reinterpret_cast<float*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np) + 1] = act_s;
+    }
     // (the kind-0 images were last read in chunk 2 of the head, two barriers ago)
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) fc_produce<false, SAVE, false, FcIdentity, MID>(x[rt], bop_wr + (unsigned)rt * FC_BOP_BYTES, hx[rt], nullptr, amax, FcIdentity(), a.mid_units);
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's look-ahead loads (stream padding) and the stash stores
 
-    if (!(amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+    f2_report_amax(a.status, amax, lane);  // range control (r2l_f2.h): AMAX, and FLAG if this launch belongs to the bf16x3 kernel
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt): per-wave partial dot products over its 64 features, summed through LDS ----------
     const float* tw = a.params + cf_off_tail_w(a.n_block) + 4 * h;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
                 }
 #endif
                 // slot n of save_x: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
-                if (SAVE) *reinterpret_cast<f32x4*>(a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 32 * T + 8 * q + 4 * h) = yv;
+                if (SAVE) *reinterpret_cast<f32x4*>(a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 32 * T + 8 * q + 4 * h) = yv * act_s;
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c) p3[c] += __shfl_xor(p3[c], 32);
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
             const int rj = rt * 32 + j;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = ((red[0][rj][c] + red[1][rj][c]) + (red[2][rj][c] + red[3][rj][c])) + a.params[cf_off_tail_b(a.n_block) + c];
+                const float v = ((red[0][rj][c] + red[1][rj][c]) + (red[2][rj][c] + red[3][rj][c])) * act_s + a.params[cf_off_tail_b(a.n_block) + c];
                 a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
             }
         }

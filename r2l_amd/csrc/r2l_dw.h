@@ -44,6 +44,9 @@ struct R2LDwArgs {
     // exact weight gradients of the fp16 trio (r2l_dw16.hip): != 0 -> the slots also hold the operands' mid halves, this many
     // bytes behind the hi stage pieces (r2l_f2.h R2L_H16_MID_BYTES), and every fp32 product is taken as hi*hi + hi*mid + mid*hi
     unsigned mid_off = 0u;
+    // fp16 trio: the forward chain ran on x / s (range control, r2l_f2.h) and stashed that; *act_scale = s (the word behind the
+    // stash format word): r2l_dw16 multiplies dW — not db, which never sees an activation — by it at the flush
+    const float* act_scale = nullptr;
 };
 
 #define DW_SLAB_FLOATS (R2L_W * R2L_W + R2L_W)  // one layer: dW[256][256] then db[256], as in the flat gradient

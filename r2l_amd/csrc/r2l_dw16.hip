@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
         return;
     }
     const float unscale = a.scale_dev != nullptr ? a.scale_dev[1] : a.unscale;
+    const float wscale = a.act_scale != nullptr ? unscale * a.act_scale[0] : unscale;  // powers of two: exact
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wo = wave >> 1, wi = wave & 1;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * unscale;
+                            rowp[(32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei] = acc[eo][ei][c] * wscale;
                             acc[eo][ei][c] = 0.f;
                         }
             } else {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     for (int ei = 0; ei < 4; ++ei)
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
-                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * unscale);
+                            atomicAdd(rowp + (32 * eo + 8 * (c >> 2) + (c & 3)) * R2L_W + 32 * ei, acc[eo][ei][c] * wscale);
                             acc[eo][ei][c] = 0.f;
                         }
             }

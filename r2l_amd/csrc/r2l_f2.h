@@ -54,6 +54,159 @@ struct F2Split {
     f16x8 h, m;
 };
 
+// ---- range control of the fp16x2 forward (round 4) ---------------------------------------------------------------------------
+// fp16 ends at 65504, and a trained 88-layer residual stream is not bounded a priori.  A ReLU net is positively homogeneous:
+// dividing the head's weights and EVERY bias by s divides every activation (x_b and t_b alike) by s, with the body weights
+// untouched; the tail multiplies its dot products by s again.  For s a power of two all of this is exact in fp32, so the stage
+// stream is simply PACKED for the scale s the previous launches asked for, and the kernels multiply by s where they leave the
+// chain (tail, y slot of the stash; the weight-gradient GEMMs that read the stash of x / s multiply dW by s at their flush).
+// Everything lives in the 16 status words behind the stage stream, on the device — no host round trip:
+//   FLAG      != 0: the fp16x2 launch in flight saw |value| >= R2L_F2_RANGE (or s is exhausted): the bf16x3 kernel behind redoes it
+//   AMAX      largest |B value| (scaled units, float bits; atomicMax) of the launches since the scale was last committed
+//   SCALE/INV s and 1/s of the packed stream (floats)
+//   MAGIC     the area has been initialised by a pack of this library (else: s = 1, nothing known)
+//   TRIPS / RESCALES   launches that fell back / commits that changed s (telemetry)
+//   PEAK      unscaled amax of the epoch closed by the last commit (telemetry; host reports max(PEAK, AMAX * SCALE))
+//   DONE / GO fallback protocol: workgroups of the fallback pack that have finished; the bf16x3 forward runs iff GO != 0
+// Policy (f2_next_scale): keep AMAX / s within [2^10, 2^13] — s = 1 for every net whose activations stay below 8192, so the
+// default-init and the measured trained nets run bit-for-bit as before.  A launch that trips is redone by the bf16x3 kernel
+// ONCE; the fallback's pack kernel re-packs the scaled stages (head + bias stages, 2.4 MB) for the new s and its last
+// workgroup commits it, so the next launch is back on the fp16 kernels: the guard is per launch, not sticky.
+// (the word indices F2S_* live in r2l_common.h, next to the status area's offset)
+#define F2_SCALE_MAX_EXP 24   // s <= 2^24: activations up to ~1e11 stay on the fp16 kernels
+struct F2Next {
+    float s, inv;   // the scale to pack for
+    float peak;     // unscaled amax of the epoch this decision closes
+    bool tripped;   // FLAG was set
+    bool stuck;     // tripped with s already at its maximum: the flag stays (sticky fallback, as before round 4)
+    bool changed;
+};
+__device__ __forceinline__ int f2_ceil_log2(float a) {  // smallest e with a < 2^e (a > 0, finite)
+    int e = 0;
+    (void)frexpf(a, &e);
+    return e;
+}
+__device__ __forceinline__ F2Next f2_next_scale(const unsigned* st) {
+    F2Next r;
+    const bool valid = st[F2S_MAGIC] == F2_MAGIC;
+    int es = 0;
+    if (valid) {
+        int e = 0;
+        const float m = frexpf(__builtin_bit_cast(float, st[F2S_SCALE]), &e);
+        if (m == 0.5f && e >= 1 && e <= F2_SCALE_MAX_EXP + 1) es = e - 1;
+    }
+    const float a = valid ? __builtin_bit_cast(float, st[F2S_AMAX]) : 0.f;  // scaled units; inf once an operand overflowed
+    r.tripped = valid && st[F2S_FLAG] != 0u;
+    int en = es;
+    if (r.tripped) {
+        // a value in [32768, 65504) tripped the guard while everything was still finite: AMAX is the truth; beyond that an
+        // operand became inf and AMAX only says "too large": jump 2^8 and let the next launch's AMAX refine it
+        en = (a < 60000.f) ? es + (f2_ceil_log2(a) - 13 > 1 ? f2_ceil_log2(a) - 13 : 1) : es + 8;
+    } else if (a >= 8192.f) {
+        en = es + f2_ceil_log2(a) - 13;
+    } else if (a > 0.f && a < 1024.f && es > 0) {
+        en = es + f2_ceil_log2(a) - 13;
+        if (en < 0) en = 0;
+    }
+    if (en > F2_SCALE_MAX_EXP) en = F2_SCALE_MAX_EXP;
+    r.stuck = r.tripped && en == es;
+    r.changed = en != es;
+    r.s = ldexpf(1.0f, en);
+    r.inv = ldexpf(1.0f, -en);
+    r.peak = a * ldexpf(1.0f, es);
+    return r;
+}
+// one thread: close the epoch.  fallback: called by the last workgroup of the fallback pack (the bf16x3 forward behind it runs)
+__device__ __forceinline__ void f2_commit_scale(unsigned* st, const F2Next& nx, bool fallback) {
+    const bool valid = st[F2S_MAGIC] == F2_MAGIC;
+    const float old_peak = valid ? __builtin_bit_cast(float, st[F2S_PEAK]) : 0.f;
+    st[F2S_TRIPS] = (valid ? st[F2S_TRIPS] : 0u) + ((fallback && nx.tripped) ? 1u : 0u);
+    st[F2S_RESCALES] = (valid ? st[F2S_RESCALES] : 0u) + (nx.changed ? 1u : 0u);
+    st[F2S_PEAK] = __builtin_bit_cast(unsigned, fallback ? fmaxf(old_peak, nx.peak) : (nx.peak > 0.f ? nx.peak : old_peak));
+    st[F2S_SCALE] = __builtin_bit_cast(unsigned, nx.s);
+    st[F2S_INV] = __builtin_bit_cast(unsigned, nx.inv);
+    st[F2S_AMAX] = 0u;
+    st[F2S_DONE] = 0u;
+    st[F2S_GO] = (fallback && nx.tripped) ? 1u : 0u;
+    st[F2S_MAGIC] = F2_MAGIC;
+    st[F2S_FLAG] = nx.stuck ? 1u : 0u;
+}
+// end of a chain kernel: the wave's largest |B value| goes to AMAX, the guard to FLAG (one atomic pair per wave)
+template <int AMAX_WORD = F2S_AMAX>
+__device__ __forceinline__ void f2_report_amax(unsigned* st, float amax, int lane) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) {
+        atomicMax(st + AMAX_WORD, __builtin_bit_cast(unsigned, amax));
+        if (!(amax < R2L_F2_RANGE)) atomicOr(st, 1u);  // (FLAG is word 0 of both status areas)
+    }
+}
+
+// ---- pack: flat fp32 parameters -> fp16x2 forward stage stream (shared by r2l_fwd2.hip's pack and the fallback pack of
+// r2l_fwd3.hip).  A stage is [split sp (2)][tile t][lane (i,h)][slot s] fp16; bias stage: split region 0 only, slots 0, 1 of
+// half 0 = hi, mid.  Head weights and all biases are multiplied by inv_s (a power of two: exact).  only_scaled: just the
+// stages that depend on the scale (head, bias stages).
+__host__ __device__ static inline int64_t f2_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
+__host__ __device__ static inline int64_t f2_off_body_w(int layer) {
+    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
+}
+__host__ __device__ static inline int64_t f2_off_body_b(int layer) { return f2_off_body_w(layer) + R2L_W * R2L_W; }
+__host__ __device__ static inline int64_t f2_off_tail_w(int n_block) { return f2_off_body_w(2 * n_block); }
+__host__ __device__ static inline int64_t f2_off_tail_b(int n_block) { return f2_off_tail_w(n_block) + 3 * R2L_W; }
+__device__ __forceinline__ unsigned short f2_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void f2_pack_fwd_elements(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                                     float inv_s, bool only_scaled, int64_t first, int64_t stride) {
+    const int64_t stages = r2l_fwd3_stages(n_block);
+    const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
+    for (int64_t idx = first; idx < total; idx += stride) {
+        const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
+        const int64_t g = idx >> 12;
+        if (only_scaled && !(g < 64 || (g < stages && (g - 64) % 17 == 0))) continue;
+        const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
+        unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
+        unsigned short v0 = 0, v1 = 0;
+        if (g < stages) {
+            bool bias_stage = false;
+            float w = 0.f;
+            if (g == 0) {
+                bias_stage = true;
+                w = params[f2_off_head_b() + o] * inv_s;
+            } else if (g < 64) {
+                const int v = 8 * (int)(g - 1) + s;
+                int col;
+                if (v < 480) {
+                    const int ci = v / 20, within = v % 20, f = within >> 1;
+                    col = 21 * (3 * (8 * h + ci / 3) + ci % 3) + ((within & 1) ? 10 + f : f);
+                } else {
+                    const int e = v - 480;
+                    col = 21 * (3 * (8 * h + e / 3) + e % 3) + 20;
+                }
+                w = params[(int64_t)o * R2L_IN + col] * inv_s;
+            } else {
+                const int layer = (int)((g - 64) / 17), r17 = (int)((g - 64) % 17);
+                if (r17 == 0) {
+                    bias_stage = true;
+                    w = params[f2_off_body_b(layer) + o] * inv_s;
+                } else {
+                    const int kb = r17 - 1, T = kb >> 1, r = kb & 1;
+                    const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
+                    w = params[f2_off_body_w(layer) + (int64_t)o * R2L_W + in];
+                }
+            }
+            const _Float16 hi = (_Float16)w;
+            const _Float16 mid = (_Float16)(w - (float)hi);
+            if (bias_stage) {
+                v0 = (h == 0) ? (s == 0 ? f2_bits(hi) : (s == 1 ? f2_bits(mid) : (unsigned short)0)) : (unsigned short)0;
+            } else {
+                v0 = f2_bits(hi); v1 = f2_bits(mid);
+            }
+        }
+        const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
+        st[e] = v0;
+        st[8 * 64 * 8 + e] = v1;
+    }
+}
+
 // ---- fp16 stash of the training trio (r2l_fwd2<SAVE> / r2l_bwd2 -> r2l_dw16.hip) ------------------------------------------
 // What the weight-gradient GEMMs read of a layer input / output gradient is its fp16 `hi` part only (dW = G_hi^T A_hi, one
 // fp16 MFMA product per fp32 product: the rounding of both operands to 11 bits moves dW by ~5e-5 relative, the level at

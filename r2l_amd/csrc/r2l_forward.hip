@@ -286,10 +286,10 @@ extern "C" int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, co
         if (rc) return rc;
         // range-guard fallback: stream pack + launch, both returning at once unless the fp16x2 launch raised its status word
         const unsigned* st = reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block));
-        const int rp = r2l_fwd3_pack(params, n_block, const_cast<float*>(w3), (hipStream_t)stream, st);
+        const int rp = r2l_fwd2_fallback_pack(params, n_block, const_cast<float*>(w3), const_cast<float*>(w2), (hipStream_t)stream);
         if (rp) return rp;
         return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, w3, params, n_block, rgb, save_x, save_t, N,
-                                (hipStream_t)stream, st);
+                                (hipStream_t)stream, st + F2S_GO);
     }
     if (N > 0 && r2l_use_fwd3())
         return r2l_fwd3_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f,
@@ -359,16 +359,23 @@ static int forward_pose_impl(const float* c2w_host12, int64_t n_frames, int H, i
                                         nullptr, nullptr, a.N, (hipStream_t)stream);
         if (rc) return rc;
         const unsigned* st = reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block));
-        const int rp = r2l_fwd3_pack(params, n_block, const_cast<float*>(w3), (hipStream_t)stream, st);
+        const int rp = r2l_fwd2_fallback_pack(params, n_block, const_cast<float*>(w3), const_cast<float*>(w2), (hipStream_t)stream);
         if (rp) return rp;
         return r2l_fwd3_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, w3, params, n_block, rgb, nullptr,
-                                nullptr, a.N, (hipStream_t)stream, st);
+                                nullptr, a.N, (hipStream_t)stream, st + F2S_GO);
     }
     if (a.N > 0 && r2l_use_fwd3())
         return r2l_fwd3_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal,
                                 wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block), params,
                                 n_block, rgb, nullptr, nullptr, a.N, (hipStream_t)stream);
     return launch_fwd<MODE_POSE>(a, (hipStream_t)stream);
+}
+
+// The 16 status words of the fp16x2 forward stream inside `wstream` (include/r2l_hip.h: range control, telemetry)
+extern "C" const unsigned* r2l_forward_status_words(const float* wstream, int n_block) {
+    if (wstream == nullptr || n_block < 0 || n_block > R2L_MAX_BLOCKS) return nullptr;
+    const float* w2 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) + r2l_fwd3_stream_floats(n_block);
+    return reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block));
 }
 
 extern "C" int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,

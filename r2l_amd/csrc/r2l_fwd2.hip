@@ -5,72 +5,19 @@
 #include "r2l_f2.h"
 #include "r2l_coopf.h"
 
-__host__ __device__ static inline int64_t f2_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
-__host__ __device__ static inline int64_t f2_off_body_w(int layer) {
-    return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
-}
-__host__ __device__ static inline int64_t f2_off_body_b(int layer) { return f2_off_body_w(layer) + R2L_W * R2L_W; }
-__host__ __device__ static inline int64_t f2_off_tail_w(int n_block) { return f2_off_body_w(2 * n_block); }
-__host__ __device__ static inline int64_t f2_off_tail_b(int n_block) { return f2_off_tail_w(n_block) + 3 * R2L_W; }
-
 // =================================================================================================================
-// pack: flat fp32 parameters -> stage stream, stage order and slot numbering exactly as r2l_pack_fwd2_kernel; a stage is
-// [split sp (2)][tile t][lane (i,h)][slot s] fp16.  bias stage: split region 0 only: slots 0, 1 of half 0 = hi, mid.
+// pack: flat fp32 parameters -> stage stream for the activation scale the status words ask for (r2l_f2.h: range control).
+// The pack kernel only READS the status words (every workgroup derives the same scale from them); the one-thread commit
+// kernel behind it writes the scale, closes the amax epoch and clears the guard — every pack: new weights, new chance.
 // =================================================================================================================
-__device__ __forceinline__ unsigned short f2_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
-__global__ void r2l_pack_fwd2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
-    const int64_t stages = r2l_fwd3_stages(n_block);
-    const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
-        const int64_t g = idx >> 12;
-        const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
-        unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
-        unsigned short v0 = 0, v1 = 0;
-        if (g < stages) {
-            bool bias_stage = false;
-            float w = 0.f;
-            if (g == 0) {
-                bias_stage = true;
-                w = params[f2_off_head_b() + o];
-            } else if (g < 64) {
-                const int v = 8 * (int)(g - 1) + s;
-                int col;
-                if (v < 480) {
-                    const int ci = v / 20, within = v % 20, f = within >> 1;
-                    col = 21 * (3 * (8 * h + ci / 3) + ci % 3) + ((within & 1) ? 10 + f : f);
-                } else {
-                    const int e = v - 480;
-                    col = 21 * (3 * (8 * h + e / 3) + e % 3) + 20;
-                }
-                w = params[(int64_t)o * R2L_IN + col];
-            } else {
-                const int layer = (int)((g - 64) / 17), r17 = (int)((g - 64) % 17);
-                if (r17 == 0) {
-                    bias_stage = true;
-                    w = params[f2_off_body_b(layer) + o];
-                } else {
-                    const int kb = r17 - 1, T = kb >> 1, r = kb & 1;
-                    const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
-                    w = params[f2_off_body_w(layer) + (int64_t)o * R2L_W + in];
-                }
-            }
-            const _Float16 hi = (_Float16)w;
-            const _Float16 mid = (_Float16)(w - (float)hi);
-            if (bias_stage) {
-                v0 = (h == 0) ? (s == 0 ? f2_bits(hi) : (s == 1 ? f2_bits(mid) : (unsigned short)0)) : (unsigned short)0;
-            } else {
-                v0 = f2_bits(hi); v1 = f2_bits(mid);
-            }
-        }
-        const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
-        st[e] = v0;
-        st[8 * 64 * 8 + e] = v1;
-    }
+__global__ void r2l_pack_fwd2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                     const unsigned* __restrict__ status) {
+    const F2Next nx = f2_next_scale(status);
+    f2_pack_fwd_elements(params, out, n_block, nx.inv, false, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                         (int64_t)gridDim.x * blockDim.x);
 }
-// status word behind the stages: cleared by every pack (new weights: new chance)
-__global__ void r2l_fwd2_status_clear_kernel(unsigned* status) {
-    if (threadIdx.x < 16) status[threadIdx.x] = 0u;
+__global__ void r2l_fwd2_commit_kernel(unsigned* status) {
+    if (threadIdx.x == 0) f2_commit_scale(status, f2_next_scale(status), false);
 }
 
 // =================================================================================================================
@@ -249,8 +196,12 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     const unsigned hvoff = (unsigned)((tile * R2L_H16_TILE_UNITS + lane) * 16);  // this lane's unit of stage piece 0 in a slot
     const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
     constexpr bool mid = SAVE && MID;
-    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0)  // stash format word: fp16 stage pieces (a fallback launch overwrites it)
-        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;
+    // the activation scale this stream was packed for (r2l_f2.h range control): what the chain holds is x / act_s
+    const float act_s = __builtin_bit_cast(float, a.status[F2S_SCALE]);
+    if (SAVE && blockIdx.x == 0 && threadIdx.x == 0) {  // stash format word: fp16 stage pieces (a fallback launch overwrites it),
+        reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;  // and the scale of the stashed x, relu(t)
+        reinterpret_cast<float*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np) + 1] = act_s;
+    }
 #pragma unroll 1
     for (int b = 0; b < a.n_block; ++b) {
         float* const hxr = SAVE ? a.save_x + (int64_t)b * slot : nullptr;  // this block's slots
@@ -293,12 +244,13 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<f32x4*>(sy + 32 * T + 8 * q) =
-                    f32x4{x[T][4 * q] + x0[T][4 * q], x[T][4 * q + 1] + x0[T][4 * q + 1], x[T][4 * q + 2] + x0[T][4 * q + 2],
-                          x[T][4 * q + 3] + x0[T][4 * q + 3]};
+                    f32x4{(x[T][4 * q] + x0[T][4 * q]) * act_s, (x[T][4 * q + 1] + x0[T][4 * q + 1]) * act_s,
+                          (x[T][4 * q + 2] + x0[T][4 * q + 2]) * act_s, (x[T][4 * q + 3] + x0[T][4 * q + 3]) * act_s};
     }
 
-    // range guard: a value that close to 65504 may have become inf in a product's operand -> hand the launch over
-    if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+    // range control (r2l_f2.h): the wave's largest |B value| -> AMAX; one that close to 65504 may have become inf in a
+    // product's operand -> FLAG: the bf16x3 kernel behind this launch redoes it and the stream is re-packed for a larger scale
+    f2_report_amax(a.status, P.amax, lane);
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt) on the VALU -------------------------------------------------------------
     const float* tw = a.params + f2_off_tail_w(a.n_block) + 4 * h;
@@ -322,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     if (valid && h == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = p3[c] + a.params[f2_off_tail_b(a.n_block) + c];
+            const float v = p3[c] * act_s + a.params[f2_off_tail_b(a.n_block) + c];  // (the chain ran on y / act_s: exact)
             a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
         }
     }
@@ -332,11 +284,11 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 int r2l_fwd2_pack(const float* params, int n_block, float* wstream2, hipStream_t stream) {
+    unsigned* status = reinterpret_cast<unsigned*>(wstream2 + r2l_fwd2_status_offset(n_block));
     hipLaunchKernelGGL(r2l_pack_fwd2_kernel, dim3(2048), dim3(256), 0, stream, params,
-                       reinterpret_cast<unsigned short*>(wstream2), n_block);
+                       reinterpret_cast<unsigned short*>(wstream2), n_block, status);
     R2L_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(r2l_fwd2_status_clear_kernel, dim3(1), dim3(64), 0, stream,
-                       reinterpret_cast<unsigned*>(wstream2 + r2l_fwd2_status_offset(n_block)));
+    hipLaunchKernelGGL(r2l_fwd2_commit_kernel, dim3(1), dim3(64), 0, stream, status);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -18,7 +18,7 @@
 // Since r2l_fwd2.hip (three fp16 products per fp32 product) became the default this kernel is its range-guard fallback
 // (launched behind it, returns at once unless the fp16 kernel raised its status word) and the R2L_NO_FWD2=1 path; with SAVE
 // it also writes the training stash (chunked layout + ReLU mask words, r2l_common.h).
-#include "r2l_f3.h"
+#include "r2l_f2.h"  // (r2l_f3.h + the fp16x2 stream's range control: this file holds its fallback pack)
 
 __host__ __device__ static inline int64_t f3_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
 __host__ __device__ static inline int64_t f3_off_body_w(int layer) {
@@ -38,9 +38,7 @@ __host__ __device__ static inline int64_t f3_off_tail_b(int n_block) { return f3
 //   body k-block kb = 2T + r: feature 32T + 8(2r + (s>>2)) + 4h + (s&3)  — fragment registers 8r .. 8r+7 of tile T.
 //   bias stage: split region 0 only: slots 0,1,2 of half 0 = hi, mid, lo of bias[32t + i]; everything else 0.
 // =================================================================================================================
-__global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
-                                     const unsigned* __restrict__ run_if) {
-    if (run_if != nullptr && __builtin_nontemporal_load(run_if) == 0u) return;  // fallback stream: only packed when needed
+__device__ __forceinline__ void f3_pack_fwd_elements(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block) {
     const int64_t stages = r2l_fwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -92,6 +90,29 @@ __global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned 
         st[8 * 64 * 8 + e] = v1;
         st[2 * 8 * 64 * 8 + e] = v2;
     }
+}
+__global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                     const unsigned* __restrict__ run_if) {
+    if (run_if != nullptr && __builtin_nontemporal_load(run_if) == 0u) return;
+    f3_pack_fwd_elements(params, out, n_block);
+}
+// The fallback pack behind an fp16x2 forward launch (r2l_f2.h: range control).  FLAG == 0 (the launch stayed in range): GO = 0,
+// done.  Else: this (unscaled) bf16x3 stream for the r2l_fwd3 launch behind, the scale-dependent stages of the fp16x2 stream
+// for the scale f2_next_scale derives from the (still unchanged) status words — and the LAST workgroup to finish commits that
+// scale: FLAG cleared (unless the scale is exhausted), GO = 1.  Every workgroup read FLAG before any could have cleared it.
+__global__ void r2l_fwd2_fallback_pack_kernel(const float* __restrict__ params, unsigned short* __restrict__ out3,
+                                              unsigned short* __restrict__ out2, int n_block, unsigned* status) {
+    if (__builtin_nontemporal_load(status + F2S_FLAG) == 0u) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) status[F2S_GO] = 0u;
+        return;
+    }
+    const F2Next nx = f2_next_scale(status);
+    f3_pack_fwd_elements(params, out3, n_block);
+    f2_pack_fwd_elements(params, out2, n_block, nx.inv, true, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                         (int64_t)gridDim.x * blockDim.x);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(status + F2S_DONE, 1u) == gridDim.x - 1u) f2_commit_scale(status, nx, true);
 }
 
 // =================================================================================================================
@@ -338,6 +359,14 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
 int r2l_fwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if) {
     hipLaunchKernelGGL(r2l_pack_fwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
                        reinterpret_cast<unsigned short*>(wstream3), n_block, run_if);
+    R2L_CHECK(hipGetLastError());
+    return 0;
+}
+
+int r2l_fwd2_fallback_pack(const float* params, int n_block, float* wstream3, float* wstream2, hipStream_t stream) {
+    hipLaunchKernelGGL(r2l_fwd2_fallback_pack_kernel, dim3(2048), dim3(256), 0, stream, params,
+                       reinterpret_cast<unsigned short*>(wstream3), reinterpret_cast<unsigned short*>(wstream2), n_block,
+                       reinterpret_cast<unsigned*>(wstream2 + r2l_fwd2_status_offset(n_block)));
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -421,6 +421,12 @@ def main(argv=None):
         if uneven:  # this step's rays over all ranks: shard rows + what each rank's hard-ray pool appends (deterministic)
             rows = [q * loader.rows_per_file for q in shards]
             n_global = [r + (pool.extra_rays(r, i - start - 1) if pool is not None else 0) for r in rows]
+            # the ray count PREDICTED for this rank is the weight its gradient gets: it must be the batch it really holds (a
+            # shard with another row count, a pool that fills differently: silently wrong weights, and ranks that disagree
+            # on the collective sequence — ADVICE r3)
+            if rays_o.shape[0] != n_global[rank]:
+                raise RuntimeError("uneven --N_rand: rank %d holds %d rays in iteration %d, the share computed on every rank "
+                                   "says %d (shards with differing row counts?)" % (rank, rays_o.shape[0], i, n_global[rank]))
         rgb, loss_out = trainer.step(rays_o, rays_d, target, lr, perturb=args.perturb, n_global=n_global)
         if pool is not None:
             pool.update(rgb, rays_o, rays_d, target, batch_size)
@@ -430,6 +436,13 @@ def main(argv=None):
             hist_psnr = psnr if hist_psnr == 0. else hist_psnr * 0.95 + psnr * 0.05
             logger.info("[TRAIN] Iter %d data_time %.4f batch_time %.4f loss %.6f psnr %.4f hist_psnr %.4f LR %.10f" %
                         (i, t_data, t_batch, loss, psnr, hist_psnr, lr))
+            # where the fp16 kernels stand with this model (include/r2l_hip.h range control): largest |activation| / |chain
+            # gradient| of the last step, the power-of-two scales the streams run on, head-room to the guard, fallbacks so far
+            ri = trainer.range_info()
+            logger.info("[RANGE] Iter %d act_amax %.4g act_scale %g headroom x%.3g | grad_amax %.4g grad_scale %g headroom x%.3g | "
+                        "fallbacks fwd %d bwd %d" % (i, ri["amax"], ri["scale"], ri["headroom"], ri.get("grad_amax", 0.),
+                                                     ri.get("grad_scale", 1.), ri.get("grad_headroom", float("inf")),
+                                                     ri["trips"], ri.get("bwd_trips", 0)))
         if i % args.i_testset == 0:
             savedir = os.path.join(logger.gen_img_path, "testset_%s_iter%d" % (logger.ExpID, i))
             os.makedirs(savedir, exist_ok=True)

@@ -120,8 +120,11 @@ class R2LEngine:
                 off += n
         self.flat = flat
         self.device = device
-        self.wstream = torch.empty(self.lib.r2l_fwd_stream_floats(self.n_block), dtype=torch.float32, device=device)
+        # zero-filled: the status words inside carry the range-control history (include/r2l_hip.h); recycled memory of a
+        # previous engine would be taken for this one's
+        self.wstream = torch.zeros(self.lib.r2l_fwd_stream_floats(self.n_block), dtype=torch.float32, device=device)
         self._packed_version = None
+        self._status = None
 
     def mark_dirty(self):
         """Call after writing the parameters behind autograd's back (fused Adam through the C ABI)."""
@@ -156,6 +159,28 @@ class R2LEngine:
                 _lib.check(self.lib.r2l_pack_forward_layout(_ptr(self.flat), self.n_block, _ptr(self.wstream), layout,
                                                             _stream()), "r2l_pack_forward_layout")
                 self._packed_version[layout] = ver
+
+    # ---- range control telemetry (include/r2l_hip.h: "range control of the fp16 kernels") ---------------------------------
+    def status_words(self):
+        """The 16 status words of the fp16x2 forward stream as an int32 view of self.wstream (device; no sync)."""
+        if self._status is None or self._status.data_ptr() < self.wstream.data_ptr():
+            word = ctypes.cast(self.lib.r2l_forward_status_words(_ptr(self.wstream), self.n_block), ctypes.c_void_p).value
+            off = (word - self.wstream.data_ptr()) // 4
+            self._status = self.wstream[off:off + 16].view(torch.int32)
+        return self._status
+
+    def range_info(self):
+        """Where the fp16 forward kernels stand with this model's activations (synchronises: a 64-byte copy).
+        amax: largest |activation| the launches have seen (current scale epoch, else the previous one); scale: the power of
+        two the stream is packed for; headroom: 32768 * scale / amax (x-fold growth the fp16 kernels still take before a
+        launch has to be redone by the bf16x3 kernel); trips: launches that were redone; rescales: times the scale changed."""
+        w = self.status_words().cpu()
+        f = w.view(torch.float32)
+        scale = float(f[2]) if int(w[4]) == 0x52324c34 else 1.0
+        live = float(f[1]) * scale
+        amax = live if live > 0 else float(f[6])
+        return {"amax": amax, "scale": scale, "headroom": (32768.0 * scale / amax) if amax > 0 else float("inf"),
+                "trips": int(w[5]), "rescales": int(w[7]), "flag": int(w[0])}
 
     # ---- sampler tables ---------------------------------------------------------------------------------------
     def ztab(self, z_vals, perturb):

@@ -56,11 +56,15 @@ class R2LTrainer:
         # whose chain raised the range-guard word is skipped on the device (r2l_adam_step_guarded, on every rank: MAX over
         # ranks), read here STATUS_LAG steps later (no stall; the same step on every rank), and the trainer goes back to the uncut form for good.
         # Gradients are bit-identical to the staged form.  On one GPU it only adds launches (4096 rays: 0.78 ms one call, 0.85
-        # in 3 segments, 0.96 staged in 4 buckets; profiles/r03_staged_backward.txt), so the default is 1 (off) there and 3 at
-        # world > 1, where it replaces the staged form for the steps it applies to (argument, or R2L_CHAIN_SEGMENTS=n;
-        # unmeasured on more than one GPU).
-        default = "3" if self.reducer.world() > 1 and self.n_buckets > 0 else "1"
-        self.chain_segments = int(os.environ.get("R2L_CHAIN_SEGMENTS", default)) if chain_segments is None else int(chain_segments)
+        # in 3 segments, 0.96 staged in 4 buckets; profiles/r03_staged_backward.txt).  OPT-IN (argument, or
+        # R2L_CHAIN_SEGMENTS=n): the default is 1 (off) at every world size until the form has been measured on more than one
+        # GPU — it drops a batch where the reference never does, and its gain is a projection so far.
+        self.chain_segments = int(os.environ.get("R2L_CHAIN_SEGMENTS", "1")) if chain_segments is None else int(chain_segments)
+        # range control (include/r2l_hip.h): the first step is preceded by forward-only launches on its batch until the weight
+        # stream's activation scale fits this model, so that no TRAINING step has to fall back (or, segmented, be skipped)
+        # just because a checkpoint's activations sit above fp16's range.  calibrate=False: tests of the fallback itself.
+        self.calibrate = True
+        self._calibrated = False
         self.segments_disabled = False
         self.skipped_steps = 0
         self._side = None
@@ -89,7 +93,8 @@ class R2LTrainer:
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.wstream_bwd = torch.empty(self.lib.r2l_bwd_stream_floats(eng.n_block), dtype=torch.float32, device=dev)
+        # (zero-filled: its status words carry the gradient-scale history, include/r2l_hip.h)
+        self.wstream_bwd = torch.zeros(self.lib.r2l_bwd_stream_floats(eng.n_block), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self._bwd_packed = None
 
@@ -145,6 +150,8 @@ class R2LTrainer:
         if perturb <= 0:
             t_rand = None
         ztab = eng.ztab(self.ps.z_vals, perturb)
+        if self.calibrate and not self._calibrated:
+            self._calibrate(rays_o, rays_d, perturb, t_rand)
         rgb = eng.forward_rays(rays_o, rays_d, self.ps.z_vals, perturb, t_rand, save=(self.save_x, self.save_t))
         if zero_grad:
             self.grads.zero_()
@@ -179,6 +186,37 @@ class R2LTrainer:
             self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
                                      _ptr(self.loss_out), _stream()), "r2l_loss_finish")
         return rgb
+
+    # ---- range control ------------------------------------------------------------------------------------------------------
+    def _calibrate(self, rays_o, rays_d, perturb, t_rand):
+        """Once per trainer (a handful of forward-only launches and host reads before the first step): a launch that leaves
+        fp16's range is redone by the bf16x3 kernel and re-scales the stream (library side, include/r2l_hip.h); repeat until
+        a launch stays on the fp16 kernels.  Nets within range (s = 1: default init, every net measured so far): one launch."""
+        self._calibrated = True
+        eng = self.eng
+        if eng.layout_for(rays_o.shape[0], True) != 2:  # not the fp16 trio: nothing to scale
+            return
+        trips = eng.range_info()["trips"]
+        for _ in range(6):
+            eng.forward_rays(rays_o, rays_d, self.ps.z_vals, perturb, t_rand)
+            now = eng.range_info()
+            if now["trips"] == trips:
+                break
+            trips = now["trips"]
+
+    def range_info(self):
+        """Telemetry of the fp16 kernels' range control (synchronises; the driver logs it every i_print):
+        forward (engine.range_info) + 'grad_amax' / 'grad_scale' / 'grad_headroom' / 'bwd_trips' of the backward chain."""
+        info = dict(self.eng.range_info())
+        word = ctypes.cast(self.lib.r2l_backward_status_words(_ptr(self.wstream_bwd), self.eng.n_block), ctypes.c_void_p).value
+        off = (word - self.wstream_bwd.data_ptr()) // 4
+        w = self.wstream_bwd[off:off + 16].view(torch.int32).cpu()
+        f = w.view(torch.float32)
+        if int(w[9]) == 0x52324c34:
+            gscale, scaled = float(f[4]), float(f[8])
+            info.update(grad_scale=gscale, grad_amax=(scaled / gscale if gscale > 0 else 0.0),
+                        grad_headroom=(32768.0 / scaled if scaled > 0 else float("inf")), bwd_trips=int(w[10]) + int(w[0] != 0))
+        return info
 
     # ---- segmented dX chain (small steps) -----------------------------------------------------------------------------------
     def _segments_ok(self, n, uneven, shares):

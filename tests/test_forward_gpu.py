@@ -140,17 +140,26 @@ def test_small_depth_and_gain(golden_dir):
     assert (out.cpu() - ref).abs().max().item() < TOL
 
 
-def test_fp16_range_guard_falls_back(chain_variant):
-    """Activations beyond fp16's range: the fp16x2 forward raises its status word and the bf16x3 kernel behind it redoes the
-    launch, so the result still matches the oracle (3-block net with a head scaled up until |x_0| reaches ~1e5)."""
-    from model.nerf_raybased import PointSampler
+def _big_activation_net(gain=3.0e4):
+    """3-block net with a head scaled up until |x_0| reaches ~1e5 (tail scaled down to keep the sigmoid active)."""
     sd = O.make_state_dict(n_block=3, seed=4)
     sd = {k: v.clone() for k, v in sd.items()}
-    sd["head.0.weight"] *= 3.0e4
-    sd["head.0.bias"] *= 3.0e4
-    for k in sd:  # keep the output in the sigmoid's active range
+    sd["head.0.weight"] *= gain
+    sd["head.0.bias"] *= gain
+    for k in sd:
         if k.startswith("tail."):
-            sd[k] = sd[k] * 1.0e-5
+            sd[k] = sd[k] * (0.3 / gain)
+    return sd
+
+
+def test_fp16_range_control(chain_variant):
+    """Activations beyond fp16's range (|x| ~ 1e5): the FIRST fp16x2 launch raises its flag, the bf16x3 kernel behind it redoes
+    that launch — and re-packs the stream for a power-of-two activation scale, on the device (include/r2l_hip.h "range
+    control") — so every LATER launch runs on the fp16 kernels again (flag 0, no further fallbacks), all of them within the
+    parity bar of the oracle.  Launches that stay in range never change the scale: the default nets run at s = 1."""
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.engine import get_engine
+    sd = _big_activation_net()
     m = build_model(sd, 3)
     ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
     g = torch.Generator().manual_seed(11)
@@ -159,14 +168,71 @@ def test_fp16_range_guard_falls_back(chain_variant):
     d = torch.randn(n, 3, generator=g)
     emb = O.positional_embed(O.sample_train(o[:2048], d[:2048], O.z_vals(16, 2., 6.), 0.), 10)
     ref, xs, ts = O.r2l_forward(sd, emb, return_acts=True)
-    assert max(x.abs().max().item() for x in xs) > 4.0e4  # the case really leaves the guarded range
+    amax_ref = max(x.abs().max().item() for x in xs + ts)
+    assert amax_ref > 4.0e4  # the case really leaves the guarded range
+    eng = get_engine(m)
+    fp16 = chain_variant in ("main", "coopf", "coopf2")
     with torch.no_grad():
         rgb = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
-        rgb2 = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)  # second launch: status word already raised
-    assert torch.isfinite(rgb).all()
-    # relative bar: with activations of 1e5 the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 tail
-    assert (rgb[:2048].cpu() - ref).abs().max().item() < TOL
-    assert torch.equal(rgb, rgb2)
+        i1 = eng.range_info()
+        rgb2 = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
+        i2 = eng.range_info()
+        rgb3 = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
+        i3 = eng.range_info()
+    for r in (rgb, rgb2, rgb3):
+        assert torch.isfinite(r).all()
+        # relative bar: with activations of 1e5 the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 tail
+        assert (r[:2048].cpu() - ref).abs().max().item() < TOL
+    assert torch.equal(rgb2, rgb3)
+    if fp16:
+        assert i1["trips"] == 1 and i1["scale"] >= 4 and i1["flag"] == 0, i1  # redone once, re-scaled, guard open again
+        assert i2["trips"] == 1 and i3["trips"] == 1 and i3["flag"] == 0, (i2, i3)  # ... and never again
+        assert i3["scale"] == i1["scale"]
+        # telemetry: the largest |activation| of the scaled launches, in the model's own units (fp32 vs 2048 oracle rays)
+        assert 0.5 * amax_ref < i3["amax"] < 4.0 * amax_ref, (i3, amax_ref)
+        assert 4.0 <= i3["headroom"] <= 64.0, i3
+    else:
+        assert i3["trips"] == 0 and i3["scale"] == 1.0
+
+
+def test_fp16_range_control_rescales_at_pack(chain_variant):
+    """The scale follows the weights at every pack: activations that grow towards the guard without crossing it get a larger
+    scale with the NEXT pack (no launch is ever redone), activations that shrink again bring it back to 1 — and a net in
+    range is bit-identical whatever history the stream has seen (powers of two: exact)."""
+    if chain_variant not in ("main", "coopf"):
+        pytest.skip("fp16 families")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.engine import get_engine
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    g = torch.Generator().manual_seed(3)
+    n = 40000 if chain_variant == "main" else 4000
+    o, d = (torch.randn(n, 3, generator=g) * 1.5).cuda(), torch.randn(n, 3, generator=g).cuda()
+    base = O.make_state_dict(n_block=3, seed=4)
+    m = build_model(base, 3)
+    eng = get_engine(m)
+    with torch.no_grad():
+        ref = m.forward_rays(o, d, ps, perturb=0.).clone()
+        assert eng.range_info()["scale"] == 1.0
+        # |x| ~ 1.6e4: in range (no flag), above the 8192 mark
+        big = _big_activation_net(3.2e3)
+        m.load_state_dict(big)
+        r1 = m.forward_rays(o, d, ps, perturb=0.)
+        i1 = eng.range_info()
+        assert i1["trips"] == 0 and i1["scale"] == 1.0 and 8192 < i1["amax"] < 32768, i1
+        eng.mark_dirty()  # "an optimizer step": the stream is re-packed before the next launch
+        r2 = m.forward_rays(o, d, ps, perturb=0.)
+        i2 = eng.range_info()
+        assert i2["trips"] == 0 and i2["scale"] in (2.0, 4.0) and i2["rescales"] == 1, i2
+        assert (r1 - r2).abs().max().item() < 2e-5
+        # back to the small net: first launch still at the old scale (precision to spare), then s = 1 again
+        m.load_state_dict(base)
+        r3 = m.forward_rays(o, d, ps, perturb=0.)
+        assert (r3 - ref).abs().max().item() < 2e-5
+        eng.mark_dirty()
+        r4 = m.forward_rays(o, d, ps, perturb=0.)
+        i4 = eng.range_info()
+        assert i4["scale"] == 1.0 and i4["trips"] == 0, i4
+        assert torch.equal(r4, ref)
 
 
 def test_explicit_config_selects_the_family(chain_variant, monkeypatch):

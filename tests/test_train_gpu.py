@@ -341,7 +341,10 @@ def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, m
     for k in sd:
         if k.startswith("tail."):
             sd[k] = sd[k] * 1.0e-5
+    # (round 4: a trainer first calibrates the stream's activation scale on its first batch, include/r2l_hip.h "range control":
+    # the same net then never skips — checked at the end; calibrate = False reproduces a range excursion in mid-training)
     tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    tr.calibrate = False
     p0, m0 = tr.eng.flat.clone(), tr.exp_avg.clone()
     tr.forward_backward(o, d, tgt)
     assert not tr.gradients_valid()  # what a caller that reads tr.grads itself has to ask
@@ -349,22 +352,35 @@ def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, m
     torch.cuda.synchronize()
     assert torch.equal(tr.eng.flat, p0) and torch.equal(tr.exp_avg, m0)  # skipped on the device
     assert tr.drain() == 1 and tr.segments_disabled
-    tr.step(o, d, tgt, 1e-4)  # this one runs uncut, with the fallback kernels
+    tr.step(o, d, tgt, 1e-4)  # this one runs uncut (and, the stream re-scaled by the first fallback, on the fp16 kernels)
     torch.cuda.synchronize()
     assert not torch.equal(tr.eng.flat, p0) and torch.isfinite(tr.eng.flat).all()
     # the training loop never synchronises: the host runs steps ahead of the device, and the word of step i is read at the start
     # of step i + STATUS_LAG (the same step on every rank, so that all ranks leave the segmented form together); every skipped
     # step is counted (each has its own slot of the pinned ring)
     from r2l_amd.train_step import STATUS_LAG
+    # (only the FIRST step is skipped now: its fallback forward re-scaled the stream, the later segmented steps are clean)
     tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    tr.calibrate = False
     p0 = tr.eng.flat.clone()
-    for i in range(STATUS_LAG):
+    tr.step(o, d, tgt, 1e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.eng.flat, p0)
+    for i in range(STATUS_LAG - 1):
         tr.step(o, d, tgt, 1e-4)
         assert not tr.segments_disabled
-    assert torch.equal(tr.eng.flat, p0)
+    assert not torch.equal(tr.eng.flat, p0)
     tr.step(o, d, tgt, 1e-4)  # reads step 1's word first: uncut from here on
     assert tr.segments_disabled and tr.skipped_steps == 1
-    assert tr.drain() == STATUS_LAG and not torch.equal(tr.eng.flat, p0)
+    assert tr.drain() == 1
+    # the default trainer calibrates on its first batch: the same net trains segmented without a single skipped step
+    tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    p0 = tr.eng.flat.clone()
+    for i in range(STATUS_LAG + 2):
+        tr.step(o, d, tgt, 1e-4)
+    assert tr.drain() == 0 and not tr.segments_disabled and not torch.equal(tr.eng.flat, p0)
+    info = tr.range_info()
+    assert info["scale"] >= 4 and info["trips"] >= 1 and info.get("bwd_trips", 0) == 0, info
 
 
 def test_generic_mode_backward_after_forward_rays():
@@ -402,9 +418,14 @@ def test_generic_mode_backward_after_forward_rays():
         assert rel_err(g_gen[k], g_mse[k]) < 3e-4, (k, rel_err(g_gen[k], g_mse[k]))
 
 
-def test_fp16_range_guards_in_training():
-    """Activations beyond fp16's range (head scaled up until |x| ~ 1e5): the fp16 forward and the fp16 dW kernel raise
-    their status words and the bf16x3 kernels behind them redo the launches: gradients still match the oracle."""
+@pytest.mark.parametrize("calibrate", [True, False])
+def test_fp16_range_control_in_training(chain_variant, calibrate):
+    """Activations beyond fp16's range (head scaled up until |x| ~ 1e5) and chain gradients far below it (tail scaled down by
+    1e5).  calibrate = False: the step is redone by the bf16x3 kernels behind the fp16 ones (forward flag -> fp32 stash ->
+    bf16x3 dX chain and weight gradients), as in rounds 2 - 3.  calibrate = True (the trainer's default): forward-only
+    launches on the first batch re-scale the stream first (include/r2l_hip.h "range control"), so the STEP itself runs on the
+    fp16 trio — stash of x / s, dW scaled back by s at the flush — and the gradient chain on a scale corrected for the tiny
+    tail weights.  Either way rgb and every gradient match the oracle."""
     from model.nerf_raybased import PointSampler
     from r2l_amd.train_step import R2LTrainer
     sd = {k: v.clone() for k, v in O.make_state_dict(n_block=3, seed=4).items()}
@@ -423,12 +444,57 @@ def test_fp16_range_guards_in_training():
     emb = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
     loss, rgb_ref, gref = O.r2l_loss_and_grads(sd, emb, tgt)
     tr = R2LTrainer(m, ps)
-    rgb = tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda())
-    assert (rgb.cpu() - rgb_ref).abs().max().item() < 1e-4
-    grads = split_flat(tr.grads.cpu(), sd)
-    for k in sd:
-        assert torch.isfinite(grads[k]).all(), k
-        assert rel_err(grads[k], gref[k]) < 2e-3, (k, rel_err(grads[k], gref[k]))
+    tr.calibrate = calibrate
+    fp16 = chain_variant in ("main", "coopf", "coopf2", "main-exact", "coopf-exact")
+    for it in range(2):  # the second pass: same step again, now certainly on the re-scaled stream
+        rgb = tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda())
+        assert (rgb.cpu() - rgb_ref).abs().max().item() < 1e-4
+        grads = split_flat(tr.grads.cpu(), sd)
+        for k in sd:
+            assert torch.isfinite(grads[k]).all(), k
+            assert rel_err(grads[k], gref[k]) < 2e-3, (it, k, rel_err(grads[k], gref[k]))
+        info = tr.range_info()
+        if fp16:
+            assert info["scale"] >= 4 and info["trips"] == 1, info
+            # every step ran on the fp16 chains, except the uncalibrated first one (forward fell back: fp32 stash)
+            assert info["bwd_trips"] == (0 if calibrate else 1), (it, info)
+            assert info["grad_scale"] > 2.0 ** 20, info  # a-priori rule x 2^17 for the 1e-5 tail
+
+
+def test_gradient_scale_follows_the_gradients(chain_variant):
+    """The power of two the fp16 dX chain runs on is chosen on the device, step to step, from the last clean step's largest
+    chain value (r2l_bwd_prepare_kernel): kept while that lies in [2^-2, 2^13] scaled (so default nets run bit for bit on the
+    a-priori scale of rounds 1 - 3), re-centred when the gradients drift out of the band — here by rescaling the TARGETS' error
+    through lw_rgb between steps: x 2^-12 (would underflow fp16's mid halves) and x 2^+14 (would cross the guard)."""
+    if chain_variant not in ("main", "coopf", "main-exact"):
+        pytest.skip("fp16 trio")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    sd = O.make_state_dict(n_block=5, seed=2)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    gen = torch.Generator().manual_seed(5)
+    n = 40000 if chain_variant != "coopf" else 3000
+    o = (torch.randn(n, 3, generator=gen) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=gen).cuda()
+    tr = R2LTrainer(build_model(sd, 5), ps)
+    tr.forward_backward(o, d, tgt)
+    g0, i0 = tr.grads.clone(), tr.range_info()
+    tr.forward_backward(o, d, tgt)
+    i1 = tr.range_info()
+    assert torch.equal(tr.grads, g0) and i1["grad_scale"] == i0["grad_scale"] and i1["bwd_trips"] == 0  # in band: kept
+    assert 0.25 <= i1["grad_amax"] * i1["grad_scale"] <= 8192, i1
+    for factor in (2.0 ** -12, 2.0 ** 14):
+        tr.lw_rgb = factor  # the same step with every gradient x factor (a power of two: the truth is g0 * factor exactly)
+        tr.forward_backward(o, d, tgt)  # still on the old scale's estimate x factor: out of band -> re-centred already
+        ia = tr.range_info()
+        assert ia["bwd_trips"] == 0, ia
+        assert 2.0 ** 5 <= ia["grad_amax"] * ia["grad_scale"] <= 2.0 ** 9, ia
+        assert rel_err(tr.grads / factor, g0) < 1e-3
+        tr.forward_backward(o, d, tgt)
+        ib = tr.range_info()
+        assert ib["grad_scale"] == ia["grad_scale"] and ib["bwd_trips"] == 0
+    tr.lw_rgb = 1.0
 
 
 def test_coopf_two_tiles_bitwise(chain_variant, monkeypatch):
