@@ -242,6 +242,9 @@ int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_den
 int64_t r2l_teacher_param_count(void);     /* 595 844 */
 int64_t r2l_teacher_stream_floats(void);
 int r2l_pack_teacher(const float* tparams, float* wstream, void* stream);
+/* Range control of the fp16 teacher kernel: same scheme and word layout as r2l_forward_status_words (zero-fill `wstream`
+ * once after allocating it). */
+const unsigned* r2l_teacher_status_words(const float* wstream);
 
 /* raw[R,S,4] = network_query_fn(pts = o + d*z, viewdirs, NeRF): run_network (create_data.py:55-77: embed xyz L=10 and
  * dirs L=4, helpers:24-74; the netchunk loop disappears) + NeRF.forward (model/nerf_raybased.py:377-401), fused. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "r2l_backward_status_word": (_p, [_p, _i]),
     "r2l_forward_status_words": (_p, [_p, _i]),
     "r2l_backward_status_words": (_p, [_p, _i]),
+    "r2l_teacher_status_words": (_p, [_p]),
     "r2l_loss_finish": (_i, [_p, _l, _f, _p, _p]),
     "r2l_teacher_param_count": (_l, []),
     "r2l_teacher_stream_floats": (_l, []),

@@ -385,7 +385,7 @@ __host__ __device__ static inline int64_t r2l_fwd2_status_offset(int n_block) {
 __host__ __device__ static inline int64_t r2l_fwd2_stream_floats(int n_block) { return r2l_fwd2_status_offset(n_block) + 16; }
 // the 16 status words (range control of the fp16x2 forward: r2l_f2.h)
 enum { F2S_FLAG = 0, F2S_AMAX = 1, F2S_SCALE = 2, F2S_INV = 3, F2S_MAGIC = 4, F2S_TRIPS = 5, F2S_PEAK = 6, F2S_RESCALES = 7,
-       F2S_DONE = 8, F2S_GO = 9 };
+       F2S_DONE = 8, F2S_GO = 9, F2S_REFINE = 10 };
 #define F2_MAGIC 0x52324c34u
 __host__ __device__ static inline int64_t r2l_bwd3_stages(int n_block) { return 34 * (int64_t)n_block; }
 __host__ __device__ static inline int64_t r2l_bwd3_stream_floats(int n_block) {

@@ -68,6 +68,8 @@ struct F2Split {
 //   TRIPS / RESCALES   launches that fell back / commits that changed s (telemetry)
 //   PEAK      unscaled amax of the epoch closed by the last commit (telemetry; host reports max(PEAK, AMAX * SCALE))
 //   DONE / GO fallback protocol: workgroups of the fallback pack that have finished; the bf16x3 forward runs iff GO != 0
+//   REFINE    the last re-scale was a blind jump (AMAX was inf): the kernel behind the next launch re-packs once more, for the
+//             scale that launch's AMAX — now the truth — asks for (no fallback involved)
 // Policy (f2_next_scale): keep AMAX / s within [2^10, 2^13] — s = 1 for every net whose activations stay below 8192, so the
 // default-init and the measured trained nets run bit-for-bit as before.  A launch that trips is redone by the bf16x3 kernel
 // ONCE; the fallback's pack kernel re-packs the scaled stages (head + bias stages, 2.4 MB) for the new s and its last
@@ -80,7 +82,13 @@ struct F2Next {
     bool tripped;   // FLAG was set
     bool stuck;     // tripped with s already at its maximum: the flag stays (sticky fallback, as before round 4)
     bool changed;
+    bool blind;     // tripped, and AMAX was not usable: s jumped by 2^8 (REFINE is set)
 };
+// does the kernel launched behind an fp16 launch have work?  FLAG (redo + re-scale), or a pending refinement with a fresh AMAX
+__device__ __forceinline__ bool f2_rescale_due(const unsigned* st, bool& tripped) {
+    tripped = __builtin_nontemporal_load(st + F2S_FLAG) != 0u;
+    return tripped || (st[F2S_REFINE] != 0u && st[F2S_AMAX] != 0u);
+}
 __device__ __forceinline__ int f2_ceil_log2(float a) {  // smallest e with a < 2^e (a > 0, finite)
     int e = 0;
     (void)frexpf(a, &e);
@@ -97,11 +105,13 @@ __device__ __forceinline__ F2Next f2_next_scale(const unsigned* st) {
     }
     const float a = valid ? __builtin_bit_cast(float, st[F2S_AMAX]) : 0.f;  // scaled units; inf once an operand overflowed
     r.tripped = valid && st[F2S_FLAG] != 0u;
+    r.blind = false;
     int en = es;
     if (r.tripped) {
         // a value in [32768, 65504) tripped the guard while everything was still finite: AMAX is the truth; beyond that an
         // operand became inf and AMAX only says "too large": jump 2^8 and let the next launch's AMAX refine it
-        en = (a < 60000.f) ? es + (f2_ceil_log2(a) - 13 > 1 ? f2_ceil_log2(a) - 13 : 1) : es + 8;
+        r.blind = !(a < 60000.f);
+        en = r.blind ? es + 8 : es + (f2_ceil_log2(a) - 13 > 1 ? f2_ceil_log2(a) - 13 : 1);
     } else if (a >= 8192.f) {
         en = es + f2_ceil_log2(a) - 13;
     } else if (a > 0.f && a < 1024.f && es > 0) {
@@ -128,6 +138,7 @@ __device__ __forceinline__ void f2_commit_scale(unsigned* st, const F2Next& nx, 
     st[F2S_AMAX] = 0u;
     st[F2S_DONE] = 0u;
     st[F2S_GO] = (fallback && nx.tripped) ? 1u : 0u;
+    st[F2S_REFINE] = (nx.blind && !nx.stuck) ? 1u : 0u;
     st[F2S_MAGIC] = F2_MAGIC;
     st[F2S_FLAG] = nx.stuck ? 1u : 0u;
 }

@@ -102,17 +102,18 @@ __global__ void r2l_pack_fwd3_kernel(const float* __restrict__ params, unsigned 
 // scale: FLAG cleared (unless the scale is exhausted), GO = 1.  Every workgroup read FLAG before any could have cleared it.
 __global__ void r2l_fwd2_fallback_pack_kernel(const float* __restrict__ params, unsigned short* __restrict__ out3,
                                               unsigned short* __restrict__ out2, int n_block, unsigned* status) {
-    if (__builtin_nontemporal_load(status + F2S_FLAG) == 0u) {
+    bool tripped;
+    if (!f2_rescale_due(status, tripped)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) status[F2S_GO] = 0u;
         return;
     }
     const F2Next nx = f2_next_scale(status);
-    f3_pack_fwd_elements(params, out3, n_block);
+    if (tripped) f3_pack_fwd_elements(params, out3, n_block);  // (else: a refinement of the scale only, GO stays 0)
     f2_pack_fwd_elements(params, out2, n_block, nx.inv, true, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
                          (int64_t)gridDim.x * blockDim.x);
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(status + F2S_DONE, 1u) == gridDim.x - 1u) f2_commit_scale(status, nx, true);
+    if (threadIdx.x == 0 && atomicAdd(status + F2S_DONE, 1u) == gridDim.x - 1u) f2_commit_scale(status, nx, tripped);
 }
 
 // =================================================================================================================

@@ -1,7 +1,9 @@
 // r2l_teacher2.hip — the NeRF teacher's point network of r2l_teacher3.hip on the fp16 matrix pipe with two-way operand splits
 // (machinery: r2l_f2.h): three fp16 products per fp32 product, ~2^-21 relative.  Stage order, gatherers and epilogue are
 // r2l_teacher3.hip's; stages are 16 KiB.  A range guard raises a status word behind the stream and the bf16x3 kernel launched
-// behind this one redoes the launch (sticky until the next pack: the teacher's weights do not change).
+// behind this one redoes the launch — and the stream is re-packed for a power-of-two activation scale (r2l_f2.h "range
+// control": layer 0, the two embedding column blocks and every bias divided by s, the alpha / rgb heads multiplied by s: exact),
+// so the launches after it run here again: the teacher's weights do not change, a sticky guard would be for good.
 #include "r2l_f2.h"
 
 #define T2_W 256
@@ -52,7 +54,10 @@ __host__ __device__ static inline int t2_emb_col(int v, int h, int nfreq_half) {
 // =================================================================================================================
 // pack
 // =================================================================================================================
-__global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out) {
+// inv_s: 1 / activation scale (a power of two).  The hidden activations, the feature vector and the views layer's output are
+// all divided by s when layer 0 (whose input, the embedding, is not), the embedding column blocks of layer 5 and of the views
+// layer, and every bias are: kinds 0, 1, 4 below.
+__device__ __forceinline__ void t2_pack_elements(const float* __restrict__ params, unsigned short* __restrict__ out, float inv_s) {
     const T2Off off = t2_offsets();
     const int64_t total = (int64_t)(T2_STAGES + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -117,6 +122,7 @@ __global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsig
         }
         unsigned short v0 = 0, v1 = 0;
         if (have) {
+            if (kind == 0 || kind == 1 || kind == 4) w *= inv_s;
             const _Float16 hi = (_Float16)w;
             const _Float16 mid = (_Float16)(w - (float)hi);
             const unsigned short hb = __builtin_bit_cast(unsigned short, hi), mb = __builtin_bit_cast(unsigned short, mid);
@@ -131,8 +137,28 @@ __global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsig
         st[8 * 64 * 8 + e] = v1;
     }
 }
-__global__ void r2l_teacher2_status_clear_kernel(unsigned* status) {
-    if (threadIdx.x < 16) status[threadIdx.x] = 0u;
+// pack for the scale the status words ask for, then (one thread) commit it: r2l_f2.h range control, as r2l_fwd2.hip
+__global__ void r2l_pack_teacher2_kernel(const float* __restrict__ params, unsigned short* __restrict__ out,
+                                         const unsigned* __restrict__ status) {
+    t2_pack_elements(params, out, f2_next_scale(status).inv);
+}
+__global__ void r2l_teacher2_commit_kernel(unsigned* status) {
+    if (threadIdx.x == 0) f2_commit_scale(status, f2_next_scale(status), false);
+}
+// Behind every r2l_teacher2_kernel launch.  FLAG == 0 (the launch stayed in range): GO = 0, done.  Else the stream is re-packed
+// for the next scale and the last workgroup commits it: FLAG cleared, GO = 1 — the r2l_teacher3 launch behind (run_if = GO)
+// redoes this launch on its own (unscaled, always packed) stream, the next launch runs on the fp16 kernel again.
+__global__ void r2l_teacher2_rescale_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, unsigned* status) {
+    bool tripped;
+    if (!f2_rescale_due(status, tripped)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) status[F2S_GO] = 0u;
+        return;
+    }
+    const F2Next nx = f2_next_scale(status);
+    t2_pack_elements(params, out, nx.inv);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(status + F2S_DONE, 1u) == gridDim.x - 1u) f2_commit_scale(status, nx, tripped);
 }
 
 // =================================================================================================================
@@ -287,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
         }
     }
     const float* P0 = a.params;
+    const float act_s = __builtin_bit_cast(float, a.status[F2S_SCALE]);  // the activation scale the stream is packed for
 
     F2Pipe P;
     {
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
                     for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(wv[j], fmaxf(t[T][4 * q + j], 0.f), acc);
                 }
             acc += __shfl_xor(acc, 32);
-            alpha = acc + P0[off.alpha_b];
+            alpha = acc * act_s + P0[off.alpha_b];  // (the chain holds activations / act_s: exact)
         }
         f2_stage<true, true, false>(x, P, Relu4{t[0], 0, nullptr, 0}, Relu4{t[0], 4, nullptr, 0});
 #pragma unroll
@@ -407,8 +434,8 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
             }
         }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) acc3[c] = acc3[c] + __shfl_xor(acc3[c], 32) + P0[off.rgb_b + c];
-    if (!(P.amax < R2L_F2_RANGE)) atomicOr(a.status, 1u);
+    for (int c = 0; c < 3; ++c) acc3[c] = (acc3[c] + __shfl_xor(acc3[c], 32)) * act_s + P0[off.rgb_b + c];
+    f2_report_amax(a.status, P.amax, lane);  // AMAX, and FLAG if this launch belongs to the bf16x3 kernel
     if (valid && h == 0) {
         const f32x4 o4 = {acc3[0], acc3[1], acc3[2], alpha};
         *reinterpret_cast<f32x4*>(a.raw + pt * 4) = o4;
@@ -423,11 +450,11 @@ int64_t r2l_teacher2_stream_floats(void) { return t2_status_offset() + 16; }
 const unsigned* r2l_teacher2_status(const float* wstream2) { return reinterpret_cast<const unsigned*>(wstream2 + t2_status_offset()); }
 
 int r2l_teacher2_pack(const float* tparams, float* wstream2, hipStream_t stream) {
+    unsigned* status = reinterpret_cast<unsigned*>(wstream2 + t2_status_offset());
     hipLaunchKernelGGL(r2l_pack_teacher2_kernel, dim3(512), dim3(256), 0, stream, tparams,
-                       reinterpret_cast<unsigned short*>(wstream2));
+                       reinterpret_cast<unsigned short*>(wstream2), status);
     R2L_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(r2l_teacher2_status_clear_kernel, dim3(1), dim3(64), 0, stream,
-                       reinterpret_cast<unsigned*>(wstream2 + t2_status_offset()));
+    hipLaunchKernelGGL(r2l_teacher2_commit_kernel, dim3(1), dim3(64), 0, stream, status);
     R2L_CHECK(hipGetLastError());
     return 0;
 }
@@ -441,6 +468,9 @@ int r2l_teacher2_mlp(const float* rays_o, const float* rays_d, const float* view
     a.status = reinterpret_cast<unsigned*>(const_cast<float*>(wstream2) + t2_status_offset());
     const int64_t tiles = (n_pts + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     hipLaunchKernelGGL(r2l_teacher2_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+    R2L_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(r2l_teacher2_rescale_kernel, dim3(512), dim3(256), 0, stream, tparams,
+                       reinterpret_cast<unsigned short*>(const_cast<float*>(wstream2)), a.status);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -336,6 +336,12 @@ extern "C" int64_t r2l_teacher_stream_floats(void) {
     return t_stream32_floats() + r2l_teacher3_stream_floats() + r2l_teacher2_stream_floats();
 }
 
+// the 16 status words of the fp16x2 teacher stream inside `wstream` (include/r2l_hip.h: range control, telemetry)
+extern "C" const unsigned* r2l_teacher_status_words(const float* wstream) {
+    if (wstream == nullptr) return nullptr;
+    return r2l_teacher2_status(wstream + t_stream32_floats() + r2l_teacher3_stream_floats());
+}
+
 extern "C" int r2l_pack_teacher(const float* params, float* wstream, void* stream) {
     R2L_REQUIRE(params && wstream, "r2l_pack_teacher: tparams / wstream is NULL");
     hipLaunchKernelGGL(r2l_pack_teacher_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, params, wstream);
@@ -366,7 +372,7 @@ extern "C" int r2l_teacher_mlp_cfg(const float* rays_o, const float* rays_d, con
         const int rc = r2l_teacher2_mlp(rays_o, rays_d, viewdirs, z, w2, params, raw, a.n_pts, S, (hipStream_t)stream);
         if (rc) return rc;
         return r2l_teacher3_mlp(rays_o, rays_d, viewdirs, z, w3, params, raw, a.n_pts, S, (hipStream_t)stream,
-                                r2l_teacher2_status(w2));
+                                r2l_teacher2_status(w2) + F2S_GO);
     }
     if (r2l_use_fwd3())  // R2L_NO_FWD2=1: fp32-exact products on the bf16 matrix pipe (R2L_NO_FWD3=1: fp32 MFMA)
         return r2l_teacher3_mlp(rays_o, rays_d, viewdirs, z, wstream + t_stream32_floats(), params, raw, a.n_pts, S,

@@ -169,16 +169,26 @@ class NativeGradAllReducer:
 
     def submit(self, bucket, op=None):
         ct = self._ctypes
-        if op is not None:
+        if op is not None and op not in (torch.distributed.ReduceOp.SUM, torch.distributed.ReduceOp.MAX):
             raise NotImplementedError("the C-ABI exchange is a SUM of floats (include/r2l_hip.h r2l_grad_allreduce)")
+        is_max = op is not None and op == torch.distributed.ReduceOp.MAX
+        if not is_max and bucket.dtype != torch.float32:
+            raise NotImplementedError("r2l_grad_allreduce sums fp32 buffers")
         stream = torch.cuda.current_stream()
         if self._comm_stream is not None:
             ready = torch.cuda.Event()
             ready.record(stream)                    # the bucket's gradient kernels are enqueued in front of this
             self._comm_stream.wait_event(ready)
             stream = self._comm_stream
-        self._lib.check(self.lib.r2l_grad_allreduce(self._h, ct.c_void_p(bucket.data_ptr()), bucket.numel(),
-                                                    ct.c_void_p(stream.cuda_stream)), "r2l_grad_allreduce")
+        with torch.cuda.stream(stream):
+            # MAX of a flag word (the segmented trainer's step-validity word, train_step.py): "any rank raised it" is the SUM
+            # of the flags being > 0 — the exchange stays a float SUM
+            buf = (bucket != 0).to(torch.float32) if is_max else bucket
+            self._lib.check(self.lib.r2l_grad_allreduce(self._h, ct.c_void_p(buf.data_ptr()), buf.numel(),
+                                                        ct.c_void_p(stream.cuda_stream)), "r2l_grad_allreduce")
+            if is_max:
+                bucket.copy_((buf > 0).to(bucket.dtype))
+                buf.record_stream(stream)
         if self._comm_stream is not None:
             done = torch.cuda.Event()
             done.record(self._comm_stream)

@@ -104,7 +104,8 @@ class TeacherEngine:
                     p.data = v
                     off += n
             self.flat = flat
-            self.wstream = torch.empty(self.lib.r2l_teacher_stream_floats(), dtype=torch.float32, device=dev)
+            # (zero-filled: the status words inside carry the range-control history, include/r2l_hip.h)
+            self.wstream = torch.zeros(self.lib.r2l_teacher_stream_floats(), dtype=torch.float32, device=dev)
             self._ver = None
         ver = sum(p._version for p in self.params)
         if ver != self._ver:
@@ -121,6 +122,20 @@ class TeacherEngine:
                                          _ptr(z.contiguous()), _ptr(self.wstream), _ptr(self.flat), _ptr(raw), R, S,
                                          _stream(), ctypes.byref(self.cfg)), "r2l_teacher_mlp")
         return raw
+
+
+    def range_info(self):
+        """Range control of the fp16 teacher kernel (include/r2l_hip.h; as R2LEngine.range_info; synchronises)."""
+        self.ensure_packed()
+        word = ctypes.cast(self.lib.r2l_teacher_status_words(_ptr(self.wstream)), ctypes.c_void_p).value
+        off = (word - self.wstream.data_ptr()) // 4
+        w = self.wstream[off:off + 16].view(torch.int32).cpu()
+        f = w.view(torch.float32)
+        scale = float(f[2]) if int(w[4]) == 0x52324c34 else 1.0
+        live = float(f[1]) * scale
+        amax = live if live > 0 else float(f[6])
+        return {"amax": amax, "scale": scale, "headroom": (32768.0 * scale / amax) if amax > 0 else float("inf"),
+                "trips": int(w[5]), "rescales": int(w[7]), "flag": int(w[0])}
 
 
 def teacher_engine(module):

@@ -173,26 +173,27 @@ def test_fp16_range_control(chain_variant):
     eng = get_engine(m)
     fp16 = chain_variant in ("main", "coopf", "coopf2")
     with torch.no_grad():
-        rgb = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
-        i1 = eng.range_info()
-        rgb2 = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
-        i2 = eng.range_info()
-        rgb3 = m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.)
-        i3 = eng.range_info()
-    for r in (rgb, rgb2, rgb3):
+        outs, infos = [], []
+        for _ in range(5):
+            outs.append(m.forward_rays(o.cuda(), d.cuda(), ps, perturb=0.))
+            infos.append(eng.range_info())
+    for r in outs:
         assert torch.isfinite(r).all()
         # relative bar: with activations of 1e5 the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 tail
         assert (r[:2048].cpu() - ref).abs().max().item() < TOL
-    assert torch.equal(rgb2, rgb3)
     if fp16:
+        i1, i3, i5 = infos[0], infos[2], infos[4]
         assert i1["trips"] == 1 and i1["scale"] >= 4 and i1["flag"] == 0, i1  # redone once, re-scaled, guard open again
-        assert i2["trips"] == 1 and i3["trips"] == 1 and i3["flag"] == 0, (i2, i3)  # ... and never again
-        assert i3["scale"] == i1["scale"]
+        # ... and never again.  (A value beyond 65504 makes the recorded amax inf: the first re-scale is then a blind x 256 and
+        # the kernel behind the SECOND launch refines it from that launch's amax: settled from the third launch on.)
+        assert all(i["trips"] == 1 and i["flag"] == 0 for i in infos[1:]), infos
+        assert i3["scale"] == i5["scale"] and torch.equal(outs[3], outs[4])
         # telemetry: the largest |activation| of the scaled launches, in the model's own units (fp32 vs 2048 oracle rays)
-        assert 0.5 * amax_ref < i3["amax"] < 4.0 * amax_ref, (i3, amax_ref)
-        assert 4.0 <= i3["headroom"] <= 64.0, i3
+        assert 0.5 * amax_ref < i5["amax"] < 4.0 * amax_ref, (i5, amax_ref)
+        assert 4.0 <= i5["headroom"] <= 16.0, i5
     else:
-        assert i3["trips"] == 0 and i3["scale"] == 1.0
+        assert infos[-1]["trips"] == 0 and infos[-1]["scale"] == 1.0
+        assert torch.equal(outs[0], outs[4])
 
 
 def test_fp16_range_control_rescales_at_pack(chain_variant):

@@ -1,5 +1,7 @@
-"""Data-parallel training step with TWO ranks on the one GPU a test box has (RCCL refuses two ranks on one device, so the
-process group is gloo, which all-reduces CUDA tensors through the host): the real R2LTrainer path of world_size > 1 —
+"""Data-parallel training step with TWO ranks.  On a box with >= 2 GPUs: one GPU per rank and the nccl (= RCCL) backend — the
+production path, which the 1-GPU leases of the build could never run (fires the first time a node appears).  On
+the one GPU a test box usually has: both ranks on it (RCCL refuses two ranks on one device, so the process group is gloo,
+which all-reduces CUDA tensors through the host).  Either way the real R2LTrainer path of world_size > 1 —
 replica sync from rank 0, staged backward (r2l_backward_part), bucketed gradient all-reduce submitted as the buckets finish,
 Adam with grad_scale 1/world — against the single-process oracle on the FULL batch (reference: nn.DataParallel splitting
 one batch over the GPUs, /root/reference/main.py:472-479, 1374-1406)."""
@@ -22,15 +24,20 @@ from model.nerf_raybased import PointSampler
 from r2l_amd.train_step import R2LTrainer, lr_schedule
 from r2l_amd.dist_utils import bucket_plan, parameters_in_sync
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dist.init_process_group("gloo")
+multi = torch.cuda.device_count() >= world             # one GPU per rank: RCCL over xGMI; else both ranks share GPU 0 (gloo)
+torch.cuda.set_device(rank if multi else 0)
+if multi:
+    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+else:
+    dist.init_process_group("gloo")
 variant = os.environ["R2L_FORCE_VARIANT"]
+segments = int(os.environ.get("R2L_TEST_SEGMENTS", "1"))
 nb = 3
 sd0 = O.make_state_dict(n_block=nb, seed=40)           # what rank 0 builds
 sd = O.make_state_dict(n_block=nb, seed=40 + rank)     # every rank builds ITS OWN weights ...
 m = build_model(sd, nb)
 ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
-tr = R2LTrainer(m, ps)                                  # ... and continues with rank 0's
+tr = R2LTrainer(m, ps, chain_segments=segments)        # ... and continues with rank 0's
 assert tr.world() == 2 and tr.n_buckets == 4 and tr.eng.cfg.reserve_cus == 8 and "R2L_RESERVE_CUS" not in os.environ
 assert parameters_in_sync(tr.eng.flat)
 assert torch.equal(m.state_dict()["body.1.body.0.weight"].cpu(), sd0["body.1.body.0.weight"])
@@ -53,11 +60,12 @@ for step in (1, 2, 3):
         ref[k], mo[k], vo[k] = O.adam_step(ref[k], gr[k], mo[k], vo[k], step, lr)
     tr.forward_backward(o[sl].cuda(), d[sl].cuda(), tgt[sl].cuda(),
                         n_global=[cut[1] - cut[0], cut[2] - cut[1]] if uneven else None)  # every rank's ray count
-    if variant == "coopf":
-        # small steps of the default trio at world > 1: the dX chain in 3 segments, each segment's weight gradients and
+    if segments > 1:
+        # opt-in for small steps of the default trio: the dX chain in 3 segments, each segment's weight gradients and
         # all-reduce on a second stream beside the next segment; + the head bucket + the step-validity word (MAX)
         assert tr.chain_segments == 3 and tr._guard is not None and tr.reducer.pending() == 3 + 1 + 1
     else:
+        assert tr.chain_segments == 1 and tr._guard is None  # the default at every world size (ADVICE r3)
         assert tr.reducer.pending() == len(bucket_plan(nb, tr.n_buckets)) == 4   # 3 body buckets (one per block) + the head, in flight until Adam needs them
     tr.allreduce_grads()
     assert tr.reducer.pending() == 0
@@ -80,18 +88,21 @@ else:
     assert worst < 2e-5, worst
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, variant, "ok: max |param - single-process oracle| = %%.2e, min update cosine %%.6f" %% (worst, cos))
+print("rank", rank, variant, "nccl" if multi else "gloo", "ok: max |param - single-process oracle| = %%.2e, min update cosine %%.6f" %% (worst, cos))
 """
 
 
-@pytest.mark.parametrize("variant,uneven", [("coop16", False), ("main", False), ("coopf", False), ("coopf", True)])
-def test_two_ranks_train_like_one_process(tmp_path, variant, uneven):
+@pytest.mark.parametrize("variant,uneven,segments", [("coop16", False, 1), ("main", False, 1), ("coopf", False, 1),
+                                                     ("coopf", True, 1), ("coopf", False, 3), ("coopf", True, 3)])
+def test_two_ranks_train_like_one_process(tmp_path, variant, uneven, segments):
     """coopf = the default dispatch of small steps (configs[3]: 4096 rays per GPU -> one-tile cooperative fp16 chains);
-    uneven = the ranks hold 5/8 and 3/8 of the batch and weight their gradients by ray share (n_global)."""
+    uneven = the ranks hold 5/8 and 3/8 of the batch and weight their gradients by ray share (n_global); segments = 3: the
+    opt-in segmented dX chain (R2LTrainer(chain_segments=3))."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
-    env.update(MASTER_ADDR="127.0.0.1", R2L_FORCE_VARIANT=variant, R2L_TEST_UNEVEN="1" if uneven else "0")
+    env.update(MASTER_ADDR="127.0.0.1", R2L_FORCE_VARIANT=variant, R2L_TEST_UNEVEN="1" if uneven else "0",
+               R2L_TEST_SEGMENTS=str(segments))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)], env=env,
                        capture_output=True, text=True, timeout=600)

@@ -286,11 +286,12 @@ def test_render_rays_trained_like_full_chunk(mlp_path):
     assert ((dg[ok] - dr[ok]).abs() / dr[ok].abs().clamp_min(1e-3)).max().item() < 1e-3
 
 
-def test_teacher_range_guard_falls_back(mlp_path, monkeypatch):
-    """A teacher whose first hidden layer leaves fp16's range (|x| ~ 1e5 > R2L_F2_RANGE): r2l_teacher2 raises its status word
-    and the bf16x3 kernel launched behind it redoes the launch — the result is BIT FOR BIT r2l_teacher3's (forced with
-    R2L_NO_FWD2=1), matches the oracle, and stays so on the next launch (the word is sticky until the next pack).
-    Mirrors tests/test_forward_gpu.py::test_fp16_range_guard_falls_back for r2l_teacher2.hip:188,326."""
+def test_teacher_range_control(mlp_path, monkeypatch):
+    """A teacher whose first hidden layer leaves fp16's range (|x| ~ 1e5 > R2L_F2_RANGE): r2l_teacher2 raises its flag and the
+    bf16x3 kernel launched behind it redoes the launch — the result is BIT FOR BIT r2l_teacher3's (forced with R2L_NO_FWD2=1) —
+    and the stream is re-packed for a power-of-two activation scale on the device (include/r2l_hip.h "range control"; the
+    teacher's weights never change, a sticky guard would be for good): the launches after it run on the fp16 kernel again,
+    flag 0, no further fallbacks, all within the oracle's bar.  Mirrors tests/test_forward_gpu.py::test_fp16_range_control."""
     if mlp_path != "fp16x2":
         pytest.skip("one comparison")
     from r2l_amd.render import teacher_engine
@@ -312,14 +313,23 @@ def test_teacher_range_guard_falls_back(mlp_path, monkeypatch):
     with torch.no_grad():
         ref = O.run_network(sd, pts, vd[:64])
         m = make_teacher(sd)
-        raw1 = teacher_engine(m).mlp(*args).cpu()
-        raw2 = teacher_engine(m).mlp(*args).cpu()  # status word already raised
+        eng = teacher_engine(m)
+        raws, infos = [], []
+        for _ in range(5):
+            raws.append(eng.mlp(*args).cpu())
+            infos.append(eng.range_info())
         monkeypatch.setenv("R2L_NO_FWD2", "1")
         raw3 = teacher_engine(make_teacher(sd)).mlp(*args).cpu()
-    assert torch.isfinite(raw1).all()
-    assert torch.equal(raw1, raw3) and torch.equal(raw2, raw3)
-    # with 1e5-sized activations the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 layer behind it
-    assert (raw1[:64] - ref).abs().max().item() < 2e-4
+    assert torch.equal(raws[0], raw3)  # the launch that tripped: redone by the bf16x3 kernel
+    assert infos[0]["trips"] == 1 and infos[0]["scale"] >= 4 and infos[0]["flag"] == 0, infos[0]
+    assert all(i["trips"] == 1 and i["flag"] == 0 for i in infos[1:]), infos  # ... the later ones stay on the fp16 kernel
+    assert infos[2]["scale"] == infos[4]["scale"] and torch.equal(raws[3], raws[4])
+    assert 4.0 <= infos[4]["headroom"] <= 16.0 and infos[4]["amax"] > 4.0e4, infos[4]
+    for r in raws:
+        assert torch.isfinite(r).all()
+        # with 1e5-sized activations the oracle's own fp32 rounding is ~1e-2 absolute before the 1e-5 layer behind it
+        assert (r[:64] - ref).abs().max().item() < 2e-4
+        assert (r - raw3).abs().max().item() < 2e-4
 
 
 @pytest.mark.parametrize("variant", ["black_bkgd", "coarse_only", "one_net", "retraw", "jitter_fixed"])

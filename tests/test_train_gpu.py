@@ -342,34 +342,38 @@ def test_segmented_step_skips_itself_when_the_range_guard_trips(chain_variant, m
         if k.startswith("tail."):
             sd[k] = sd[k] * 1.0e-5
     # (round 4: a trainer first calibrates the stream's activation scale on its first batch, include/r2l_hip.h "range control":
-    # the same net then never skips — checked at the end; calibrate = False reproduces a range excursion in mid-training)
+    # the same net then never skips — checked at the end; calibrate = False reproduces a range excursion in mid-training.  And
+    # the guard is per launch: the fallback forward of the skipped step re-scales the stream, the NEXT step is clean.)
+    tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
+    tr.calibrate = False
+    tr.forward_backward(o, d, tgt)
+    assert not tr.gradients_valid()  # what a caller that reads tr.grads itself has to ask
+    tr.forward_backward(o, d, tgt)
+    assert tr.gradients_valid()      # the stream has been re-scaled: the same batch now stays on the fp16 kernels
     tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
     tr.calibrate = False
     p0, m0 = tr.eng.flat.clone(), tr.exp_avg.clone()
-    tr.forward_backward(o, d, tgt)
-    assert not tr.gradients_valid()  # what a caller that reads tr.grads itself has to ask
     tr.step(o, d, tgt, 1e-4)
     torch.cuda.synchronize()
     assert torch.equal(tr.eng.flat, p0) and torch.equal(tr.exp_avg, m0)  # skipped on the device
     assert tr.drain() == 1 and tr.segments_disabled
-    tr.step(o, d, tgt, 1e-4)  # this one runs uncut (and, the stream re-scaled by the first fallback, on the fp16 kernels)
+    tr.step(o, d, tgt, 1e-4)  # this one runs uncut
     torch.cuda.synchronize()
     assert not torch.equal(tr.eng.flat, p0) and torch.isfinite(tr.eng.flat).all()
     # the training loop never synchronises: the host runs steps ahead of the device, and the word of step i is read at the start
-    # of step i + STATUS_LAG (the same step on every rank, so that all ranks leave the segmented form together); every skipped
-    # step is counted (each has its own slot of the pinned ring)
+    # of step i + STATUS_LAG (the same step on every rank, so that all ranks leave the segmented form together)
     from r2l_amd.train_step import STATUS_LAG
-    # (only the FIRST step is skipped now: its fallback forward re-scaled the stream, the later segmented steps are clean)
     tr = R2LTrainer(build_model(sd, 3), ps, chain_segments=3)
     tr.calibrate = False
     p0 = tr.eng.flat.clone()
     tr.step(o, d, tgt, 1e-4)
     torch.cuda.synchronize()
-    assert torch.equal(tr.eng.flat, p0)
+    assert torch.equal(tr.eng.flat, p0)  # only the FIRST step is skipped ...
     for i in range(STATUS_LAG - 1):
         tr.step(o, d, tgt, 1e-4)
         assert not tr.segments_disabled
-    assert not torch.equal(tr.eng.flat, p0)
+    torch.cuda.synchronize()
+    assert not torch.equal(tr.eng.flat, p0)  # ... the later segmented ones are clean
     tr.step(o, d, tgt, 1e-4)  # reads step 1's word first: uncut from here on
     assert tr.segments_disabled and tr.skipped_steps == 1
     assert tr.drain() == 1
