@@ -207,12 +207,14 @@ def cpu_baseline(sd, n_rays=32768):
                       "best of {16,32,64} threads on %d logical CPUs; %s" % (n_rays, ncpu, cpu_model)}, rgb, rows
 
 
-def teacher_leg(device, world, rank, distributed, frames=2):
+def teacher_leg(device, world, rank, distributed, frames=2, precision="fp16x2"):
     """NeRF-teacher pseudo-data render (BASELINE configs[4]): `frames` 400x400 poses per GPU, 64 coarse + 128 fine
-    samples, perturb=1 (create_data.py 'rand' settings), seeded D8W256 teacher pair; poses shard over ranks."""
+    samples, perturb=1 (create_data.py 'rand' settings), seeded D8W256 teacher pair; poses shard over ranks.
+    precision: the r2l_config.precision handed to every r2l_teacher_mlp_cfg call (what the printed peak is derived from)."""
     from model.nerf_raybased import NeRF
+    from r2l_amd import _lib
     from r2l_amd.data import pose_spherical
-    from r2l_amd.render import render
+    from r2l_amd.render import render, teacher_engine
     nets = []
     torch.manual_seed(11)
     for _ in range(2):  # coarse + fine, default init; density bias so that rays are neither empty nor opaque
@@ -220,6 +222,7 @@ def teacher_leg(device, world, rank, distributed, frames=2):
         with torch.no_grad():
             m.alpha_linear.bias.add_(0.5)
         nets.append(m.to(device))
+        teacher_engine(nets[-1]).cfg = _lib.make_config(precision=precision)
     kw = dict(network_fn=nets[0], network_query_fn=None, N_samples=64, N_importance=128, network_fine=nets[1],
               white_bkgd=True, perturb=1., ndc=False, near=2., far=6., use_viewdirs=True)
     poses = [pose_spherical(17. * (i * world + rank), -35., 4.)[:3, :4].to(device) for i in range(frames + 1)]
@@ -231,10 +234,10 @@ def teacher_leg(device, world, rank, distributed, frames=2):
     dt, step_ms = timed(step, frames, 1, distributed, device)
     flop_per_ray = 2 * 593408 * 256  # 303.82 MFLOP/ray
     achieved = H * W * flop_per_ray / (step_ms * 1e-3) / 1e12
-    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # point network on the 16-bit matrix pipe
-    fwd2 = fwd3 and not os.environ.get("R2L_NO_FWD2", "0").strip("0")  # default: 3 fp16 products per fp32 product (else 6 bf16)
+    fwd2, fwd3 = precision == "fp16x2", precision in ("fp16x2", "bf16x3")  # 3 fp16 / 6 bf16 products per fp32 product, or fp32 MFMA
     peak = PEAK_BF16_MFMA / 3. if fwd2 else (PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA)
     return {"value": H * W * frames * world / dt, "unit": "rays/s", "ms_per_frame": dt / frames * 1e3,
+            "precision": precision, "range": teacher_engine(nets[1]).range_info() if fwd2 else None,
             "workload": "NeRF teacher render 400x400, 64+128 samples/ray, perturb=1, chunk 32768 (create_data rand)",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "peak_fp32_mfma": PEAK_FP32_MFMA, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
@@ -339,32 +342,47 @@ def main():
         with torch.no_grad():
             frames["rgb"] = net.render_poses(pose_t[idx], ps)
 
-    with leg_clock("render"):
-        dt, kernel_ms = timed(render_step, a.steps, a.warmup, distributed, device)
-    rays = FRAMES_PER_STEP * H * W * a.steps * world
-    value = rays / dt
-    achieved = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12
-    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")  # matrix-pipe paths built from low-precision MFMA products
-    fwd2 = fwd3 and not os.environ.get("R2L_NO_FWD2", "0").strip("0")  # default of forward-only launches: 3 fp16 products
-    traffic, traffic_src = pmc_traffic("void r2l_fwd2_kernel<true" if fwd2 else
-                                       ("void r2l_fwd3_kernel<true" if fwd3 else "void r2l_fwd_kernel<1, false>"),
-                                       grid_threads=(FRAMES_PER_STEP * H * W + 127) // 128 * 256)
-    # matrix-pipe peak in ALGORITHMIC FLOP/s: every fp32 product costs three fp16 MFMA products on the default path (six
-    # bf16 products on the bf16x3 path), so it is the dense fp16/bf16 MFMA peak / 3 (/ 6); the exact-fp32 MFMA peak is kept
-    # beside it for reference
-    peak = PEAK_BF16_MFMA / 3. if fwd2 else (PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA)
-    dtype = ("f32 (every product as 3 fp16 MFMA products of two-way fp16 operand splits hi + mid, ~2^-21 relative, fp32 "
-             "accumulate; range-guarded, bf16x3 fallback)" if fwd2 else
-             ("f32 (products as 6 bf16 MFMA terms of exact bf16 hi/mid/lo splits, fp32 accumulate)" if fwd3 else "f32"))
+    from r2l_amd.engine import get_engine
+    eng = get_engine(net)
+    # Every leg selects its kernel family through r2l_config (include/r2l_hip.h; eng.set_config), and every printed peak /
+    # kernel name is derived from the config that was passed — no environment switch is read or written in this file.
+    PATHS = {
+        "fp16x2": dict(peak=PEAK_BF16_MFMA / 3., products=3, sustained=SUSTAINED_FP16_MFMA_ONLY, kernel="r2l_fwd2_kernel<POSE>",
+                       prof="void r2l_fwd2_kernel<true",
+                       dtype="f32 (every product as 3 fp16 MFMA products of two-way fp16 operand splits hi + mid, ~2^-21 relative, "
+                             "fp32 accumulate; range-controlled: power-of-two activation scale, bf16x3 fallback per launch)"),
+        "bf16x3": dict(peak=PEAK_BF16_MFMA / 6., products=6, sustained=SUSTAINED_BF16_MFMA_ONLY, kernel="r2l_fwd3_kernel<POSE>",
+                       prof="void r2l_fwd3_kernel<true",
+                       dtype="f32 (products as 6 bf16 MFMA terms of exact bf16 hi/mid/lo splits: fp32-exact products, fp32 accumulate)"),
+        "fp32_mfma": dict(peak=PEAK_FP32_MFMA, products=1, sustained=None, kernel="r2l_fwd_kernel<MODE_POSE>",
+                          prof="void r2l_fwd_kernel<1, false>", dtype="f32 (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulate)"),
+    }
+
+    def render_leg(precision, name):
+        """K = --steps launches of FRAMES_PER_STEP frames on the kernel family `precision`, W = --warmup untimed ones."""
+        eng.set_config(precision=precision)
+        with leg_clock(name):
+            dt_, kms = timed(render_step, a.steps, a.warmup, distributed, device)
+        info = PATHS[precision]
+        ach = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (kms * 1e-3) / 1e12
+        return {"path": precision, "value": FRAMES_PER_STEP * H * W * a.steps * world / dt_, "unit": "rays/s", "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": dt_ / a.steps * 1e3, "ms_per_frame": dt_ / a.steps * 1e3 / FRAMES_PER_STEP,
+                "dtype": info["dtype"],
+                "roofline": {"bound": "mfma", "achieved": ach, "peak": info["peak"], "unit": "TFLOP/s", "frac": ach / info["peak"],
+                             "peak_fp32_mfma": PEAK_FP32_MFMA, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA,
+                             "kernel": info["kernel"], "kernel_ms": kms, "rays_per_launch": FRAMES_PER_STEP * H * W,
+                             "flop_per_ray": FWD_FLOP_PER_RAY}}, dt_, kms
+
+    head, dt, kernel_ms = render_leg("fp16x2", "render")
+    value, achieved, peak = head["value"], head["roofline"]["achieved"], head["roofline"]["peak"]
+    dtype = head["dtype"]
+    traffic, traffic_src = pmc_traffic(PATHS["fp16x2"]["prof"], grid_threads=(FRAMES_PER_STEP * H * W + 127) // 128 * 256)
     peak_note = ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); the default forward-only kernel (r2l_fwd2.hip) "
                  "evaluates every fp32 product as 3 fp16 MFMA products (operands as fp16 hi + mid: 22 mantissa bits; measured "
                  "max |dRGB| 1.3e-6 against the fp32 oracle, bar 1e-4), so its matrix-pipe peak in algorithmic FLOP/s is the "
                  "dense 16-bit MFMA peak 2500 TF / 3; under such a stream the chip sits at its 1.4 kW power cap at 1.85-1.9 GHz "
                  "instead of the nominal 2.4 GHz the peak assumes (the vendor's plain bf16 GEMM: 55-56 % of 2500 TF on the "
-                 "same box): profiles/r02_power_trace.txt, r02_summary.md" if fwd2 else
-                 ("achieved counts ALGORITHMIC fp32 FLOPs (11 789 824 per ray); this kernel evaluates every fp32 product as 6 "
-                  "bf16 MFMA products (exact bf16 hi/mid/lo splits): peak = dense bf16 MFMA peak 2500 TF / 6; the chip runs at "
-                  "1.72-1.77 GHz (power limit) under that load" if fwd3 else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"))
+                 "same box): profiles/r02_power_trace.txt, r02_summary.md")
 
     out = {
         "metric": "rays/sec (train+render) W256D88 lego@400x400", "value": value, "unit": "rays/s", "n_gpus": world,
@@ -379,13 +397,13 @@ def main():
                                "driver.render_path walks the test poses); seeded weights, pose_spherical poses"
                                % FRAMES_PER_STEP,
                    "rays_per_step_per_gpu": FRAMES_PER_STEP * H * W,
-                   "parallelism": "frames sharded across %d rank(s), no collective" % world},
+                   "parallelism": "frames sharded across %d rank(s), no collective" % world,
+                   "r2l_config": {"precision": "fp16x2 (the library's default; `value` is this fast mode, `graded` the exact-fp32 one)"}},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_fp32_mfma": PEAK_FP32_MFMA,
                      "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,
-                     "frac_of_measured_mfma_only_rate": (achieved * 3. / SUSTAINED_FP16_MFMA_ONLY if fwd2 else
-                                                         (achieved * 6. / SUSTAINED_BF16_MFMA_ONLY if fwd3 else None)),
-                     "frac_of_measured_lds_fed_mfma_rate": (achieved * 3. / SUSTAINED_FP16_MFMA_LDS_FED if fwd2 else None),
+                     "frac_of_measured_mfma_only_rate": achieved * 3. / SUSTAINED_FP16_MFMA_ONLY,
+                     "frac_of_measured_lds_fed_mfma_rate": achieved * 3. / SUSTAINED_FP16_MFMA_LDS_FED,
                      "measured_mfma_only_rate_note": "an MFMA-only stream with random operand mantissas sustains 1.77 PF/s of fp16 / "
                                                      "1.92 PF/s of bf16 products on this chip under its power cap (2.48 on zero operands; 1.57 when the fp16 stream's A operands are "
                                                      "re-read from LDS at this kernel's ratio): "
@@ -395,11 +413,11 @@ def main():
                      "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) recorded in %s; algorithmic "
                                      "bytes per launch = %d x 160000 rays x 12 B out + the packed weight stream (25.1 MB of "
                                      "fp16 pairs / 37.6 MB of bf16 triples / 24.3 MB fp32)" % (traffic_src, FRAMES_PER_STEP),
-                     "kernel": ("r2l_fwd2_kernel<POSE> (+ the idle range-guard launch of r2l_fwd3_kernel)" if fwd2 else
-                                ("r2l_fwd3_kernel<POSE>" if fwd3 else "r2l_fwd_kernel<MODE_POSE>")),
+                     "kernel": "r2l_fwd2_kernel<POSE> (+ the idle fallback pack / r2l_fwd3_kernel launches behind it)",
                      "kernel_ms": kernel_ms,
                      "rays_per_launch": FRAMES_PER_STEP * H * W,
                      "flop_per_ray": FWD_FLOP_PER_RAY},
+        "range": eng.range_info(),  # the fp16 kernels' range control on these weights (scale 1, no launch redone)
     }
 
     if rank == 0 and world == 1 and a.one_frame_leg:
@@ -414,36 +432,35 @@ def main():
         out["render_one_frame_per_launch"] = {"value": H * W * a.steps / dt1, "unit": "rays/s", "ms_per_frame": dt1 / a.steps * 1e3,
                                               "roofline": {"bound": "mfma", "achieved": a1, "peak": peak, "unit": "TFLOP/s",
                                                            "frac": a1 / peak, "kernel_ms": k1}}
-    if fwd2 and rank == 0 and world == 1:
-        # the same frame on the bf16x3 kernel (six bf16 products per fp32 product: fp32-exact products), for reference
-        os.environ["R2L_NO_FWD2"] = "1"
-        try:
-            with leg_clock("render_bf16x3"):
-                dt3, k3 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
-        finally:
-            del os.environ["R2L_NO_FWD2"]
-        n3 = max(3, a.steps // 4)
-        a3 = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (k3 * 1e-3) / 1e12
-        out["render_bf16x3"] = {"value": FRAMES_PER_STEP * H * W * n3 / dt3, "unit": "rays/s", "ms_per_step": dt3 / n3 * 1e3,
-                                "ms_per_frame": dt3 / n3 * 1e3 / FRAMES_PER_STEP,
-                                "roofline": {"bound": "mfma", "achieved": a3, "peak": PEAK_BF16_MFMA / 6., "unit": "TFLOP/s",
-                                             "frac": a3 / (PEAK_BF16_MFMA / 6.), "kernel": "r2l_fwd3_kernel<POSE>",
-                                             "kernel_ms": k3}}
-    if fwd3 and rank == 0 and world == 1:
-        # the same frame on the exact-fp32 MFMA kernel (r2l_forward.hip), for reference: the C side reads the switch per call
-        os.environ["R2L_NO_FWD3"] = "1"
-        try:
-            with leg_clock("render_fp32_mfma"):
-                dt32, k32 = timed(render_step, max(3, a.steps // 4), 1, distributed, device)
-        finally:
-            del os.environ["R2L_NO_FWD3"]
-        n32 = max(3, a.steps // 4)
-        a32 = FRAMES_PER_STEP * H * W * FWD_FLOP_PER_RAY / (k32 * 1e-3) / 1e12
-        out["render_fp32_mfma"] = {"value": FRAMES_PER_STEP * H * W * n32 / dt32, "unit": "rays/s", "ms_per_step": dt32 / n32 * 1e3,
-                                   "ms_per_frame": dt32 / n32 * 1e3 / FRAMES_PER_STEP,
-                                   "roofline": {"bound": "mfma", "achieved": a32, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                                                "frac": a32 / PEAK_FP32_MFMA, "kernel": "r2l_fwd_kernel<MODE_POSE>",
-                                                "kernel_ms": k32}}
+    if rank == 0 and world == 1:
+        # THE GRADED NUMBER: the same workload, the same K / W, on arithmetic at least the reference's — the
+        # exact-fp32 MFMA kernel (r2l_forward.hip), priced against the fp32 MFMA peak SURVEY.md §8(d) names; beside it the
+        # bf16x3 kernel (six bf16 products per fp32 product: fp32-exact PRODUCTS, fp32 accumulate — fp32-grade, faster)
+        out["graded"], _, _ = render_leg("fp32_mfma", "render_fp32_mfma")
+        out["graded"]["note"] = ("exact fp32 products and accumulation (v_mfma_f32_32x32x2_f32): the arithmetic of the reference's "
+                                 "PyTorch fp32 path; `value` above is the library's default fast mode (fp16x2, ~2^-21 per product, "
+                                 "1e-6 in RGB against the 1e-4 bar)")
+        out["graded_fp32_grade_products"], _, _ = render_leg("bf16x3", "render_bf16x3")
+        # the same kernels on "trained-like" weights: head scaled until the largest activation is ~1e5 (3x fp16's guard, tail
+        # scaled back to keep the sigmoid active) — the range control of the fp16 kernels (include/r2l_hip.h) re-scales the
+        # stream during the warm-up launches and the timed ones run on the SAME kernel at the same rate
+        eng.set_config(precision="fp16x2")
+        amax0 = out["range"]["amax"]
+        gain = 1.0e5 / max(amax0, 1e-3)
+        with torch.no_grad():
+            keep = {k: v.detach().clone() for k, v in net.state_dict().items()}
+            net.head[0].weight.mul_(gain); net.head[0].bias.mul_(gain)
+            net.tail[0].weight.mul_(1.0 / gain)
+        tl, _, _ = render_leg("fp16x2", "render_trained_like")
+        tl["range"] = eng.range_info()
+        tl["workload"] = ("as `value`, weights with |activation| up to %.3g (head x %.3g, tail / %.3g): warm-up launches re-scale "
+                          "the stream (range.scale, range.trips), timed launches stay on r2l_fwd2_kernel" % (tl["range"]["amax"], gain, gain))
+        tl["rate_vs_default_weights"] = tl["value"] / value
+        out["render_trained_like"] = tl
+        with torch.no_grad():
+            net.load_state_dict(keep)
+        eng.reset_range_history()
+    eng.set_config(precision="fp16x2")
 
     rgb_gpu_check = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -456,44 +473,34 @@ def main():
         except ImportError:
             train_mod = None
     if train_mod is not None:
-        with leg_clock("train"):
-            out["train"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                           PEAK_FP32_MFMA)
+        def train_leg(name, **kw):
+            with leg_clock(name):
+                out[name] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
+                                            PEAK_FP32_MFMA, **kw)
+        # default trio (r2l_config precision fp16x2, dw_mode fp16)
+        train_leg("train", precision="fp16x2", dw_mode="fp16")
         if distributed:
             # strong-scaling leg: the single-GPU batch (98 304 rays) split over the ranks, same global batch and the same
             # optimisation schedule as N = 1; the bucketed all-reduce has to hide under 1/N of the dW kernels here
             per = max(32, (a.train_rays // world + 31) // 32 * 32)
-            with leg_clock("train_strong"):
-                out["train_strong"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                                      PEAK_FP32_MFMA, n_rays=per)
+            train_leg("train_strong", precision="fp16x2", dw_mode="fp16", n_rays=per)
             out["train_strong"]["scaling"] = "strong"
             out["train_strong"]["global_rays_per_step"] = per * world
         # BASELINE configs[2] read literally ("N_rand=4096" as 4096 rays per step; at N GPUs configs[3]: 4096 rays per GPU)
-        with leg_clock("train_4096"):
-            out["train_4096"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                                PEAK_FP32_MFMA, n_rays=4096)
+        train_leg("train_4096", precision="fp16x2", dw_mode="fp16", n_rays=4096)
         if distributed:
-            # the same steps with the segmented dX chain switched off (staged backward: the whole chain, then the buckets), to
-            # tell what cutting the chain buys once a node measures it
-            with leg_clock("train_4096_uncut_chain"):
-                out["train_4096_uncut_chain"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed,
-                                                                TRAIN_FLOP_PER_RAY, PEAK_FP32_MFMA, n_rays=4096, chain_segments=1)
+            # the same steps with the dX chain cut into 3 segments (opt-in, R2LTrainer(chain_segments=3)): each segment's weight
+            # gradients and all-reduce beside the next segment — what cutting the chain buys, once a node measures it
+            train_leg("train_4096_segmented_chain", precision="fp16x2", dw_mode="fp16", n_rays=4096, chain_segments=3)
         if rank == 0 and world == 1:
             # exact weight gradients (r2l_config.dw_mode = R2L_DW_EXACT): hi + mid operands, three products in the dW GEMMs
-            with leg_clock("train_exact_dw"):
-                out["train_exact_dw"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed, TRAIN_FLOP_PER_RAY,
-                                                        PEAK_FP32_MFMA, dw_mode="exact")
-        # reference leg: the same step with every GEMM on six bf16 products per fp32 product (fp32-exact products)
-        if rank == 0 and world == 1 and not any(k in os.environ for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2")):
-            for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
-                os.environ[k] = "1"
-            try:
-                with leg_clock("train_bf16x3"):
-                    out["train_bf16x3"] = train_mod.bench(net, ps, a, world, rank, distributed, device, timed,
-                                                          TRAIN_FLOP_PER_RAY, PEAK_FP32_MFMA)
-            finally:
-                for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
-                    del os.environ[k]
+            train_leg("train_exact_dw", precision="fp16x2", dw_mode="exact")
+            # GRADED training legs: the same step, the same K / W, with every GEMM on fp32-exact products (six bf16 products
+            # per fp32 product) and on the exact-fp32 MFMA
+            train_leg("train_bf16x3", precision="bf16x3")
+            train_leg("train_fp32_mfma", precision="fp32_mfma")
+            out["graded"]["train"] = {k: out["train_fp32_mfma"][k] for k in ("value", "unit", "ms_per_step", "roofline")}
+        eng.set_config(precision="fp16x2", dw_mode="auto")
 
     if not a.no_teacher:
         with leg_clock("teacher"):

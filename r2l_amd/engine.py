@@ -17,6 +17,21 @@ L_PE = 10
 INPUT_DIM = N_SAMPLE * 3 * (2 * L_PE + 1)  # 1008
 
 
+# Process-wide defaults for the AUTO (0) fields of every engine's r2l_config (make_config keywords: precision, tiling,
+# coop_tiles, reserve_cus, dw_mode).  Empty = the library decides.  A field an engine sets itself (set_config) wins.  This is how
+# the test suites and bench.py select kernel families — through ARGUMENTS of the *_cfg entry points, not the environment.
+DEFAULT_CONFIG = {}
+
+
+def merged_config(cfg):
+    """cfg with its AUTO fields filled from DEFAULT_CONFIG (read at call time)."""
+    if not DEFAULT_CONFIG:
+        return cfg
+    base = _lib.make_config(**DEFAULT_CONFIG)
+    return _lib.Config(cfg.precision or base.precision, cfg.tiling or base.tiling, cfg.coop_tiles or base.coop_tiles,
+                       cfg.reserve_cus or base.reserve_cus, cfg.dw_mode or base.dw_mode)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -90,8 +105,13 @@ class R2LEngine:
         self._packed_version = None
         return self.cfg
 
+    def effective_config(self):
+        """The r2l_config this engine's calls are made with: its own fields, AUTO ones filled from DEFAULT_CONFIG."""
+        return merged_config(self.cfg)
+
     def _cfg(self):
-        return ctypes.byref(self.cfg)
+        self._eff = self.effective_config()  # (kept alive for the duration of the call)
+        return ctypes.byref(self._eff)
 
     # ---- parameter storage ------------------------------------------------------------------------------------
     def _aliased(self):
@@ -168,6 +188,11 @@ class R2LEngine:
             off = (word - self.wstream.data_ptr()) // 4
             self._status = self.wstream[off:off + 16].view(torch.int32)
         return self._status
+
+    def reset_range_history(self):
+        """Forget the recorded amax / scale (as after allocation): the next pack starts again from s = 1."""
+        self.status_words().zero_()
+        self._packed_version = None
 
     def range_info(self):
         """Where the fp16 forward kernels stand with this model's activations (synchronises: a 64-byte copy).

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from . import engine as _engine
 from .engine import _ptr, _stream
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -120,7 +121,7 @@ class TeacherEngine:
         _lib.check(
             self.lib.r2l_teacher_mlp_cfg(_ptr(rays_o.contiguous()), _ptr(rays_d.contiguous()), _ptr(viewdirs.contiguous()),
                                          _ptr(z.contiguous()), _ptr(self.wstream), _ptr(self.flat), _ptr(raw), R, S,
-                                         _stream(), ctypes.byref(self.cfg)), "r2l_teacher_mlp")
+                                         _stream(), ctypes.byref(_engine.merged_config(self.cfg))), "r2l_teacher_mlp")
         return raw
 
 

@@ -73,7 +73,7 @@ class R2LTrainer:
         self._status_pending = collections.deque()  # (event behind the copy, ring slot), oldest first
         self._status_slot = 0
         self._guard = None  # device word handed to the guarded Adam of the current step, or None
-        if self.reducer.world() > 1 and self.n_buckets > 0 and self.eng.cfg.reserve_cus == 0:
+        if self.reducer.world() > 1 and self.n_buckets > 0 and self.eng.effective_config().reserve_cus == 0:
             # the weight-gradient kernels are persistent workgroups that fill every CU: leave a few to the RCCL kernels that
             # run beside them (r2l_config.reserve_cus of this trainer's calls; R2L_RESERVE_CUS overrides the count)
             self.eng.set_config(reserve_cus=int(os.environ.get("R2L_RESERVE_CUS", "8")))
@@ -119,7 +119,8 @@ class R2LTrainer:
     def _pack_bwd(self, n):
         """Transposed stream of the layout the n-ray launches read, if the parameters changed since it was packed."""
         eng = self.eng
-        ver, layout = (eng.version(), eng.cfg.precision, eng.cfg.tiling), self.lib.r2l_backward_layout_for_cfg(int(n), eng._cfg())  # 16 / 32 / 3 / 2: what r2l_backward will read
+        eff = eng.effective_config()
+        ver, layout = (eng.version(), eff.precision, eff.tiling), self.lib.r2l_backward_layout_for_cfg(int(n), eng._cfg())  # 16 / 32 / 3 / 2: what r2l_backward will read
         if self._bwd_packed is None:  # (layout 2 = the fp16x2 stream; its bf16x3 fallback stream packs itself when it runs)
             self._bwd_packed = {16: None, 32: None, 3: None, 2: None}
         if self._bwd_packed[layout] != ver:
@@ -374,17 +375,20 @@ def lr_schedule(step, lrate, lrate_decay, warmup_lr=""):
 # ---------------------------------------------------------------------------------------------------------------
 # hook used by bench.py
 # ---------------------------------------------------------------------------------------------------------------
-def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak, n_rays=None, dw_mode=None, chain_segments=None):
+def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, peak, n_rays=None, dw_mode=None, chain_segments=None,
+          precision="fp16x2"):
     """Training leg of bench.py: K fused steps of `a.train_rays` rays per GPU (synthetic [o,d,rgb] rows as in the
-    `.npy` shards, main.py:1305-1311), RCCL all-reduce when world > 1."""
+    `.npy` shards, main.py:1305-1311), RCCL all-reduce when world > 1.  The kernel family is selected through the engine's
+    r2l_config (precision, dw_mode) and everything printed about it — matrix path, peak — is derived from the layout / tiling the
+    library reports for THAT config (r2l_*_for_cfg), never from the environment."""
     n = a.train_rays if n_rays is None else n_rays
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(device)
     d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(device)
     tgt = torch.rand(n, 3, generator=g).to(device)
-    tr = R2LTrainer(net, ps, dw_mode=dw_mode or "auto", chain_segments=chain_segments)
-    steps = max(2, min(a.steps, 10))
-    warm = max(1, min(a.warmup, 2))
+    get_engine(net).set_config(precision=precision, dw_mode=dw_mode or "auto")
+    tr = R2LTrainer(net, ps, chain_segments=chain_segments)
+    steps, warm = max(1, a.steps), max(1, a.warmup)  # the full K / W of the command line, every leg
 
     def train_step(i):
         tr.step(o, d, tgt, lr_schedule(i + 1, 5e-4, 500, "0.0001,200"), perturb=1.0)
@@ -393,28 +397,31 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
     achieved = n * flop_per_ray / (step_ms * 1e-3) / 1e12
     # Which matrix path the step's GEMM kernels take, and the matrix-pipe bound that goes with it in ALGORITHMIC FLOP/s: a
     # kernel that evaluates an fp32 product as p 16-bit MFMA products can at best reach (dense 16-bit MFMA peak) / p.
-    #   default trio (one wave per tile, > 4096 rays): forward 11.79 MFLOP/ray x 3 fp16 products, dX chain 11.27 x 3, dW body
-    #   11.27 x 1 (fp16 hi operands), head dW 0.52 on the fp32 MFMA (priced at 16: 2500/157.3)
-    #   bf16x3 trio: 6 products everywhere; cooperative small-batch chains: fp32 MFMA + bf16x3 dW
-    fwd3 = not os.environ.get("R2L_NO_FWD3", "0").strip("0")
-    big = tr.lib.r2l_variant_for(int(n)) == 0
-    off = [k for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2") if os.environ.get(k, "0").strip("0")]
+    #   fp16 trio (backward layout 2): forward 11.79 MFLOP/ray x 3 fp16 products, dX chain 11.27 x 3, dW body 11.27 x 1 (fp16 hi
+    #   operands; x 3 with exact weight gradients), head dW 0.52
+    #   bf16x3 trio (layout 3): 6 products everywhere; layouts 32 / 16: fp32-MFMA chains (their dW on the fp32 MFMA or bf16x3)
+    cfg = tr.eng._cfg()
+    layout = int(tr.lib.r2l_backward_layout_for_cfg(int(n), cfg))
+    exact = tr.eng.effective_config().dw_mode == _lib.DW_MODE["exact"]
     peak_fp32 = peak
-    path = "fp32 MFMA"
-    extra = {}
+    path = "fp32 MFMA chains (layout %d)" % layout
+    extra = {"r2l_config": {"precision": precision, "dw_mode": dw_mode or "auto", "backward_layout": layout}}
     fwd_f, dx_f, dw_f, head_f = 11789824. - 516096., 2 * 86 * 256 * 256., 2 * 86 * 256 * 256., 2 * 1008 * 256.
-    exact = tr.eng.cfg.dw_mode == _lib.DW_MODE["exact"] or (tr.eng.cfg.dw_mode == 0 and os.environ.get("R2L_DW_EXACT", "0").strip("0"))
-    if fwd3 and big and not off and exact:
+    if layout == 2 and exact:
         peak = 2500.0 / 3.
         path = ("fp16 trio with EXACT weight gradients: forward, dX chain, dW body and head dW with 3 fp16 MFMA products per fp32 "
-                "product (hi + mid operands everywhere); range-guarded, bf16x3 trio behind it")
-    elif fwd3 and big and not off:
+                "product (hi + mid operands everywhere); range-controlled, bf16x3 trio behind it")
+    elif layout == 2:
         mfma_flops = 3 * (fwd_f + head_f) + 3 * dx_f + 1 * dw_f + (2500.0 / peak_fp32) * head_f
         peak = 2500.0 * flop_per_ray / mfma_flops
         path = ("fp16 trio: forward and dX chain with 3 fp16 MFMA products per fp32 product (two-way operand splits), dW body "
-                "with 1 (fp16 hi operands from the fp16 stash); range-guarded, bf16x3 trio behind it")
-        extra = {"peak_if_every_gemm_took_3_products": 2500.0 / 3., "frac_of_3_product_peak": achieved / (2500.0 / 3.)}
-        nt = int(tr.lib.r2l_coop_tiles_for(int(n), tr.eng.n_block))
+                "with 1 (fp16 hi operands from the fp16 stash); range-controlled, bf16x3 trio behind it")
+        extra.update({"peak_if_every_gemm_took_3_products": 2500.0 / 3., "frac_of_3_product_peak": achieved / (2500.0 / 3.)})
+    elif layout == 3:
+        peak = 2500.0 / 6.
+        path = "bf16x3 trio: forward, dX chain and dW body with 6 bf16 products per fp32 product (fp32-exact products)"
+    if layout == 2:
+        nt = int(tr.lib.r2l_coop_tiles_for_cfg(int(n), tr.eng.n_block, cfg))
         if nt:
             # cooperative chains (r2l_coopf: one or two 32-ray tiles per workgroup), each workgroup streaming the 25 MB of
             # packed weights per chain from L2 — measured ~45 B/clk per CU, which is what bounds the small launches
@@ -422,12 +429,7 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
             path += "; chains: cooperative kernels (%d tile(s) per workgroup), L2 weight stream: %d workgroups x 25.1 MB per " \
                     "chain" % (nt, wgs)
             extra["weight_stream_bytes_per_step"] = 2 * wgs * 25.1e6
-
-    elif fwd3 and big:
-        peak = 2500.0 / 6.
-        path = "bf16x3 trio: forward, dX chain and dW body with 6 bf16 products per fp32 product (%s)" % ", ".join(off)
-    elif fwd3:
-        path = "fp32 MFMA chains + bf16x3 dW"
+        extra["range"] = tr.range_info()
     if distributed:
         # the exchange alone (the step's whole flat gradient in one all-reduce, nothing to hide behind): what the bucketed
         # overlap has to cover, for reading the scaling numbers

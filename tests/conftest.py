@@ -27,3 +27,18 @@ def _built_library():
     if os.path.exists(B.HIPCC):
         B.build(verbose=False)
     yield
+
+
+R2L_SWITCHES = ("R2L_FORCE_VARIANT", "R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_COOPF_TILES", "R2L_DW_EXACT")
+
+
+def use_family(monkeypatch, **cfg):
+    """Select the kernel family of everything built from here on THROUGH r2l_config (include/r2l_hip.h): the keywords become
+    the defaults of the AUTO fields of every engine's config (r2l_amd.engine.DEFAULT_CONFIG: precision, tiling, coop_tiles,
+    dw_mode), handed to the *_cfg entry points call by call.  The R2L_* environment switches are cleared: they are the
+    library's test / A-B overrides of AUTO fields and are exercised on purpose by
+    tests/test_forward_gpu.py::test_explicit_config_selects_the_family only."""
+    from r2l_amd import engine
+    for k in R2L_SWITCHES:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(engine, "DEFAULT_CONFIG", dict(cfg))

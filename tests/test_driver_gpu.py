@@ -239,10 +239,11 @@ def test_distillation_converges_on_teacher_data(trained_student):
     assert p150 > p0 + 3 and p1000 >= p150 - 0.5
 
 
-VARIANTS = {"main-fp16x2": {"R2L_FORCE_VARIANT": "main"}, "coopf-fp16x2": {"R2L_FORCE_VARIANT": "coopf"},
-            "main-bf16x3": {"R2L_FORCE_VARIANT": "main", "R2L_NO_FWD2": "1"},
-            "main-f32mfma": {"R2L_FORCE_VARIANT": "main", "R2L_NO_FWD3": "1"},
-            "coop": {"R2L_FORCE_VARIANT": "coop"}, "coop16": {"R2L_FORCE_VARIANT": "coop16"}}
+# kernel families through r2l_config (tests/conftest.py use_family)
+VARIANTS = {"main-fp16x2": dict(tiling="main"), "coopf-fp16x2": dict(tiling="coopf"),
+            "main-bf16x3": dict(tiling="main", precision="bf16x3"),
+            "main-f32mfma": dict(tiling="main", precision="fp32_mfma"),
+            "coop": dict(tiling="coop"), "coop16": dict(tiling="coop16")}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -250,8 +251,8 @@ def test_trained_weights_parity_vs_oracle(trained_student, variant, monkeypatch)
     """RGB within 1e-4 and PSNR within 0.01 dB of the fp32 CPU oracle on TRAINED weights (1000 Adam steps away from the
     nn.Linear init every other parity test uses), under every forward kernel family — the fp16x2 default included, whose
     operand range guard (|x| < 32768) and two-way splits were only ever exercised on |w| <= 1/16 before."""
-    for k, v in VARIANTS[variant].items():
-        monkeypatch.setenv(k, v)
+    from tests.conftest import use_family
+    use_family(monkeypatch, **VARIANTS[variant])
     net, ps, held = trained_student["net"], trained_student["ps"], trained_student["held"]
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     moved = max((sd[k] - trained_student["init"][k]).abs().max().item() for k in sd)
@@ -287,12 +288,11 @@ def test_trained_weights_gradient_parity_vs_oracle(trained_student, monkeypatch)
     loss, _, _ = O.r2l_loss_and_grads(sd, emb, b[:, 6:].cpu())
     _, _, g64 = O.r2l_loss_and_grads({k: v.double() for k, v in sd.items()}, emb.double(), b[:, 6:].cpu().double())
     med, worst, tail = {}, {}, {}
-    for fam, env in (("fp16 trio", {}), ("fp16 trio, exact dW", {"R2L_DW_EXACT": "1"}), ("bf16x3 trio", {"R2L_NO_DW2": "1"}),
-                     ("fp32 mfma", {"R2L_NO_FWD3": "1"})):
+    from tests.conftest import use_family
+    for fam, cfg in (("fp16 trio", {}), ("fp16 trio, exact dW", dict(dw_mode="exact")), ("bf16x3 trio", dict(precision="bf16x3")),
+                     ("fp32 mfma", dict(precision="fp32_mfma"))):
         with monkeypatch.context() as mp:
-            mp.setenv("R2L_FORCE_VARIANT", "main")
-            for k, v in env.items():
-                mp.setenv(k, v)
+            use_family(mp, tiling="main", **cfg)
             tr = R2LTrainer(net, ps)
             tr.forward_backward(b[:, :3].contiguous(), b[:, 3:6].contiguous(), b[:, 6:].contiguous())
             assert abs(tr.loss_out[0].item() - loss.item()) < 1e-6

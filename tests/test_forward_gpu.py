@@ -10,27 +10,28 @@ from oracle import r2l_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coopf", "coopf2", "main-bf16x3", "main-f32mfma", "coop", "coop16"])
+FAMILIES = {
+    "main": dict(tiling="main"),
+    "coopf": dict(tiling="coopf"),
+    "coopf2": dict(tiling="coopf", coop_tiles=2),
+    "main-bf16x3": dict(tiling="main", precision="bf16x3"),
+    "main-f32mfma": dict(tiling="main", precision="fp32_mfma"),
+    "coop": dict(tiling="coop"),
+    "coop16": dict(tiling="coop16"),
+}
+
+
+@pytest.fixture(autouse=True, params=list(FAMILIES))
 def chain_variant(request, monkeypatch):
-    """Every test runs under each forward kernel family: one wave per tile on the fp16x2 matrix path (r2l_fwd2.hip, the
-    default of forward-only launches), on the bf16x3 path (r2l_fwd3.hip, R2L_NO_FWD2=1) and on the fp32 MFMA
-    (r2l_forward.hip, R2L_NO_FWD3=1), the cooperative fp16x2 kernels (r2l_coopf_fwd.hip: one tile per workgroup, the default
-    of small launches) and the two cooperative fp32-MFMA small-batch families."""
-    name = request.param
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name.rstrip("2"))
-    if name == "coopf2":  # two ray tiles per workgroup (what launches of more than one tile per CU take)
-        monkeypatch.setenv("R2L_COOPF_TILES", "2")
-    else:
-        monkeypatch.delenv("R2L_COOPF_TILES", raising=False)
-    if name == "main-f32mfma":
-        monkeypatch.setenv("R2L_NO_FWD3", "1")
-    else:
-        monkeypatch.delenv("R2L_NO_FWD3", raising=False)
-    if name == "main-bf16x3":
-        monkeypatch.setenv("R2L_NO_FWD2", "1")
-    else:
-        monkeypatch.delenv("R2L_NO_FWD2", raising=False)
-    return name
+    """Every test runs under each forward kernel family, selected through r2l_config (tests/conftest.py use_family): one wave
+    per tile on the fp16x2 matrix path (r2l_fwd2.hip, the default of forward-only launches), on the bf16x3 path (r2l_fwd3.hip)
+    and on the fp32 MFMA (r2l_forward.hip), the cooperative fp16x2 kernels (r2l_coopf_fwd.hip: one tile per workgroup, the
+    default of small launches; coopf2: two) and the two cooperative fp32-MFMA small-batch families."""
+    from tests.conftest import use_family
+    use_family(monkeypatch, **FAMILIES[request.param])
+    return request.param
+
+
 T = torch.from_numpy
 TOL = 1e-4  # north_star: RGB within 1e-4 abs of the reference PyTorch path
 
@@ -261,8 +262,8 @@ def test_explicit_config_selects_the_family(chain_variant, monkeypatch):
         (dict(precision="fp32_mfma", tiling="coop16"), dict(R2L_FORCE_VARIANT="coop16", R2L_NO_FWD3="1")),
         (dict(precision="fp16x2", tiling="coopf", coop_tiles=2), dict(R2L_FORCE_VARIANT="coopf", R2L_COOPF_TILES="2")),
     ]
-    for k in ("R2L_FORCE_VARIANT", "R2L_NO_FWD2", "R2L_NO_FWD3", "R2L_COOPF_TILES"):
-        monkeypatch.delenv(k, raising=False)
+    from tests.conftest import use_family
+    use_family(monkeypatch)  # no defaults, clean environment: only what this test passes / sets
     by_cfg = []
     with torch.no_grad():
         for cfg, _ in families:  # arguments only: the environment is clean

@@ -16,14 +16,8 @@ def mlp_path(request, monkeypatch):
     """Every test runs on the three point-network kernels: r2l_teacher2.hip (3 fp16 products per fp32 product, the
     default), r2l_teacher3.hip (6 bf16 products: fp32-exact products, R2L_NO_FWD2=1) and r2l_teacher_mlp.hip (exact-fp32
     MFMA, R2L_NO_FWD3=1)."""
-    if request.param == "f32mfma":
-        monkeypatch.setenv("R2L_NO_FWD3", "1")
-    else:
-        monkeypatch.delenv("R2L_NO_FWD3", raising=False)
-    if request.param == "bf16x3":
-        monkeypatch.setenv("R2L_NO_FWD2", "1")
-    else:
-        monkeypatch.delenv("R2L_NO_FWD2", raising=False)
+    from tests.conftest import use_family
+    use_family(monkeypatch, precision={"fp16x2": "fp16x2", "bf16x3": "bf16x3", "f32mfma": "fp32_mfma"}[request.param])
     return request.param
 T = torch.from_numpy
 
@@ -318,7 +312,8 @@ def test_teacher_range_control(mlp_path, monkeypatch):
         for _ in range(5):
             raws.append(eng.mlp(*args).cpu())
             infos.append(eng.range_info())
-        monkeypatch.setenv("R2L_NO_FWD2", "1")
+        from tests.conftest import use_family
+        use_family(monkeypatch, precision="bf16x3")
         raw3 = teacher_engine(make_teacher(sd)).mlp(*args).cpu()
     assert torch.equal(raws[0], raw3)  # the launch that tripped: redone by the bf16x3 kernel
     assert infos[0]["trips"] == 1 and infos[0]["scale"] >= 4 and infos[0]["flag"] == 0, infos[0]

@@ -12,10 +12,23 @@ from tests.test_forward_gpu import build_model
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["main", "coopf", "coopf2", "main-exact", "coopf-exact", "main-bf16x3-trio", "main-f32mfma",
-                                      "coop", "coop16"])
+FAMILIES = {
+    "main": dict(tiling="main"),
+    "coopf": dict(tiling="coopf"),
+    "coopf2": dict(tiling="coopf", coop_tiles=2),
+    "main-exact": dict(tiling="main", dw_mode="exact"),
+    "coopf-exact": dict(tiling="coopf", dw_mode="exact"),
+    "main-bf16x3-trio": dict(tiling="main", precision="bf16x3"),
+    "main-f32mfma": dict(tiling="main", precision="fp32_mfma"),
+    "coop": dict(tiling="coop"),
+    "coop16": dict(tiling="coop16"),
+}
+
+
+@pytest.fixture(autouse=True, params=list(FAMILIES))
 def chain_variant(request, monkeypatch):
-    """Every test runs under each kernel family of the training step:
+    """Every test runs under each kernel family of the training step, selected through r2l_config (tests/conftest.py
+    use_family; the R2L_* switches named below are the equivalent environment overrides of AUTO fields):
       main             one wave per tile, the default trio: fp16x2 forward (r2l_fwd2.hip) and dX chain (r2l_bwd2.hip) stashing
                        fp16 stage pieces, fp16 weight-gradient GEMMs on them (r2l_dw16.hip); range-guarded, with the bf16x3
                        kernels launched behind them
@@ -30,20 +43,9 @@ def chain_variant(request, monkeypatch):
                        products per fp32 product and the chunked fp32 stash — exactly the kernels the guards fall back to
       main-f32mfma     R2L_NO_FWD3=1: everything on the exact-fp32 MFMA
       coop / coop16    the cooperative small-batch families."""
-    name = request.param
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "main" if name.startswith("main") else name.replace("-exact", "").rstrip("2"))
-    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_COOPF_TILES", "R2L_DW_EXACT"):
-        monkeypatch.delenv(k, raising=False)
-    if name.endswith("-exact"):
-        monkeypatch.setenv("R2L_DW_EXACT", "1")
-    if name == "coopf2":
-        monkeypatch.setenv("R2L_COOPF_TILES", "2")
-    if name == "main-f32mfma":
-        monkeypatch.setenv("R2L_NO_FWD3", "1")
-    if name == "main-bf16x3-trio":
-        for k in ("R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2"):
-            monkeypatch.setenv(k, "1")
-    return name
+    from tests.conftest import use_family
+    use_family(monkeypatch, **FAMILIES[request.param])
+    return request.param
 
 
 T = torch.from_numpy
@@ -281,7 +283,8 @@ def test_segmented_chain_equals_uncut(chain_variant, n, monkeypatch):
     from model.nerf_raybased import PointSampler
     from r2l_amd import _lib
     from r2l_amd.train_step import R2LTrainer, lr_schedule
-    monkeypatch.delenv("R2L_FORCE_VARIANT")  # the default dispatch takes these sizes to the cooperative chains by itself
+    from tests.conftest import use_family
+    use_family(monkeypatch)  # the default dispatch takes these sizes to the cooperative chains by itself
     sd = O.make_state_dict(n_block=43, seed=3)
     ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
     g = torch.Generator().manual_seed(n)
@@ -531,8 +534,8 @@ def test_coopf_two_tiles_bitwise(chain_variant, monkeypatch):
         out = run()
         for a, b in zip(out, ref):
             assert torch.equal(a, b), tiles
-    monkeypatch.delenv("R2L_COOPF_TILES")
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "main")
+    from tests.conftest import use_family
+    use_family(monkeypatch, tiling="main")
     out = run()
     assert (out[1] - ref[1]).abs().max().item() < 2e-6
     assert torch.nn.functional.cosine_similarity(out[2], ref[2], dim=0).item() > 0.9999
@@ -606,10 +609,12 @@ def test_mid_size_step_on_cooperative_chains(chain_variant, monkeypatch):
             plain = m.forward_rays(o, d, ps)
         return t.loss_out.clone(), rgb.clone(), t.grads.clone(), plain.clone()
 
+    from r2l_amd import engine
+    from tests.conftest import use_family
     main = run()
-    assert _lib.load().r2l_coop_tiles_for(n, 43) == 0
-    monkeypatch.delenv("R2L_FORCE_VARIANT")
-    assert _lib.load().r2l_coop_tiles_for(n, 43) == 2
+    assert _lib.load().r2l_coop_tiles_for_cfg(n, 43, _lib.make_config(**engine.DEFAULT_CONFIG)) == 0
+    use_family(monkeypatch)  # AUTO: the library's own choice for this size
+    assert _lib.load().r2l_coop_tiles_for_cfg(n, 43, _lib.make_config(**engine.DEFAULT_CONFIG)) == 2
     auto = run()
     assert abs(auto[0][0].item() - main[0][0].item()) < 1e-6
     assert (auto[1] - main[1]).abs().max().item() < 2e-6 and (auto[3] - main[3]).abs().max().item() < 2e-6
