@@ -41,10 +41,14 @@ class R2LEmbFunction(torch.autograd.Function):
         dpre = torch.empty(n * 3, **f)
         slab = torch.empty(int(lib.r2l_dw_slab_floats()), **f)
         drgb = grad_rgb.reshape(-1, 3).contiguous().float()
+        # The pre-embedded path always runs on the exact-fp32 MFMA kernels with a row-major stash (r2l_forward_emb has one
+        # kernel); of the engine's r2l_config only `tiling` applies — which fp32 chain walks the backward — and `reserve_cus`;
+        # precision / dw_mode concern the fused (ray-input) path only
         _lib.check(
-            lib.r2l_backward(None, None, None, None, _ptr(emb2), _ptr(rgb), None, _ptr(drgb), _ptr(save_x),
-                             _ptr(save_t), _ptr(wbwd), _ptr(eng.flat), nb, 0.0, _ptr(dpre), _ptr(gx), _ptr(gt), None,
-                             _ptr(grads), _ptr(slab), n, _stream()), "r2l_backward")
+            lib.r2l_backward_part_cfg(None, None, None, None, _ptr(emb2), _ptr(rgb), None, _ptr(drgb), _ptr(save_x),
+                                      _ptr(save_t), _ptr(wbwd), _ptr(eng.flat), nb, 0.0, _ptr(dpre), _ptr(gx), _ptr(gt), None,
+                                      _ptr(grads), _ptr(slab), n, _stream(), _lib.BWD_ALL, 0, 2 * nb, eng._cfg()),
+            "r2l_backward")
         out, off = [], 0
         for p in eng.params:
             k = p.numel()

@@ -414,10 +414,12 @@ def test_generic_mode_backward_after_forward_rays():
     assert torch.equal(rgb, rgb2)
     drgb = ((2.0 / (3.0 * n)) * (rgb2 - tgt)).contiguous()
     tr.grads.zero_()
-    _lib.check(tr.lib.r2l_backward(_ptr(o), _ptr(d), None, _ptr(eng.ztab(ps.z_vals, 0.)), None, _ptr(rgb2), None, _ptr(drgb),
-                                   _ptr(tr.save_x), _ptr(tr.save_t), _ptr(tr.wstream_bwd), _ptr(eng.flat), eng.n_block, 0.0,
-                                   _ptr(tr.dpre), _ptr(tr.gx), _ptr(tr.gt), None, _ptr(tr.grads), _ptr(tr.dw_slab), n,
-                                   _stream()), "r2l_backward (generic)")
+    # (the config the forward was given: a stash is only readable by the family that wrote it, include/r2l_hip.h)
+    _lib.check(tr.lib.r2l_backward_part_cfg(_ptr(o), _ptr(d), None, _ptr(eng.ztab(ps.z_vals, 0.)), None, _ptr(rgb2), None,
+                                            _ptr(drgb), _ptr(tr.save_x), _ptr(tr.save_t), _ptr(tr.wstream_bwd), _ptr(eng.flat),
+                                            eng.n_block, 0.0, _ptr(tr.dpre), _ptr(tr.gx), _ptr(tr.gt), None, _ptr(tr.grads),
+                                            _ptr(tr.dw_slab), n, _stream(), _lib.BWD_ALL, 0, 2 * eng.n_block, eng._cfg()),
+               "r2l_backward (generic)")
     g_gen = split_flat(tr.grads.cpu(), sd)
     for k in sd:
         assert torch.isfinite(g_gen[k]).all(), k
