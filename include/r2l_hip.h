@@ -283,6 +283,20 @@ int64_t r2l_ssim_partial_count(int H, int W, int C);
 int r2l_ssim(const float* img1, const float* img2, int H, int W, int C, const float* window_host, float* partial,
              float* out, void* stream);
 
+/* ---- frame writer (host threads; test-set evaluation) ------------------------------------------------------------------
+ * Replaces `imageio.imwrite(filename, to8b(rgb))` of every prediction / ground-truth frame in render_path (main.py:337-344):
+ * a pool of encoder threads (zlib, Sub filter; lossless, so the decoded pixels are the bytes handed over).  `pixels`: HOST
+ * buffer of H*W*C bytes (C = 1, 3 or 4; row-major), owned by the caller and left untouched until the job is done;
+ * `ready_event`: NULL, or a hipEvent_t the worker waits for before reading `pixels` (the frame's asynchronous device-to-host
+ * copy).  r2l_png_writer_wait(job): job and all earlier ones are on disk (job < 0: everything submitted); non-zero if any
+ * job failed (r2l_last_error).  level: zlib 0..9 (1: ~2 ms per 400x400 frame). */
+typedef struct r2l_png_writer r2l_png_writer;
+int r2l_png_writer_open(int n_threads, int level, r2l_png_writer** out);
+int r2l_png_writer_submit(r2l_png_writer* w, const char* path, const unsigned char* pixels, int H, int W, int C,
+                          void* ready_event, int64_t* job_id);
+int r2l_png_writer_wait(r2l_png_writer* w, int64_t job_id);
+int r2l_png_writer_close(r2l_png_writer* w);
+
 /* ---- ray-shard reader (host threads; --data_mode rays) ------------------------------------------------------------
  * Replaces BlenderDataset_v2.__getitem__ (dataset/load_blender.py:257-324: np.load of one [4096,9] f32 shard),
  * InfiniteSamplerWrapper (main.py:759-776: random permutations of the file list, forever) and the DataLoader's

@@ -85,6 +85,10 @@ SIGNATURES = {
     "r2l_sample_pdf_sort": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
     "r2l_ssim_partial_count": (_l, [_i, _i, _i]),
     "r2l_ssim": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "r2l_png_writer_open": (_i, [_i, _i, _p]),
+    "r2l_png_writer_submit": (_i, [_p, ctypes.c_char_p, _p, _i, _i, _i, _p, _p]),
+    "r2l_png_writer_wait": (_i, [_p, _l]),
+    "r2l_png_writer_close": (_i, [_p]),
     "r2l_npy_shape": (_i, [ctypes.c_char_p, _p, _p]),
     "r2l_reader_open": (_i, [_p, _l, _i, _i, ctypes.c_uint64, _p, _i, _p]),
     "r2l_reader_info": (_i, [_p, _p, _p, _p]),

@@ -109,7 +109,7 @@ def build(verbose=True, force=False):
     rebuilt = any(c for _, c in results) or not os.path.exists(LIB)
     if rebuilt:
         tmp = "%s.%d.tmp" % (LIB, os.getpid())  # link aside, then rename: other ranks never see a half-written .so
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lz"]  # zlib: csrc/r2l_png.hip
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -3,6 +3,7 @@ training with hard-ray mining / checkpoints), mirroring the control flow of the 
 accelerated path only.  One process per GPU; under torchrun the ray shards, test frames and log output are
 rank-partitioned and the only collective is the flat-gradient all-reduce inside R2LTrainer.
 """
+import ctypes
 import math
 import os
 import time
@@ -155,46 +156,61 @@ def render_frame(model, point_sampler, c2w):
 
 
 class _FrameWriter:
-    """PNG writing off the render loop: the frame is quantised to 8 bit on the device (same rounding as to8b), copied
-    non-blocking into a pinned buffer, and a small thread pool waits for the copy and encodes (zlib releases the GIL).
-    At 13 ms per rendered frame, encoding two 400x400 PNGs inline (~2 x 15 ms) would triple the wall time."""
+    """PNG writing off the render loop (replaces the inline imageio.imwrite of main.py:337-344): the frame is quantised to 8
+    bit on the device (same rounding as to8b), copied non-blocking into a pinned buffer, and handed — with the event behind
+    the copy — to the library's encoder threads (include/r2l_hip.h r2l_png_writer_*: native threads, zlib level 1, no GIL).
+    Rounds 1 - 3 encoded with PIL in Python threads: ~15 ms per 400x400 PNG with the GIL held around zlib, which made the
+    test-set loop encoder-bound (6.5 ms/frame against 4.5 without images, profiles/r03_e2e_render.txt)."""
 
-    # (measured with the 4.4 ms forward, one frame per launch: 4 workers 11.1, 8: 6.5, 12: 6.5 ms/frame.  With 9 frames per launch
-    # 18 images arrive at once: the pinned staging slots must cover two groups, or save() blocks on the encoders before the next
-    # group's render is launched — 8 slots: 11.0 ms/frame)
-    def __init__(self, device, workers=8, slots=4 * POSES_PER_LAUNCH + 4):
-        from concurrent.futures import ThreadPoolExecutor
-        self.device, self.pool, self.pending = device, ThreadPoolExecutor(max_workers=workers), []
-        self.slots, self.bufs = slots, {}
+    # With 9 frames per launch 18 images arrive at once: the pinned staging slots must cover two groups, or save() blocks on the
+    # encoders before the next group's render is launched.
+    def __init__(self, device, workers=None, slots=4 * POSES_PER_LAUNCH + 4, level=1):
+        from . import _lib
+        self._lib, self.lib = _lib, _lib.load()
+        self.device, self.slots = device, slots
+        n = workers or max(4, min(16, os.cpu_count() or 8))
+        self._h = ctypes.c_void_p()
+        _lib.check(self.lib.r2l_png_writer_open(n, level, ctypes.byref(self._h)), "r2l_png_writer_open")
+        self.inflight = []  # (job id, what must stay alive until it is done, recyclable pinned buffer or None)
+        self.free = {}
 
-    @staticmethod
-    def _save(arr, path, event, release):
-        from PIL import Image
-        if event is not None:
-            event.synchronize()
-        Image.fromarray(arr).save(path)
-        release()
+    def _submit(self, path, ptr, shape, event):
+        H, W = int(shape[0]), int(shape[1])
+        C = int(shape[2]) if len(shape) == 3 else 1
+        job = ctypes.c_int64()
+        self._lib.check(self.lib.r2l_png_writer_submit(self._h, os.fsencode(path), ctypes.c_void_p(ptr), H, W, C,
+                                                       ctypes.c_void_p(event) if event else None, ctypes.byref(job)),
+                        "r2l_png_writer_submit")
+        return job.value
+
+    def _retire(self, n_keep):
+        while len(self.inflight) > n_keep:
+            job, _, host = self.inflight.pop(0)
+            self._lib.check(self.lib.r2l_png_writer_wait(self._h, job), "r2l_png_writer_wait")
+            if host is not None:
+                self.free.setdefault(tuple(host.shape), []).append(host)
 
     def save(self, img, path):
         """img: float [H,W,3] in [0,1] (device or host tensor / array)."""
         if isinstance(img, torch.Tensor) and img.is_cuda:
-            q = (255 * torch.clamp(img, 0, 1)).to(torch.uint8)  # float -> uint8 truncates, as numpy's astype does
+            q = (255 * torch.clamp(img, 0, 1)).to(torch.uint8).contiguous()  # float -> uint8 truncates, as numpy's astype does
             key = tuple(q.shape)
-            free = self.bufs.setdefault(key, [])
-            while not free and len(self.pending) >= self.slots:
-                self.pending.pop(0).result()
+            free = self.free.setdefault(key, [])
+            if not free:
+                self._retire(self.slots - 1)
             host = free.pop() if free else torch.empty(key, dtype=torch.uint8, pin_memory=True)
             host.copy_(q, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self.pending.append(self.pool.submit(self._save, host.numpy(), path, ev, lambda h=host: free.append(h)))
+            self.inflight.append((self._submit(path, host.data_ptr(), key, ev.cuda_event), (ev, q), host))
         else:
-            self.pending.append(self.pool.submit(self._save, to8b(img), path, None, lambda: None))
+            arr = np.ascontiguousarray(to8b(img))
+            self.inflight.append((self._submit(path, arr.ctypes.data, arr.shape, None), arr, None))
 
     def close(self):
-        for f in self.pending:
-            f.result()
-        self.pool.shutdown()
+        self._retire(0)
+        self._lib.check(self.lib.r2l_png_writer_close(self._h), "r2l_png_writer_close")
+        self._h = ctypes.c_void_p()
 
 
 def save_video(rgbs, logger, expid, iter_, tag, rank=0, world=1, device=None):
@@ -233,7 +249,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     rgbs, sq_err, psnrs, ssims, events = [], [], [], [], []
     if savedir is not None:
         os.makedirs(savedir, exist_ok=True)  # every rank writes its own frames: none may rely on rank 0's mkdir
-    writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "12"))) if savedir is not None else None
+    writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "0")) or None) if savedir is not None else None
     on_gpu = device.type == "cuda"
     t_loop = time.time()
     def account(i, rgb):

@@ -598,3 +598,45 @@ def test_logger_layout_round_trips_through_parse_expid_iter(tmp_path, monkeypatc
     assert parse_expid_iter(os.path.join(lg.weights_path, "ckpt_1000.tar")) == (lg.ExpID, "ckpt_1000")
     other = Logger(argparse.Namespace(experiment_name="x", debug=True), rank=1)  # other ranks: same attributes, no files
     assert other.exp_path.startswith("Debug_Dir") and not os.path.exists(other.exp_path)
+
+
+def test_native_png_writer_round_trip(tmp_path):
+    """include/r2l_hip.h r2l_png_writer_*: the encoder threads that replace imageio.imwrite in render_path (main.py:337-344).
+    RGB, grey and RGBA frames, odd sizes, many jobs in flight, out-of-order completion: every file decodes (PIL) to exactly the
+    bytes handed over; wait(job) covers all earlier jobs; a path that cannot be written is reported, not swallowed."""
+    import ctypes
+    import numpy as np
+    from PIL import Image
+    from r2l_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.r2l_png_writer_open(0, 1, ctypes.byref(h)) != 0 and b"n_threads" in lib.r2l_last_error()
+    _lib.check(lib.r2l_png_writer_open(4, 1, ctypes.byref(h)), "open")
+    rng = np.random.default_rng(0)
+    jobs = []
+    for i, shape in enumerate([(400, 400, 3), (37, 53, 3), (1, 1, 3), (64, 48, 1), (33, 17, 4)] * 6):
+        if i % 2:  # smooth content (compresses) and noise (does not)
+            arr = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        else:
+            yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+            arr = np.stack([(xx * 3 + yy * (c + 1) + i) % 256 for c in range(shape[2])], -1).astype(np.uint8)
+        arr = np.ascontiguousarray(arr)
+        path = str(tmp_path / ("f%03d.png" % i))
+        job = ctypes.c_int64()
+        _lib.check(lib.r2l_png_writer_submit(h, path.encode(), ctypes.c_void_p(arr.ctypes.data), shape[0], shape[1], shape[2],
+                                             None, ctypes.byref(job)), "submit")
+        assert job.value == i
+        jobs.append((path, arr))
+    _lib.check(lib.r2l_png_writer_wait(h, 9), "wait")  # jobs 0 .. 9 are on disk now
+    for path, arr in jobs[:10]:
+        got = np.asarray(Image.open(path))
+        assert np.array_equal(got.reshape(arr.shape), arr), path
+    _lib.check(lib.r2l_png_writer_wait(h, -1), "wait all")
+    for path, arr in jobs:
+        got = np.asarray(Image.open(path))
+        assert np.array_equal(got.reshape(arr.shape), arr), path
+    bad = np.zeros((2, 2, 3), np.uint8)
+    assert lib.r2l_png_writer_submit(h, str(tmp_path / "no_such_dir" / "x.png").encode(), ctypes.c_void_p(bad.ctypes.data), 2, 2, 3,
+                                     None, None) == 0
+    assert lib.r2l_png_writer_close(h) != 0 and b"cannot open" in lib.r2l_last_error()
+    assert lib.r2l_png_writer_submit(None, b"x", None, 1, 1, 3, None, None) != 0
