@@ -283,6 +283,25 @@ int64_t r2l_ssim_partial_count(int H, int W, int C);
 int r2l_ssim(const float* img1, const float* img2, int H, int W, int C, const float* window_host, float* partial,
              float* out, void* stream);
 
+/* ---- hard-ray pool (training data path) ---------------------------------------------------------------------------------
+ * The three data movements of main.py:1325-1347 (n_hard_out random pool rows [o, d, rgb] appended to every batch) and
+ * main.py:1410-1425 (the hard rays of the step enter the pool, appended until it is full, then replacing the rows that were
+ * handed out), one kernel each; ranking the per-ray errors stays a sort on the host's side of the ABI.
+ *   r2l_pool_pick: idx_out[i], i < n_out = n_out DISTINCT rows of [0, n_rows), every row equally likely: a keyed bijection
+ *     (4-round Feistel, cycle-walked) evaluated at 0 .. n_out-1 — replaces np.random.permutation(n_rows)[:n_out]; same key,
+ *     same rows.
+ *   r2l_pool_augment: out_{o,d,t}[B + n_out, 3] (contiguous) = the batch's rows (inputs may be column slices of a [B, 9] shard
+ *     batch: row strides in floats) followed by pool rows idx[0 .. n_out).
+ *   r2l_pool_store: pool[dst(i)] = [o, d, t][hard[i]], i < n_in, dst(i) = dst_idx[i] (replace) or dst0 + i (dst_idx NULL: append).
+ * pool: [rows, 9] fp32 row-major.  idx / hard / dst_idx: device int64. */
+int r2l_pool_pick(int64_t* idx_out, int64_t n_out, int64_t n_rows, uint64_t key, void* stream);
+int r2l_pool_augment(const float* rays_o, const float* rays_d, const float* target, int64_t stride_o, int64_t stride_d,
+                     int64_t stride_t, const float* pool, const int64_t* idx, int64_t B, int64_t n_out, float* out_o, float* out_d,
+                     float* out_t, void* stream);
+int r2l_pool_store(const float* rays_o, const float* rays_d, const float* target, int64_t stride_o, int64_t stride_d,
+                   int64_t stride_t, const int64_t* hard, float* pool, const int64_t* dst_idx, int64_t dst0, int64_t n_in,
+                   void* stream);
+
 /* ---- frame writer (host threads; test-set evaluation) ------------------------------------------------------------------
  * Replaces `imageio.imwrite(filename, to8b(rgb))` of every prediction / ground-truth frame in render_path (main.py:337-344):
  * a pool of encoder threads (zlib, Sub filter; lossless, so the decoded pixels are the bytes handed over).  `pixels`: HOST

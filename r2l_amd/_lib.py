@@ -85,6 +85,9 @@ SIGNATURES = {
     "r2l_sample_pdf_sort": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
     "r2l_ssim_partial_count": (_l, [_i, _i, _i]),
     "r2l_ssim": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "r2l_pool_pick": (_i, [_p, _l, _l, ctypes.c_uint64, _p]),
+    "r2l_pool_augment": (_i, [_p, _p, _p, _l, _l, _l, _p, _p, _l, _l, _p, _p, _p, _p]),
+    "r2l_pool_store": (_i, [_p, _p, _p, _l, _l, _l, _p, _p, _p, _l, _l, _p]),
     "r2l_png_writer_open": (_i, [_i, _i, _p]),
     "r2l_png_writer_submit": (_i, [_p, ctypes.c_char_p, _p, _i, _i, _i, _p, _p]),
     "r2l_png_writer_wait": (_i, [_p, _l]),

@@ -36,6 +36,15 @@
 // [G hi | A hi | G mid | A mid] = 32 KiB, four units deep like the default kernel's four tiles (a DMA instruction moves 16
 // rays of two stage pieces either way), one barrier per k-step: the same 96 KiB in flight per CU and the same continuous
 // stream.  (First version: whole tiles of 64 KiB, two deep, vmcnt(0) per tile: 4.5 TB/s instead of 5.9.)
+// (A/B: -DDW16_NT streams the stash — read exactly once — past the caches: `nt` on the LDS-DMA loads of the exact kernel)
+#ifdef DW16_NT
+__device__ __forceinline__ void dw16_dma16_nt(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+#define DW16_DMA dw16_dma16_nt
+#else
+#define DW16_DMA f3_dma16
+#endif
 template <bool EXACT> struct Dw16Cfg {
     static constexpr int NB = 4;
     static constexpr unsigned STAGE_BYTES = 32768u;
@@ -153,10 +162,10 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {  // the wave's two piece pairs (pieces 4w + 2pr, 4w + 2pr + 1), 16 rays of each
                     const unsigned po = so + (unsigned)pr * 2048u, lp = ld + (unsigned)pr * 1024u;
-                    f3_dma16(grs, dvoff, po, lp);
-                    f3_dma16(ars, dvoff, po, lp + 8192u);
-                    f3_dma16(grs, dvoff, po + a.mid_off, lp + 16384u);
-                    f3_dma16(ars, dvoff, po + a.mid_off, lp + 24576u);
+                    DW16_DMA(grs, dvoff, po, lp);
+                    DW16_DMA(ars, dvoff, po, lp + 8192u);
+                    DW16_DMA(grs, dvoff, po + a.mid_off, lp + 16384u);
+                    DW16_DMA(ars, dvoff, po + a.mid_off, lp + 24576u);
                 }
             };
             const unsigned gq = img_lds + rl + (unsigned)wo * 4096u, aq = img_lds + 8192u + rl + (unsigned)wi * 4096u;

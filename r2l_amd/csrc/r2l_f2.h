@@ -264,6 +264,10 @@ struct F2Side {
     F3Dma extra = F3Dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};  // one more 1 KiB piece, issued with step 5 (backward: mask tile)
     F2Hst hst = F2Hst{false, nullptr, 0u, 0u};  // second half stage only: stash the assembled hi operand (step 4)
     const unsigned* uh_first = nullptr;  // the first half stage's packed hi pairs (values 0-3 of the operand)
+#ifdef F2_MID_LATE  // (A/B: the mid-half store of exact weight gradients as side step 5 of the second half stage)
+    F2Hst hmid_late = F2Hst{false, nullptr, 0u, 0u};
+    u32x4 mid_bits = u32x4{0u, 0u, 0u, 0u};
+#endif
     float x[4];
     unsigned uh[2], um[2];  // packed fp16 pairs: values (0,1) and (2,3)
     static __device__ __forceinline__ unsigned pk(float a0, float a1) {
@@ -296,6 +300,9 @@ struct F2Side {
             f2_dma_piece_i(i, dma.rs, dma.voff, dma.so);
         }
         if (i == 5 && extra.on) f3_dma16(extra.rs, extra.voff, extra.so, extra.la);
+#ifdef F2_MID_LATE
+        if (i == 5 && hmid_late.on) f2_hst_store(hmid_late, mid_bits);
+#endif
         if (!want_b) return;
         if (i == 0) {
             gather(x);
@@ -403,12 +410,19 @@ __device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo g
                                          F2Hst hmid = F2Hst{false, nullptr, 0u, 0u}) {
     // exact weight gradients: the MID half of THIS stage's B operand goes to its own piece (hmid: the stage's piece +
     // R2L_H16_MID_BYTES).  It is the register quad the MFMAs of the stage read: no copy, nothing extra kept alive.
+#ifndef F2_MID_LATE
     if (!BIAS_K && hmid.on) f2_hst_store(hmid, __builtin_bit_cast(u32x4, P.sb.m));
+#endif
     F2Side<BIAS_K, GLo> sa{P.a2, P.lb, 1, glo, !BIAS_NEXT, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax, extra_a};
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
     __builtin_amdgcn_sched_barrier(0);
     P.sync_next();
+#ifdef F2_MID_LATE
+    F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax, extra_b, hst, sa.uh,
+                               F2Hst{!BIAS_K && hmid.on, hmid.slot, hmid.voff, hmid.soff}, __builtin_bit_cast(u32x4, P.sb.m)};
+#else
     F2Side<BIAS_NEXT, GHi> sb2{P.a1, P.lb, 0, ghi, !BIAS_NEXT, P.request(), P.amax, extra_b, hst, sa.uh};
+#endif
     f2_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
     __builtin_amdgcn_sched_barrier(0);
     if (BIAS_NEXT) {

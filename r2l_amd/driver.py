@@ -61,7 +61,7 @@ class HardRayPool:
         self.full = False
         self.rng = rng or np.random
         self.seed = seed
-        self._gen = None
+        self._draws = 0
         self._ix_out = None
 
     def sizes(self, batch_size):
@@ -73,11 +73,24 @@ class HardRayPool:
 
     def _pick(self, n_rows, n_out, device):
         if device.type == "cuda":
-            if self._gen is None:
-                self._gen = torch.Generator(device=device)
-                self._gen.manual_seed(self.seed)
-            return torch.randperm(n_rows, device=device, generator=self._gen)[:n_out]
+            # n_out distinct rows, every row equally likely: a keyed bijection of [0, n_rows) evaluated at 0 .. n_out-1
+            # (include/r2l_hip.h r2l_pool_pick) instead of a 1.6 M-key randperm per step; key = f(seed, draw counter)
+            from . import _lib
+            lib = _lib.load()
+            ix = torch.empty(n_out, dtype=torch.int64, device=device)
+            self._draws += 1
+            key = (self.seed * 0x9E3779B97F4A7C15 + self._draws * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+            _lib.check(lib.r2l_pool_pick(ctypes.c_void_p(ix.data_ptr()), n_out, n_rows, key,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "r2l_pool_pick")
+            return ix
         return torch.as_tensor(self.rng.permutation(n_rows)[:n_out], device=device)
+
+    @staticmethod
+    def _rows(x):
+        """(tensor, row stride in floats) of a [N,3] fp32 tensor whose rows are contiguous (column slices of a shard batch)."""
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 3 or x.stride(1) != 1:
+            x = x.float().contiguous()
+        return x, x.stride(0)
 
     def extra_rays(self, batch_size, updates_done):
         """Rays augment() appends to a batch of `batch_size` after `updates_done` update() calls on batches of that size — a
@@ -94,6 +107,16 @@ class HardRayPool:
             return rays_o, rays_d, target
         _, n_out = self.sizes(rays_o.shape[0])
         self._ix_out = self._pick(self.pool.shape[0], n_out, self.pool.device)
+        if self.pool.is_cuda:  # one kernel: batch rows (possibly column slices of the [B,9] shard batch) + picked pool rows
+            from . import _lib
+            lib, B = _lib.load(), rays_o.shape[0]
+            (o, so), (d, sd), (t, st) = self._rows(rays_o), self._rows(rays_d), self._rows(target)
+            out = torch.empty(3, B + n_out, 3, dtype=torch.float32, device=self.pool.device)
+            p = lambda x: ctypes.c_void_p(x.data_ptr())
+            _lib.check(lib.r2l_pool_augment(p(o), p(d), p(t), so, sd, st, p(self.pool), p(self._ix_out), B, n_out, p(out[0]),
+                                            p(out[1]), p(out[2]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "r2l_pool_augment")
+            return out[0], out[1], out[2]
         picked = self.pool[self._ix_out]
         return (torch.cat([rays_o, picked[:, :3]], 0), torch.cat([rays_d, picked[:, 3:6]], 0),
                 torch.cat([target, picked[:, 6:]], 0))
@@ -105,15 +128,27 @@ class HardRayPool:
         err = torch.mean((rgb[:batch_size] - target[:batch_size])**2, dim=1)
         _, order = torch.sort(err)
         hard = order[-n_in:]
-        rows = torch.cat([rays_o[hard], rays_d[hard], target[hard]], dim=-1)
-        if self.full:
-            self.pool[self._ix_out[:n_in]] = rows
-            return
         if self._store is None:  # final size: the first multiple of n_in that reaches batch_size * hard_mul
             steps = max(1, -(-int(np.ceil(batch_size * self.mul)) // n_in))
-            self._store = torch.empty(steps * n_in, rows.shape[1], dtype=rows.dtype, device=rows.device)
+            self._store = torch.empty(steps * n_in, 9, dtype=torch.float32, device=rays_o.device)
             self._n = 0
-        self._store[self._n:self._n + n_in] = rows
+        if rays_o.is_cuda:  # one kernel: gather the hard rows [o, d, rgb] and put them where they go (replace / append)
+            from . import _lib
+            lib = _lib.load()
+            (o, so), (d, sd), (t, st) = self._rows(rays_o), self._rows(rays_d), self._rows(target)
+            hard = hard.contiguous()
+            dst = self._ix_out[:n_in].contiguous() if self.full else None
+            p = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else None
+            _lib.check(lib.r2l_pool_store(p(o), p(d), p(t), so, sd, st, p(hard), p(self._store), p(dst), 0 if self.full else self._n,
+                                          n_in, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "r2l_pool_store")
+            if self.full:
+                return
+        else:
+            rows = torch.cat([rays_o[hard], rays_d[hard], target[hard]], dim=-1)
+            if self.full:
+                self.pool[self._ix_out[:n_in]] = rows
+                return
+            self._store[self._n:self._n + n_in] = rows
         self._n += n_in
         self.pool = self._store[:self._n]
         if self._n >= batch_size * self.mul:
@@ -168,7 +203,7 @@ class _FrameWriter:
         from . import _lib
         self._lib, self.lib = _lib, _lib.load()
         self.device, self.slots = device, slots
-        n = workers or max(4, min(16, os.cpu_count() or 8))
+        n = workers or max(4, min(32, os.cpu_count() or 8))
         self._h = ctypes.c_void_p()
         _lib.check(self.lib.r2l_png_writer_open(n, level, ctypes.byref(self._h)), "r2l_png_writer_open")
         self.inflight = []  # (job id, what must stay alive until it is done, recyclable pinned buffer or None)
@@ -195,10 +230,15 @@ class _FrameWriter:
         if isinstance(img, torch.Tensor) and img.is_cuda:
             q = (255 * torch.clamp(img, 0, 1)).to(torch.uint8).contiguous()  # float -> uint8 truncates, as numpy's astype does
             key = tuple(q.shape)
-            free = self.free.setdefault(key, [])
+            free = self.free.get(key)
+            if free is None:  # ONE pinned allocation for all staging slots of this frame size (44 separate ones cost ~100 ms)
+                slab = torch.empty((self.slots,) + key, dtype=torch.uint8, pin_memory=True)
+                free = self.free[key] = [slab[i] for i in range(self.slots)]
             if not free:
                 self._retire(self.slots - 1)
-            host = free.pop() if free else torch.empty(key, dtype=torch.uint8, pin_memory=True)
+            if not free:  # (every slot of this size still in flight behind jobs of another size: wait for all)
+                self._retire(0)
+            host = free.pop()
             host.copy_(q, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()

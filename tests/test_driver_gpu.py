@@ -364,3 +364,65 @@ def test_hard_ray_pool_on_gpu(golden_dir):
             p.update(rgb, o, d, target, 256)
         p.augment(o, d, target)
     assert torch.equal(a._ix_out, b._ix_out) and not torch.equal(a._ix_out, c._ix_out)
+
+
+def test_pool_kernels_vs_torch_ops():
+    """include/r2l_hip.h r2l_pool_pick / _augment / _store (the hard-ray pool's row choice and data movement, main.py:1325-1347,
+    1410-1425): the picked rows are distinct, in range, reproducible per key, different per key and cover the pool evenly; the
+    augmented batch and the stored rows are bit for bit what the torch ops of the CPU path give — on column slices of a [B,9]
+    shard batch (row stride 9) as the training loop passes them."""
+    import ctypes
+    from r2l_amd import _lib
+    from r2l_amd.driver import HardRayPool
+    lib = _lib.load()
+    p = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n_rows, n_out in ((1638400, 16384), (561, 51), (5, 5), (1, 1), (4097, 4097)):
+        a = torch.empty(n_out, dtype=torch.int64, device="cuda")
+        b, c = torch.empty_like(a), torch.empty_like(a)
+        _lib.check(lib.r2l_pool_pick(p(a), n_out, n_rows, 12345, st), "pick")
+        _lib.check(lib.r2l_pool_pick(p(b), n_out, n_rows, 12345, st), "pick")
+        _lib.check(lib.r2l_pool_pick(p(c), n_out, n_rows, 12346, st), "pick")
+        assert int(a.min()) >= 0 and int(a.max()) < n_rows and a.unique().numel() == n_out
+        assert torch.equal(a, b) and (n_rows < 10 or not torch.equal(a, c))
+        if n_out == n_rows:
+            assert torch.equal(a.sort()[0], torch.arange(n_rows, device="cuda"))  # a permutation
+    # every row equally likely: 200 draws of 16 384 of 1.6 M rows -> ~2 hits per row on average over 32 coarse bins
+    hits = torch.zeros(32, device="cuda")
+    ix = torch.empty(16384, dtype=torch.int64, device="cuda")
+    for k in range(200):
+        _lib.check(lib.r2l_pool_pick(p(ix), 16384, 1638400, 777 + k, st), "pick")
+        hits += torch.bincount(ix // 51200, minlength=32).float()
+    assert (hits / hits.mean() - 1).abs().max().item() < 0.02, hits
+    assert lib.r2l_pool_pick(p(ix), 10, 5, 1, st) != 0  # more rows asked for than there are
+    # augment / store against the torch ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, n_out, rows = 4096 * 3, 2457, 49140
+    batch = torch.rand(B, 9, device="cuda", generator=g)
+    pool = torch.rand(rows, 9, device="cuda", generator=g)
+    o, d, t = batch[:, :3], batch[:, 3:6], batch[:, 6:]
+    idx = torch.randperm(rows, device="cuda", generator=g)[:n_out]
+    out = torch.empty(3, B + n_out, 3, device="cuda")
+    _lib.check(lib.r2l_pool_augment(p(o), p(d), p(t), 9, 9, 9, p(pool), p(idx), B, n_out, p(out[0]), p(out[1]), p(out[2]), st), "augment")
+    assert torch.equal(out[0], torch.cat([o, pool[idx, :3]])) and torch.equal(out[1], torch.cat([d, pool[idx, 3:6]]))
+    assert torch.equal(out[2], torch.cat([t, pool[idx, 6:]]))
+    hard = torch.randperm(B, device="cuda", generator=g)[:n_out]
+    want = pool.clone()
+    want[idx] = torch.cat([o[hard], d[hard], t[hard]], -1)
+    _lib.check(lib.r2l_pool_store(p(o), p(d), p(t), 9, 9, 9, p(hard), p(pool), p(idx), 0, n_out, st), "store")
+    assert torch.equal(pool, want)
+    want[100:100 + n_out] = torch.cat([o[hard], d[hard], t[hard]], -1)
+    _lib.check(lib.r2l_pool_store(p(o), p(d), p(t), 9, 9, 9, p(hard), p(pool), None, 100, n_out, st), "store append")
+    assert torch.equal(pool, want)
+    # the pool object on strided inputs == on contiguous copies
+    pa, pb = HardRayPool(0.2, 2, seed=4), HardRayPool(0.2, 2, seed=4)
+    rgb = torch.rand(B, 3, device="cuda", generator=g)
+    for _ in range(12):
+        xa = pa.augment(o, d, t)
+        xb = pb.augment(o.contiguous(), d.contiguous(), t.contiguous())
+        for u, v in zip(xa, xb):
+            assert torch.equal(u, v)
+        r2 = torch.rand(xa[0].shape[0], 3, device="cuda", generator=g)
+        pa.update(r2, *xa, B)
+        pb.update(r2, *xb, B)
+    assert pa.full and torch.equal(pa.pool, pb.pool)

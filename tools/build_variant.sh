@@ -9,5 +9,5 @@ mkdir -p tools/_bin/$name
 base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@" -I include -c r2l_amd/csrc/$src -o tools/_bin/$name/$base.o
 objs=$(ls r2l_amd/lib/obj/*.o | grep -v "/$base.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_bin/$name/libr2l_hip.so $objs tools/_bin/$name/$base.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_bin/$name/libr2l_hip.so $objs tools/_bin/$name/$base.o -lz
 echo "built tools/_bin/$name/libr2l_hip.so"

@@ -30,7 +30,12 @@ def main(n=40):
     net = NeRF_v3_2(args, 1008, 3).to(dev)
     ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6., device=dev)
     poses = torch.stack([data.pose_spherical(-180. + 9. * i, -30., 4.) for i in range(n)]).to(dev)
-    gts = torch.rand(n, 400, 400, 3)
+    # ground-truth frames: smooth images (bilinear upsampling of 25x25 noise; real test frames — an object on a white
+    # background — compress at least as well) or, `noise`, incompressible ones: zlib's worst case, 10x the encode time
+    if len(sys.argv) > 2 and sys.argv[2] == "noise":
+        gts = torch.rand(n, 400, 400, 3)
+    else:
+        gts = torch.nn.functional.interpolate(torch.rand(n, 3, 25, 25), size=400, mode="bilinear").permute(0, 2, 3, 1).contiguous()
     out = tempfile.mkdtemp(prefix="r2l_frames_")
     for tag, sd in (("metrics only", None), ("metrics + PNGs", out)):
         driver.render_path(poses[:3], net, ps, dev, _Log(), gt_imgs=gts[:3], savedir=None)  # warm-up
@@ -45,4 +50,4 @@ def main(n=40):
 
 
 if __name__ == "__main__":
-    main()
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 40)
