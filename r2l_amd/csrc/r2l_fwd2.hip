@@ -4,6 +4,9 @@
 // R2L_NO_FWD2=1: bf16x3 only.
 #include "r2l_f2.h"
 #include "r2l_coopf.h"
+#ifndef F2_PARK_X0
+#define F2_PARK_X0 3  // X_0 tiles parked in LDS across the body loop (0: all of X_0 left to the register allocator, as in rounds 1 - 3)
+#endif
 
 // =================================================================================================================
 // pack: flat fp32 parameters -> stage stream for the activation scale the status words ask for (r2l_f2.h: range control).
@@ -48,6 +51,13 @@ struct F2Args {
 template <bool POSE, bool SAVE, bool MID = false>
 __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
+#if F2_PARK_X0 > 0
+    // X_0 (outer residual: needed again only at the tail) does not fit beside x, t and the A operands in 512 registers: hipcc
+    // spilled ~76 of its 128 registers per lane to scratch (0.85 GB written and read back per 9-frame launch).
+    // The LDS the six stage buffers leave free (56 KiB) takes F2_PARK_X0 = 3 of its 8 tiles: [wave][quad][lane][16 B],
+    // conflict-free 16-byte accesses; the rest stays where the register allocator puts it.
+    __shared__ __attribute__((aligned(16))) f32x4 x0park[4][F2_PARK_X0 * 4][64];
+#endif
 
     // an earlier launch with these weights left fp16's range: the bf16x3 kernel behind this one does the work
     if (__builtin_nontemporal_load(a.status) != 0u) return;
@@ -185,6 +195,13 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
             x[T][c] = fmaxf(x[T][c], 0.f);  // X_0 = relu(head)
             x0[T][c] = x[T][c];
         }
+#if F2_PARK_X0 > 0
+#pragma unroll
+    for (int T = R2L_NT - F2_PARK_X0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            x0park[wave][(T - (R2L_NT - F2_PARK_X0)) * 4 + q][lane] = f32x4{x0[T][4 * q], x0[T][4 * q + 1], x0[T][4 * q + 2], x0[T][4 * q + 3]};
+#endif
 
     // ---- body -----------------------------------------------------------------------------------------------------------
     // training (SAVE): the B values of every stage are the layer's input (x_b for the first layer of a block, relu(t_b) for the
@@ -237,6 +254,22 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
             *reinterpret_cast<u32x4*>(a.save_t + (int64_t)b * slot + R2L_MASK_OFFSET(Np) + tile * 256 + lane * 4) = mv;
         }
     }
+    // y = x_n + x_0 (outer residual), in place
+#pragma unroll
+    for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#if F2_PARK_X0 > 0
+            if (T >= R2L_NT - F2_PARK_X0) {
+                const f32x4 p4 = x0park[wave][(T - (R2L_NT - F2_PARK_X0)) * 4 + q][lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[T][4 * q + e] += p4[e];
+                continue;
+            }
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[T][4 * q + e] += x0[T][4 * q + e];
+        }
     if (SAVE) {  // slot n: y = x_n + x_0, row-major (the tail weight gradient reads nothing else)
         float* sy = a.save_x + (int64_t)a.n_block * slot + ray * R2L_W + 4 * h;
 #pragma unroll
@@ -244,8 +277,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<f32x4*>(sy + 32 * T + 8 * q) =
-                    f32x4{(x[T][4 * q] + x0[T][4 * q]) * act_s, (x[T][4 * q + 1] + x0[T][4 * q + 1]) * act_s,
-                          (x[T][4 * q + 2] + x0[T][4 * q + 2]) * act_s, (x[T][4 * q + 3] + x0[T][4 * q + 3]) * act_s};
+                    f32x4{x[T][4 * q] * act_s, x[T][4 * q + 1] * act_s, x[T][4 * q + 2] * act_s, x[T][4 * q + 3] * act_s};
     }
 
     // range control (r2l_f2.h): the wave's largest |B value| -> AMAX; one that close to 65504 may have become inf in a
@@ -264,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
             for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float y = x[T][4 * q + e] + x0[T][4 * q + e];
+                const float y = x[T][4 * q + e];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) p3[c] = __builtin_fmaf(wv[c][e], y, p3[c]);
             }

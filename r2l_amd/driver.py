@@ -247,10 +247,30 @@ class _FrameWriter:
             arr = np.ascontiguousarray(to8b(img))
             self.inflight.append((self._submit(path, arr.ctypes.data, arr.shape, None), arr, None))
 
+    def flush(self):
+        """Every frame handed over so far is on disk (the writer stays usable: its threads and pinned slots are kept)."""
+        self._retire(0)
+
     def close(self):
+        if not self._h:
+            return
         self._retire(0)
         self._lib.check(self.lib.r2l_png_writer_close(self._h), "r2l_png_writer_close")
         self._h = ctypes.c_void_p()
+
+    _shared = {}
+
+    @classmethod
+    def shared(cls, device, workers=None):
+        """One writer per device and process, kept across render_path calls (the test set is evaluated every i_testset
+        iterations: thread start-up and the pinned allocation are paid once)."""
+        key = (str(device), workers)
+        w = cls._shared.get(key)
+        if w is None:
+            import atexit
+            w = cls._shared[key] = cls(device, workers=workers)
+            atexit.register(w.close)
+        return w
 
 
 def save_video(rgbs, logger, expid, iter_, tag, rank=0, world=1, device=None):
@@ -289,7 +309,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     rgbs, sq_err, psnrs, ssims, events = [], [], [], [], []
     if savedir is not None:
         os.makedirs(savedir, exist_ok=True)  # every rank writes its own frames: none may rely on rank 0's mkdir
-    writer = _FrameWriter(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "0")) or None) if savedir is not None else None
+    writer = _FrameWriter.shared(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "0")) or None) if savedir is not None else None
     on_gpu = device.type == "cuda"
     t_loop = time.time()
     def account(i, rgb):
@@ -326,7 +346,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, time.time() - t0))
             account(i, rgb)
     if writer is not None:
-        writer.close()
+        writer.flush()  # (shared writer: threads and pinned slots stay for the next evaluation)
     if on_gpu:
         sync(device)
         for idx, e0, e1 in events:
