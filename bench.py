@@ -291,6 +291,8 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-teacher", action="store_true")
+    ap.add_argument("--segmented-leg", action="store_true",
+                    help="N > 1: also time the 4096-ray step with the opt-in segmented dX chain (R2LTrainer(chain_segments=3))")
     ap.add_argument("--one-frame-leg", action="store_true",
                     help="also time the render kernel ONE frame per launch (the step of rounds 1 / 2), for comparison; off by "
                          "default so that the kernel-trace of this command holds one population of render launches")
@@ -488,9 +490,10 @@ def main():
             out["train_strong"]["global_rays_per_step"] = per * world
         # BASELINE configs[2] read literally ("N_rand=4096" as 4096 rays per step; at N GPUs configs[3]: 4096 rays per GPU)
         train_leg("train_4096", precision="fp16x2", dw_mode="fp16", n_rays=4096)
-        if distributed:
+        if distributed and a.segmented_leg:
             # the same steps with the dX chain cut into 3 segments (opt-in, R2LTrainer(chain_segments=3)): each segment's weight
-            # gradients and all-reduce beside the next segment — what cutting the chain buys, once a node measures it
+            # gradients and all-reduce beside the next segment — what cutting the chain buys, once a node measures it.  Behind a
+            # flag: the form has never run on more than one GPU, and an unattended scaling run must not be its first test
             train_leg("train_4096_segmented_chain", precision="fp16x2", dw_mode="fp16", n_rays=4096, chain_segments=3)
         if rank == 0 and world == 1:
             # exact weight gradients (r2l_config.dw_mode = R2L_DW_EXACT): hi + mid operands, three products in the dW GEMMs
