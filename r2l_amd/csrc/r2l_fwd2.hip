@@ -5,7 +5,11 @@
 #include "r2l_f2.h"
 #include "r2l_coopf.h"
 #ifndef F2_PARK_X0
-#define F2_PARK_X0 3  // X_0 tiles parked in LDS across the body loop (0: all of X_0 left to the register allocator, as in rounds 1 - 3)
+// X_0 tiles parked in LDS across the body loop.  0 (default): all of X_0 left to the register allocator, which spills 76 of its
+// 128 registers to scratch once per tile — 0.85 GB written and read back per 9-frame launch, none of it time-limiting.  3 (what
+// the LDS left by the six stage buffers takes): 29 spills, WRITE_SIZE 849 -> 345 MB per launch (rocprofv3 --pmc), but the same-box
+// A/B says 38.18 / 38.08 ms per launch against 38.05 / 37.99 with 0 (profiles/r04_render_x0_park_ab.txt): -0.3 %, so off.
+#define F2_PARK_X0 0
 #endif
 
 // =================================================================================================================

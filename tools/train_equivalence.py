@@ -18,8 +18,9 @@ from tests.test_forward_gpu import build_model  # noqa: E402
 from model.nerf_raybased import PointSampler  # noqa: E402
 from r2l_amd.train_step import R2LTrainer, lr_schedule  # noqa: E402
 
-FAMILIES = {"fp16 trio (default)": {}, "fp16 trio, exact dW": {"R2L_DW_EXACT": "1"},
-            "bf16x3 trio": {"R2L_NO_FWD2": "1", "R2L_NO_BWD2": "1", "R2L_NO_DW2": "1"}, "fp32 MFMA": {"R2L_NO_FWD3": "1"}}
+# kernel families through r2l_config (r2l_amd.engine.DEFAULT_CONFIG), not the environment
+FAMILIES = {"fp16 trio (default)": {}, "fp16 trio, exact dW": {"dw_mode": "exact"},
+            "bf16x3 trio": {"precision": "bf16x3"}, "fp32 MFMA": {"precision": "fp32_mfma"}}
 
 
 def scene(o, d):
@@ -66,12 +67,13 @@ def main(iters=1500, n=16384):
     test_o, test_d = rays(65536, gen)
     test_rgb = scene(test_o, test_d)
     curves, finals, weights = {}, {}, {}
-    for name, env in FAMILIES.items():
-        for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_DW_EXACT"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+    from r2l_amd import engine
+    ranges = {}
+    for name, cfg in FAMILIES.items():
+        engine.DEFAULT_CONFIG = dict(cfg)
         m = build_model(sd, 43)
         tr = R2LTrainer(m, ps)
+        ranges[name] = []
         g = torch.Generator(device="cuda").manual_seed(7)       # batches
         gj = torch.Generator(device="cuda").manual_seed(8)      # jitter
         curve = []
@@ -87,6 +89,9 @@ def main(iters=1500, n=16384):
                     out = m.forward_rays(test_o, test_d, ps)
                 psnr = (-10. * torch.log10(((out - test_rgb) ** 2).mean())).item()
                 curve.append((it, psnr))
+                ri = tr.range_info()  # range control telemetry of the fp16 kernels (include/r2l_hip.h): how close does training get?
+                ranges[name].append((it, ri["amax"], ri["scale"], ri["trips"], ri.get("grad_amax", 0.), ri.get("grad_scale", 0.),
+                                     ri.get("bwd_trips", 0)))
         torch.cuda.synchronize()
         curves[name], finals[name] = curve, out.clone()
         weights[name] = m.engine().flat.clone() if hasattr(m, "engine") else None
@@ -99,6 +104,11 @@ def main(iters=1500, n=16384):
             print("  %-22s vs %-22s  %.2f dB  (max |dRGB| %.4f)" % (names[i], names[j],
                   (-10. * torch.log10(((a - b) ** 2).mean())).item(), (a - b).abs().max().item()))
     print("final held-out PSNR: " + ", ".join("%s %.3f dB" % (k, v[-1][1]) for k, v in curves.items()))
+    print("\nrange of the fp16 kernels during training (largest |activation| of the last step incl. the held-out frame, activation "
+          "scale, forward launches redone | largest |chain gradient|, gradient scale, steps redone):")
+    for name, rows in ranges.items():
+        if rows and rows[-1][5]:
+            print("  %-22s " % name + "  ".join("it %d: %.3g x%g (%d) | %.3g x%g (%d)" % r for r in rows))
 
 
 if __name__ == "__main__":
