@@ -57,7 +57,8 @@ def test_create_data_then_train(tmp_path, monkeypatch):
 def test_cli_training_two_ranks_uneven_shards(tmp_path):
     """The CLI under torchrun with TWO ranks on this one GPU (gloo: RCCL refuses a device twice) and --N_rand 3: rank 0 takes two
     shard files per step, rank 1 one, gradients weighted by ray share (driver.train, dist_utils.split_shards), hard-ray pools
-    per rank, small steps on the segmented dX chain; the replicas must end bit-identical and rank 0 writes the checkpoint."""
+    per rank, small steps on the staged backward (the default at every world size); the replicas must end bit-identical and rank 0
+    writes the checkpoint."""
     import subprocess
     import sys
     from r2l_amd import create_data
