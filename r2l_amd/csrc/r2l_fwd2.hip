@@ -63,8 +63,15 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     __shared__ __attribute__((aligned(16))) f32x4 x0park[4][F2_PARK_X0 * 4][64];
 #endif
 
+    // Tail weights (Linear(256, 3): 3 KiB) and biases, staged in LDS once per workgroup (published by the prologue's barrier).
+    // Read from global at the end of a tile — 96 16-byte loads per lane, and with no registers to spare hipcc issued them three
+    // at a time behind `s_waitcnt vmcnt(0)`: 32 serialized L2 round trips per tile, each of which ALSO waits for the twenty weight
+    // DMA loads the staging pipeline has in flight (round 4: ISA of the tail; same-box A/B profiles/r04_tail_lds_ab.txt).
+    __shared__ __attribute__((aligned(16))) float tail_w[3 * R2L_W + 4];
+
     // an earlier launch with these weights left fp16's range: the bf16x3 kernel behind this one does the work
     if (__builtin_nontemporal_load(a.status) != 0u) return;
+    for (int i = threadIdx.x; i < 3 * R2L_W + 3; i += 256) tail_w[i] = a.params[f2_off_tail_w(a.n_block) + i];  // (W then b: contiguous)
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // every wave of the workgroup takes part in the weight staging and the barriers: a wave whose tile lies past the end
@@ -289,28 +296,35 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     f2_report_amax(a.status, P.amax, lane);
 
     // ---- tail: rgb = sigmoid(Wt (x + X_0) + bt) on the VALU -------------------------------------------------------------
-    const float* tw = a.params + f2_off_tail_w(a.n_block) + 4 * h;
-    float p3[3] = {0.f, 0.f, 0.f};
+    const float* tw = tail_w + 4 * h;
+    float p3[3];
+    {
+        // packed FMAs on operand pairs that sit in adjacent registers (two weights of a 16-byte LDS read x two neighbouring values:
+        // plain v_pk_fma_f32, no op_sel), even / odd partial sums per channel
+        typedef float f2_f32x2 __attribute__((ext_vector_type(2)));
+        f2_f32x2 a2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-    for (int T = 0; T < R2L_NT; ++T)
+        for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 wv[3];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 wv[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
+                for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(tw + c * R2L_W + 32 * T + 8 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float y = x[T][4 * q + e];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) p3[c] = __builtin_fmaf(wv[c][e], y, p3[c]);
+                for (int c = 0; c < 3; ++c) {
+                    a2[c] = __builtin_elementwise_fma(f2_f32x2{wv[c][0], wv[c][1]}, f2_f32x2{x[T][4 * q], x[T][4 * q + 1]}, a2[c]);
+                    a2[c] = __builtin_elementwise_fma(f2_f32x2{wv[c][2], wv[c][3]}, f2_f32x2{x[T][4 * q + 2], x[T][4 * q + 3]}, a2[c]);
+                }
             }
-        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p3[c] = a2[c][0] + a2[c][1];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) p3[c] += __shfl_xor(p3[c], 32);
     if (valid && h == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = p3[c] * act_s + a.params[f2_off_tail_b(a.n_block) + c];  // (the chain ran on y / act_s: exact)
+            const float v = p3[c] * act_s + tail_w[3 * R2L_W + c];  // (the chain ran on y / act_s: exact)
             a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
         }
     }

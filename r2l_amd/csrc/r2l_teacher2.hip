@@ -190,7 +190,11 @@ struct T2Emb4 {
             const int v = v0 + j;
             if (v < 6 * NF) {
                 const int q = v >> 1, fl = q / 3, ax = q % 3;
+#ifdef T2_TIME_NOSINCOS  // (timing experiment only: results are wrong)
+                out[j] = c[ax] * (base * (float)(1 << fl)); out[j + 1] = out[j] + 1.0f;
+#else
                 r2l_sincos(c[ax] * (base * (float)(1 << fl)), out[j], out[j + 1]);
+#endif
             } else if (v == 6 * NF) {
                 out[j] = h ? c[2] : c[0];
                 out[j + 1] = h ? 0.f : c[1];
@@ -199,6 +203,24 @@ struct T2Emb4 {
                 out[j + 1] = 0.f;
             }
         }
+    }
+};
+// relu(frag[c0 .. c0+3]) as B values (F3Take4<true>), and — riding along — four terms of a dot product with them: the alpha head
+// (alpha_linear on relu(layer 7)) is accumulated by the 32 gathers of the feature layer's GEMM, in the shadow of its MFMAs, from
+// the values they produce anyway; as a VALU burst after the layer it cost 1043 instructions per tile with the matrix pipe idle
+// (3 v_max per ReLU, AGPR reads, serialized LDS waits: 3 - 4 % of the frame).  w: this lane's 4 weights (LDS; a zero page for
+// the layer pairs that have no head).
+struct T2ReluDot4 {
+    const f32x16& frag;
+    int c0;
+    const float* w;
+    float& acc;
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = fmaxf(frag[c0 + s], 0.f);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_fmaf(wv[s], v[s], acc);
     }
 };
 // either of two gatherers, chosen at run time (the stage in front of a conditionally inserted group of stages)
@@ -293,8 +315,19 @@ __device__ __forceinline__ void t2_vstage(f32x16 (&acc)[R2L_NT], F2Pipe& P, F2Sp
 
 __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F2_NBUF][F2_STAGE_BYTES];
+    // weights of the two VALU heads (alpha_linear [256], rgb_linear [3][128]): staged in LDS once per workgroup.  Read from global
+    // inside the tile — 80 16-byte loads per lane with no registers left to keep them in flight — the heads cost 7 % of the frame
+    // (timing build without them: 117.8 -> 109.7 ms, profiles/r04_teacher_heads_ab.txt); as broadcast LDS reads they cost ~2 %.
+    __shared__ __attribute__((aligned(16))) float head_a[2][T2_W];  // [0]: zeros, [1]: alpha_linear.weight
+    __shared__ __attribute__((aligned(16))) float head_rgb[3 * 128];
+    // the heads' four biases as well: a VMEM load at the end of a tile makes hipcc wait for vmcnt(0), i.e. for the twenty weight-DMA
+    // loads the pipeline has in flight for the stages behind the tile (1 - 2 us per 60 us tile: most of what the heads "cost")
+    __shared__ __attribute__((aligned(16))) float head_b[4];  // rgb_linear.bias[0..2], alpha_linear.bias
     if (__builtin_nontemporal_load(a.status) != 0u) return;
     const T2Off off = t2_offsets();
+    for (int i = threadIdx.x; i < T2_W; i += 256) { head_a[0][i] = 0.f; head_a[1][i] = a.params[off.alpha_w + i]; }
+    for (int i = threadIdx.x; i < 3 * 128; i += 256) head_rgb[i] = a.params[off.rgb_w + i];  // (published by the prologue's barrier)
+    if (threadIdx.x < 4) head_b[threadIdx.x] = threadIdx.x < 3 ? a.params[off.rgb_b + threadIdx.x] : a.params[off.alpha_b];
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -382,24 +415,14 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
             f2_stage<false, false, false>(t, P, Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
                                           Relu4{x[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
         f2_stage<false, false, true>(t, P, F3None{}, F3None{});
-        if (k == 3) {  // alpha_linear on relu(layer 7)
-            float acc = 0.f;
-#pragma unroll
-            for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(P0 + off.alpha_w + 32 * T + 8 * q + 4 * h);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(wv[j], fmaxf(t[T][4 * q + j], 0.f), acc);
-                }
-            acc += __shfl_xor(acc, 32);
-            alpha = acc * act_s + P0[off.alpha_b];  // (the chain holds activations / act_s: exact)
-        }
-        f2_stage<true, true, false>(x, P, Relu4{t[0], 0, nullptr, 0}, Relu4{t[0], 4, nullptr, 0});
+        // x = W_even relu(t) + b; k == 3 (feature_linear): its gathers of relu(layer 7) also accumulate the alpha head
+        const float* wa = &head_a[k == 3 ? 1 : 0][4 * h];
+        f2_stage<true, true, false>(x, P, T2ReluDot4{t[0], 0, wa, alpha}, T2ReluDot4{t[0], 4, wa + 8, alpha});
 #pragma unroll
         for (int kb = 0; kb < 15; ++kb)
-            f2_stage<false, false, false>(x, P, Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), nullptr, 0},
-                                          Relu4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, nullptr, 0});
+            f2_stage<false, false, false>(x, P,
+                                          T2ReluDot4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1), wa + 32 * ((kb + 1) >> 1) + 16 * ((kb + 1) & 1), alpha},
+                                          T2ReluDot4{t[(kb + 1) >> 1], 8 * ((kb + 1) & 1) + 4, wa + 32 * ((kb + 1) >> 1) + 16 * ((kb + 1) & 1) + 8, alpha});
         f2_stage<false, false, true>(x, P, F3None{}, F3None{});  // next: the next pair's (or the views layer's) bias stage
     }
 
@@ -419,23 +442,41 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
 
     // rgb = Wrgb relu(v) + b
     float acc3[3] = {0.f, 0.f, 0.f};
+#ifdef T2_TIME_NOHEADS
+    acc3[0] = t[0][0]; acc3[1] = t[1][1]; acc3[2] = t[2][2];
+#else
+    {
+        // Nothing gathers v any more, so this head stays a VALU burst with the matrix pipe idle — written for its instruction
+        // count: one v_max per ReLU (fmaxf costs canonicalise + max), the products as packed FMAs on operand PAIRS that already
+        // sit in adjacent registers (two weights of a 16-byte LDS read x two neighbouring values: plain v_pk_fma_f32, no op_sel),
+        // even / odd partial sums per channel.  hipcc's own vectorisation of the scalar loop: 972 instructions; this: ~330.
+        typedef float t2_f32x2 __attribute__((ext_vector_type(2)));
+        t2_f32x2 a2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        const float* wr = head_rgb + 4 * h;
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
+        for (int T = 0; T < 4; ++T)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 wv[3];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 wv[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(P0 + off.rgb_w + c * 128 + 32 * T + 8 * q + 4 * h);
+                for (int c = 0; c < 3; ++c) wv[c] = *reinterpret_cast<const f32x4*>(wr + c * 128 + 32 * T + 8 * q);
+                float y[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = fmaxf(t[T][4 * q + j], 0.f);
+                for (int j = 0; j < 4; ++j) asm("v_max_f32_e32 %0, 0, %1" : "=v"(y[j]) : "v"(t[T][4 * q + j]));
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc3[c] = __builtin_fmaf(wv[c][j], y, acc3[c]);
+                for (int c = 0; c < 3; ++c) {
+                    a2[c] = __builtin_elementwise_fma(t2_f32x2{wv[c][0], wv[c][1]}, t2_f32x2{y[0], y[1]}, a2[c]);
+                    a2[c] = __builtin_elementwise_fma(t2_f32x2{wv[c][2], wv[c][3]}, t2_f32x2{y[2], y[3]}, a2[c]);
+                }
             }
-        }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) acc3[c] = (acc3[c] + __shfl_xor(acc3[c], 32)) * act_s + P0[off.rgb_b + c];
+        for (int c = 0; c < 3; ++c) acc3[c] = a2[c][0] + a2[c][1];
+    }
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc3[c] = (acc3[c] + __shfl_xor(acc3[c], 32)) * act_s + head_b[c];
     f2_report_amax(a.status, P.amax, lane);  // AMAX, and FLAG if this launch belongs to the bf16x3 kernel
+    alpha = (alpha + __shfl_xor(alpha, 32)) * act_s + head_b[3];  // (the chain holds activations / act_s: exact)
     if (valid && h == 0) {
         const f32x4 o4 = {acc3[0], acc3[1], acc3[2], alpha};
         *reinterpret_cast<f32x4*>(a.raw + pt * 4) = o4;

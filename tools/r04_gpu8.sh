@@ -1,0 +1,8 @@
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+python -m pytest tests/test_teacher_gpu.py -m gpu -q -x 2>&1 | tail -2
+for r in 1 2 3; do
+  echo "old:     $(R2L_LIB_PATH=$R/tools/_bin/t2old/libr2l_hip.so python tools/teacher_time.py | tail -1)"
+  echo "lds-heads: $(python tools/teacher_time.py | tail -1)"
+  echo "noheads: $(R2L_LIB_PATH=$R/tools/_bin/t2noheads/libr2l_hip.so python tools/teacher_time.py | tail -1)"
+done
