@@ -230,11 +230,16 @@ struct T2Select {
     GA ga;
     GB gb;
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
-        float w[4];
+#ifdef T2_SELECT_BOTH  // (rounds 2 - 3: both gatherers evaluated, values selected — two sin / cos pairs per call for nothing in three
+        float w[4];    //  of the four layer pairs, and in a BIAS stage, whose side work is not hidden under MFMAs)
         ga(v);
         gb(w);
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = first ? v[s] : w[s];
+#else
+        if (first) ga(v);  // (wave-uniform)
+        else gb(v);
+#endif
     }
 };
 
