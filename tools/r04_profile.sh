@@ -18,6 +18,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc2 -o pmc2 --output-format csv -- python $REPO/bench.py $ARGS > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc3 -o pmc3 --output-format csv -- python $REPO/bench.py $ARGS > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc4 -o pmc4 --output-format csv -- python $REPO/bench.py $ARGS > $OUT/pmc4.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA -d $OUT/pmc5 -o pmc5 --output-format csv -- python $REPO/tools/teacher_time.py > $OUT/pmc5.log 2>&1
 cd $REPO
 python - "$OUT" <<'PY'
 import csv, glob, collections, json, sys
