@@ -337,6 +337,21 @@ __device__ __forceinline__ void r2l_sincos(float x, float& s_out, float& c_out) 
     c_out = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// (sin, cos) of 2x from (sin, cos) of x: three VALU instructions instead of the ~27 of r2l_sincos.  The encoder's frequencies are
+// consecutive powers of two of the same coordinate, so every second (sin, cos) pair of the fp16x2 kernels' head (r2l_fwd2.hip,
+// r2l_coopf_fwd.hip — NOT the bf16x3 / fp32 kernels, whose families are held to fp32-exact bars) is derived from its predecessor.
+// Error: the inputs' 1.5 ulp doubled plus one rounding, <= 8e-7 absolute on values of magnitude <= 1 — the size of the fp16x2
+// products' own 2^-21, three orders of magnitude below what one ulp of the POINT already does to these features at the highest
+// frequency (1.2e-4): invisible at the 1e-4 RGB bar (measured: max |dRGB| vs the oracle unchanged at 1.5e-6).
+// Same-box A/B of the render launch: 37.10 -> 36.94 ms (-0.4 %); with the evaluation software-pipelined (r2l_f2.h F2TrigPre)
+// 37.93 -> 37.60 ms (-0.9 %).  (A timing build WITHOUT sin / cos ran in 36.2 ms, which first read as "4.8 % to gain": most of that
+// is the power cap again — garbage encodings make a net whose activations toggle fewer bits.)
+__device__ __forceinline__ void r2l_sincos_double(float s, float c, float& s2, float& c2) {
+    const float t = s + s;
+    s2 = t * c;
+    c2 = __builtin_fmaf(-t, s, 1.0f);
+}
+
 // ---- small-batch cooperative variants (r2l_coop.hip) ---------------------------------------------------------------------
 int r2l_coop_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream, const float* params,

@@ -135,8 +135,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
                     const int v = 8 * q + 2 * p2;
                     if (v < 480) {
                         const int ci = v / 20, f = (v - 20 * ci) >> 1;
-                        const float x = pts[rt * 32 + j][24 * h + ci];
-                        r2l_sincos(x * (float)(1 << f), v8[2 * p2], v8[2 * p2 + 1]);
+                        // (odd pairs: frequency f of the coordinate whose frequency f - 1 is the pair before: angle doubling, as
+                        // F3Trig2 of the one-wave-per-tile kernels — same values, same instruction count: r2l_common.h)
+                        if ((p2 & 1) && f > 0) {
+                            r2l_sincos_double(v8[2 * p2 - 2], v8[2 * p2 - 1], v8[2 * p2], v8[2 * p2 + 1]);
+                        } else {
+                            const float x = pts[rt * 32 + j][24 * h + ci];
+                            r2l_sincos(x * (float)(1 << f), v8[2 * p2], v8[2 * p2 + 1]);
+                        }
                     } else {
                         const int e = v - 480;
                         v8[2 * p2] = pts[rt * 32 + j][24 * h + e];

@@ -358,6 +358,70 @@ __device__ __forceinline__ void f2_mfma_half(f32x16 (&acc)[R2L_NT], int half, co
 #undef F2_GROUP
 }
 
+// ---- the head's sin / cos, software-pipelined (round 4) ----------------------------------------------------------------------
+// The 63 encoding stages of a tile gathered their B values with r2l_sincos in side step 0: a DEPENDENT chain of ~20 VALU
+// instructions (range reduction -> polynomial -> quadrant) between two groups of four MFMAs, with nothing else on the SIMD: the
+// matrix pipe drained every half stage (timing build without sin / cos: 38.0 -> 36.2 ms per render launch, 4.8 % of the kernel;
+// halving the NUMBER of evaluations by angle doubling bought 0.4 %: it is the chain's latency, not its instruction count).
+// F2TrigPre cuts the evaluation into four phases that ride in side steps 2 - 5 of the PREVIOUS stage's half (a few instructions
+// each, short chains), writing four registers that the next stage's gather (F2TakeRegs) merely copies.  Values are r2l_sincos's,
+// bit for bit (same operations in the same order); the second pair of a gather is the angle doubling of the first (r2l_common.h).
+struct F2TrigPre {
+    float x;
+    int f0;
+    float (&out)[4];  // (sin, cos)(x 2^f0), (sin, cos)(x 2^(f0+1)): complete after phase 3
+    float (&st)[5];   // in flight between the phases
+    __device__ __forceinline__ void phase(int ph) const {
+        if (ph == 0) {
+            const float a = x * (float)(1 << f0);
+            const float n = rintf(a * 0.63661977236758134f);
+            float r = __builtin_fmaf(-n, 1.57079637050628662109375f, a);
+            r = __builtin_fmaf(-n, -4.37113900018624283e-8f, r);
+            r = __builtin_fmaf(-n, -1.71512449512872556e-15f, r);
+            st[0] = n; st[1] = r;
+        } else if (ph == 1) {
+            const float r = st[1], r2 = r * r;
+            float ps = __builtin_fmaf(r2, 2.718311493989822e-6f, -1.9839334836096632e-4f);
+            ps = __builtin_fmaf(ps, r2, 8.3333293858894632e-3f);
+            ps = __builtin_fmaf(ps, r2, -1.6666666641626524e-1f);
+            float pc = __builtin_fmaf(r2, 2.439044879627741e-5f, -1.388676377460993e-3f);
+            pc = __builtin_fmaf(pc, r2, 4.1666623323739063e-2f);
+            pc = __builtin_fmaf(pc, r2, -0.5f);
+            st[2] = r2; st[3] = ps; st[4] = pc;
+        } else if (ph == 2) {
+            const float r = st[1], r2 = st[2];
+            st[3] = __builtin_fmaf(st[3] * r2, r, r);    // sin(r)
+            st[4] = __builtin_fmaf(st[4], r2, 1.0f);     // cos(r)
+        } else {
+            const int q = (int)st[0];
+            const float sr = st[3], cr = st[4];
+            const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+            out[0] = (q & 2) ? -s1 : s1;
+            out[1] = ((q + 1) & 2) ? -c1 : c1;
+            r2l_sincos_double(out[0], out[1], out[2], out[3]);
+        }
+    }
+};
+struct F2NoPre {
+    __device__ __forceinline__ void phase(int) const {}
+};
+struct F2TakeRegs {  // gather = the four values a F2TrigPre finished one stage ago
+    const float (&r)[4];
+    __device__ __forceinline__ void operator()(float (&v)[4]) const {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = r[s];
+    }
+};
+template <class Side, class Pre>
+struct F2SideWithPre {  // a F2Side whose steps 2 .. 5 also advance a pre-computation by one phase each
+    Side s;
+    Pre pre;
+    __device__ __forceinline__ void step(int i) {
+        s.step(i);
+        if (i >= 2) pre.phase(i - 2);
+    }
+};
+
 // state of the weight-staging pipeline (r2l_f3.h's F3PipeT for 16 KiB stages: 4 pieces per wave and stage)
 struct F2Pipe {
     u32x4 rs;
@@ -431,4 +495,20 @@ __device__ __forceinline__ void f2_stage(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo g
         P.sb.h = __builtin_bit_cast(f16x8, u32x4{sa.uh[0], sa.uh[1], sb2.uh[0], sb2.uh[1]});
         P.sb.m = __builtin_bit_cast(f16x8, u32x4{sa.um[0], sa.um[1], sb2.um[0], sb2.um[1]});
     }
+}
+
+// f2_stage with a pre-computation riding in each half (head of r2l_fwd2.hip): plo / phi advance in the first / second half stage
+template <bool BIAS_K, bool ZERO_K, class GLo, class GHi, class PLo, class PHi>
+__device__ __forceinline__ void f2_stage_pre(f32x16 (&acc)[R2L_NT], F2Pipe& P, GLo glo, GHi ghi, PLo plo, PHi phi) {
+    typedef F2Side<BIAS_K, GLo> SA;
+    typedef F2Side<false, GHi> SB;
+    F2SideWithPre<SA, PLo> sa{SA{P.a2, P.lb, 1, glo, true, F3Dma{false, P.rs, 0u, 0u, 0u}, P.amax}, plo};
+    f2_mfma_half<BIAS_K, ZERO_K>(acc, 0, P.a1, P.sb, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    P.sync_next();
+    F2SideWithPre<SB, PHi> sb2{SB{P.a1, P.lb, 0, ghi, true, P.request(), P.amax}, phi};
+    f2_mfma_half<BIAS_K, ZERO_K>(acc, 1, P.a2, P.sb, sb2);
+    __builtin_amdgcn_sched_barrier(0);
+    P.sb.h = __builtin_bit_cast(f16x8, u32x4{sa.s.uh[0], sa.s.uh[1], sb2.s.uh[0], sb2.s.uh[1]});
+    P.sb.m = __builtin_bit_cast(f16x8, u32x4{sa.s.um[0], sa.s.um[1], sb2.s.um[0], sb2.s.um[1]});
 }

@@ -248,8 +248,15 @@ struct F3Trig2 {  // (sin, cos) of x * 2^f0 and x * 2^(f0+1)
     float x;
     int f0;
     __device__ __forceinline__ void operator()(float (&v)[4]) const {
+#ifdef F3_TIME_NOSINCOS  // (timing experiment only: results are wrong)
+        v[0] = x * (float)(1 << f0) * 1e-3f; v[1] = v[0] + 0.5f; v[2] = v[0] * 2.f; v[3] = v[2] + 0.5f;
+#else
+        // (both pairs from r2l_sincos here: this gatherer serves the bf16x3 kernels, whose products are fp32-exact and whose
+        // training family is held to the strict 2e-5 Adam bar — the angle doubling of the fp16x2 kernels' head, r2l_f2.h
+        // F2TrigPre, moved one weight of test_three_adam_steps_vs_oracle[main-bf16x3-trio] by 1.9e-4 when it was tried here)
         r2l_sincos(x * (float)(1 << f0), v[0], v[1]);
         r2l_sincos(x * (float)(1 << (f0 + 1)), v[2], v[3]);
+#endif
     }
 };
 struct F3Ident4 {  // identity features: coordinates e0 .. e0+3 of this half-wave (point = o + d * z)

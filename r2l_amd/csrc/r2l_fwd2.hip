@@ -168,10 +168,28 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
 #pragma unroll
         for (int ci = 0; ci < 6; ++ci) xc[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
     }
-    f2_stage<true, true, false>(x, P, F3Trig2{xc[0], 0}, F3Trig2{xc[0], 2});
+    // Encoding values one stage ahead (r2l_f2.h F2TrigPre): a stage's gather copies four finished registers per half (tlo / thi)
+    // while side steps 2 - 5 of the same half evaluate the NEXT stage's, a phase per step.  The first stage's are evaluated here.
+    float tlo[4], thi[4], slo[5], shi[5];
+    F3Trig2{xc[0], 0}(tlo);
+    F3Trig2{xc[0], 2}(thi);
+    struct RegsOrIdent {  // last stage of a head trip: the next trip's first block (registers), or the first identity block
+        bool ident;
+        F2TakeRegs tr;
+        F3Ident4 id;
+        __device__ __forceinline__ void operator()(float (&v)[4]) const {
+            float w[4];
+            tr(v);
+            id(w);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = ident ? w[s] : v[s];
+        }
+    };
+    const F2TakeRegs glo{tlo}, ghi{thi};
+    f2_stage_pre<true, true>(x, P, glo, ghi, F2TrigPre{xc[0], 4, tlo, slo}, F2TrigPre{xc[0], 6, thi, shi});
 #pragma unroll 1
     for (int it2 = 0; it2 < 4; ++it2) {  // two samples = six coordinates = three pairs = 15 k-blocks per trip
-        // coordinates of the NEXT trip (the last stage of this trip prepares the first B triple of the next one)
+        // coordinates of the NEXT trip (the last stages of this trip prepare the first blocks of the next one)
         float xn[6];
         {
             const float za = zsel(2 * it2 + 2), zb = zsel(2 * it2 + 3);
@@ -180,16 +198,19 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const float xa = xc[2 * p], xb = xc[2 * p + 1];
-            f2_stage<false, false, false>(x, P, F3Trig2{xa, 4}, F3Trig2{xa, 6});
-            f2_stage<false, false, false>(x, P, F3Trig2{xa, 8}, F3Trig2{xb, 0});
-            f2_stage<false, false, false>(x, P, F3Trig2{xb, 2}, F3Trig2{xb, 4});
-            f2_stage<false, false, false>(x, P, F3Trig2{xb, 6}, F3Trig2{xb, 8});
+            // gathers of this pair's five stages: [xa f4-7] [xa f8,9 | xb f0,1] [xb f2-5] [xb f6-9] [next coordinate f0-3], each
+            // evaluated by the stage in front of it
+            const float xa = xc[2 * p], xb = xc[2 * p + 1], xnext = p < 2 ? xc[2 * p + 2] : xn[0];
+            f2_stage_pre<false, false>(x, P, glo, ghi, F2TrigPre{xa, 8, tlo, slo}, F2TrigPre{xb, 0, thi, shi});
+            f2_stage_pre<false, false>(x, P, glo, ghi, F2TrigPre{xb, 2, tlo, slo}, F2TrigPre{xb, 4, thi, shi});
+            f2_stage_pre<false, false>(x, P, glo, ghi, F2TrigPre{xb, 6, tlo, slo}, F2TrigPre{xb, 8, thi, shi});
+            f2_stage_pre<false, false>(x, P, glo, ghi, F2TrigPre{xnext, 0, tlo, slo}, F2TrigPre{xnext, 2, thi, shi});
             if (p < 2) {
-                f2_stage<false, false, false>(x, P, F3Trig2{xc[2 * p + 2], 0}, F3Trig2{xc[2 * p + 2], 2});
+                f2_stage_pre<false, false>(x, P, glo, ghi, F2TrigPre{xnext, 4, tlo, slo}, F2TrigPre{xnext, 6, thi, shi});
             } else {
-                f2_stage<false, false, false>(x, P, F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 0}, F3Ident4{o, d, z, 0}},
-                                              F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 2}, F3Ident4{o, d, z, 4}});
+                f2_stage_pre<false, false>(x, P, RegsOrIdent{it2 == 3, glo, F3Ident4{o, d, z, 0}},
+                                           RegsOrIdent{it2 == 3, ghi, F3Ident4{o, d, z, 4}}, F2TrigPre{xnext, 4, tlo, slo},
+                                           F2TrigPre{xnext, 6, thi, shi});
             }
         }
 #pragma unroll
