@@ -22,13 +22,13 @@ traffic = (2 * r2["FETCH_SIZE"] + r2["WRITE_SIZE"]) * 1024 / 1e9
 g, gp, tl = o["graded"], o["graded_fp32_grade_products"], o["render_trained_like"]
 rows = [
     ("range control of the fp16 kernels (DESIGN §2)", "pack-time power-of-two activation scale chosen on the device from the recorded amax; guard per launch (redo once + re-scale); gradient scale from the last clean step.  Nets with |x| ~ 1e5: first launch redone, scale settles after the second (blind x256, then refined: 16 – 32), every later launch on the fp16 kernels, < 1e-4 of the oracle (forward, training step, teacher; `test_fp16_range_control*`, `test_teacher_range_control`).  Default nets: s = 1, bit-identical to round 3.  Launch count unchanged (the re-scale rides in the fallback pack kernel)."),
-    ("how far training moves the activations (`r04_train_equivalence.txt`: 12 000 steps x 4 families; 30 000 steps, default trio; 16 384 rays per step, analytic scene)", "largest |activation| 7 – 11 at init -> 74 (1 500 steps) -> 262 (12 000) -> **740 (30 000)**, still at scale 1 (guard at 32 768: head-room x44); chain gradient amax 3 – 4e-5 at gradient scale 2^23 throughout, no launch or step redone; held-out PSNR 25.74 / 25.82 / 25.81 / 25.89 dB at 12 000 steps (fp16 trio / exact dW / bf16x3 / fp32 MFMA), 26.58 dB at 30 000.  A factor 70 in 30 k steps is why the 1.2 M-iteration schedule of the reference needs the scale to follow."),
+    ("how far training moves the activations (`r04_train_equivalence.txt`: 12 000 steps x 4 families; 30 000 and 100 000 steps, default trio; 16 384 rays per step, analytic scene)", "largest |activation| 7 – 11 at init -> 74 (1 500 steps) -> 262 (12 000) -> 740 (30 000) -> 2 150 (50 000) -> 6 460 (75 000) -> **8 310 at 87 500 steps: activation scale 2 -> 10 800 at 100 000: scale 4**, no launch and no step redone on the way (the scale moved at the packs, before the guard at 32 768 was ever met); chain gradient amax 2.5 – 4e-5 at gradient scale 2^23 throughout; held-out PSNR 25.74 / 25.82 / 25.81 / 25.89 dB at 12 000 steps (fp16 trio / exact dW / bf16x3 / fp32 MFMA), 26.58 at 30 000, 28.52 at 100 000.  Rounds 2 – 3 would have run this student on the bf16x3 kernels (half speed) for good soon after; the reference trains for 1.2 M iterations."),
     ("bench line (`r04_bench.json`; K = 20, W = 3 for EVERY leg, legs selected through `r2l_config`)", f"`value` (fp16x2 fast mode) **{o['value']/1e6:.1f} M rays/s**, {o['ms_per_step']:.2f} ms per 9-frame launch, {o['roofline']['frac']:.3f} of 833 TF; **`graded` (exact fp32 MFMA) {g['value']/1e6:.2f} M rays/s, {g['ms_per_step']:.1f} ms per launch, {g['roofline']['frac']:.3f} of 157.3 TF**; bf16x3 (fp32-exact products) {gp['value']/1e6:.1f} M, {gp['roofline']['frac']:.3f} of 417 TF; `render_trained_like` (|x| {tl['range']['amax']:.2g}, scale {tl['range']['scale']:g}) {tl['value']/1e6:.1f} M = {tl['rate_vs_default_weights']:.3f} of `value`; train {o['train']['ms_per_step']:.2f} ms ({o['train']['value']/1e6:.2f} M rays/s); exact dW {o['train_exact_dw']['ms_per_step']:.2f} ms; bf16x3 trio {o['train_bf16x3']['ms_per_step']:.2f} ms; fp32 MFMA {o['train_fp32_mfma']['ms_per_step']:.2f} ms ({o['train_fp32_mfma']['roofline']['frac']:.3f} of 157.3 TF; its `r2l_dw_body_kernel`, 374 spills, 8.4 ms = 132 TF = 0.84 of peak: VERDICT r3 #12 asked for its profile); 4096 rays {o['train_4096']['ms_per_step']:.3f} ms; teacher {o['teacher']['ms_per_frame']:.1f} ms/frame ({o['teacher']['roofline']['frac']:.3f}).  Boxes of the pool differ by ±3 %: an earlier run of this round on another box read 38.6 M / 0.547 for `value`."),
     ("kernel counters (`r04_bench_pmc_summary.json`)", f"render `r2l_fwd2_kernel<true>` per 9-frame launch: MFMA busy {b2:.1f} % (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs), HBM-side traffic {traffic:.1f} GB (2 x FETCH_SIZE + WRITE_SIZE: the per-workgroup weight re-stream + 0.87 GB of X0 scratch), SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE {r2['SQ_LDS_BANK_CONFLICT']/r2['SQ_LDS_IDX_ACTIVE']:.4f}; exact-fp32 kernel: {b1:.1f} % busy; teacher `r2l_teacher2_kernel` (192-sample chunks): {bt:.1f} % busy (round 3: 63 %)"),
     ("teacher point network (`r04_teacher_heads_ab.txt`, `r04_teacher_tiles_per_wave_ab.txt`)", "several tiles per wave with a wrapping weight pipeline: no effect for 1 .. 16 tiles (+1.6 % for the loop's spills): not the turnover; timing builds: the two VALU heads cost 6 – 7 %; shipped: alpha head rides on the feature layer's gathers, rgb head as packed FMAs, head weights / biases from LDS, wave-uniform branch between two gatherers: **109.3 -> 106.5 ms per frame (-2.6 %)**, -0.6 % more for the branch, same-box"),
     ("pairing CUs on a tile for the 4096-ray step (`r04_cu_exchange_probe.txt`)", "not built; measured instead what a pair pays per layer: 16 KiB per direction through the shared L2 of one XCD = **1.30 us** per round (8 KiB 0.89, 4 KiB 0.72, flag 0.43) with plain stores + `sc1` loads; with the compiler's agent-scope fences 26 – 50 us (whole-L2 write-back / invalidate).  A chain layer takes 3.0 us today, 1.25 (stream) / 0.78 (MFMA) when halved: 2.55 us per layer with the exchange on the critical path (-15 %, step 0.80 -> ~0.72 ms, target 0.65): DESIGN §7"),
     ("exact weight gradients (`r04_exact_dw_ab.txt`)", "step 10.4 ms (target 9.5): late mid-half store (`-DF2_MID_LATE`) 10.48 – 10.51 vs 10.41 – 10.46; `nt` LDS-DMA loads (`-DDW16_NT`) within noise; default stays fp16 dW"),
-    ("X0 of the render kernel parked in LDS (`r04_render_x0_park_ab.txt`); tail weights from LDS", "parking: 76 -> 29 spills, WRITE_SIZE 849 -> 345 MB per launch, 38.18 / 38.08 vs 38.05 / 37.99 ms (two identical builds in the same harness differ by up to 0.4 %): no gain, default off.  Tail from LDS + packed FMAs: render 37.86 vs 37.80 ms (nothing), training step 7.75 vs 7.81 (-0.7 %): kept"),
+    ("X0 of the render kernel parked in LDS (`r04_render_x0_park_ab.txt`); tail weights from LDS", "head of the fp16x2 kernels: sin / cos one stage ahead in four phases + angle doubling for every second pair: 37.93 -> 37.60 ms per launch (-0.9 %, `r2l_f2.h F2TrigPre`).  Parking: 76 -> 29 spills, WRITE_SIZE 849 -> 345 MB per launch, 38.18 / 38.08 vs 38.05 / 37.99 ms (two identical builds in the same harness differ by up to 0.4 %): no gain, default off.  Tail from LDS + packed FMAs: render 37.86 vs 37.80 ms (nothing), training step 7.75 vs 7.81 (-0.7 %): kept"),
     ("end to end", "`render_path` with PSNR + SSIM 4.4 – 4.5 ms/frame; + prediction and ground-truth PNGs **4.8 – 4.9 ms/frame** over the 200-frame test set (round 3: 6.5; native encoder threads, `r04_e2e_render.txt`); CLI training loop **7.82 – 7.86 ms/iter** at 98 304 rays (round 3: 8.25; step alone 7.73; fused pool kernels, `r04_e2e_train.txt`)"),
     ("4096-ray step, per kernel (`r04_step4096_kernel_stats.txt`, under the profiler)", "chains 274 + 254 us, dW body 104, head 44, Adam 29, two re-packs 36, three reduces 34, nine idle / one-thread launches ~4.7 each"),
     ("multi-GPU pre-flight", "`tests/test_multirank_gpu.py` picks nccl when the box has >= 2 GPUs; `tests/test_multigpu_gpu.py` (C-ABI all-reduce between two ranks, `bench.py --gpus 2`) skips below 2 GPUs; its worker runs as one rank on every box"),
@@ -41,7 +41,7 @@ the same command), `r04_bench_pmc_summary.json` (separate `--pmc` passes, incl. 
 (`tools/cu_exchange_probe.hip`), `r04_exact_dw_ab.txt`, `r04_render_x0_park_ab.txt`, `r04_teacher_heads_ab.txt`,
 `r04_teacher_tiles_per_wave_ab.txt` (same-box A/Bs), `r04_e2e_render.txt`, `r04_e2e_train.txt`, `r04_e2e_train_kernels_before.txt`
 (kernel trace of the CLI loop before the fused pool kernels), `r04_step4096_kernel_stats.txt` (`tools/small_prof.sh 4096`),
-`r04_train_equivalence.txt` (12 000 / 30 000 training steps with range telemetry), `r04_kernel_resources.txt`.  This file and the table
+`r04_train_equivalence.txt` (12 000 / 30 000 / 100 000 training steps with range telemetry), `r04_e2e_create_data.txt`, `r04_kernel_resources.txt`.  This file and the table
 of DESIGN.md §4 are generated from the JSONs by `tools/make_r04_summary.py`.
 
 | item | result |
