@@ -100,6 +100,21 @@ SIGNATURES = {
     "r2l_reader_close": (_i, [_p]),
 }
 
+# range control of the fp16 kernels (include/r2l_hip.h "range control"; csrc/r2l_common.h F2S_* / B2S_*): the word that marks a
+# status area as initialised, and the decoding of the forward / teacher area's 16 words
+RANGE_MAGIC = 0x52324c34
+
+
+def decode_range_words(w):
+    """w: the 16 status words as an int32 CPU tensor -> {'amax', 'scale', 'headroom', 'trips', 'rescales', 'flag'}."""
+    f = w.view(__import__("torch").float32)
+    scale = float(f[2]) if int(w[4]) == RANGE_MAGIC else 1.0
+    live = float(f[1]) * scale
+    amax = live if live > 0 else float(f[6])
+    return {"amax": amax, "scale": scale, "headroom": (32768.0 * scale / amax) if amax > 0 else float("inf"),
+            "trips": int(w[5]), "rescales": int(w[7]), "flag": int(w[0])}
+
+
 # stage bits of r2l_backward_part (include/r2l_hip.h)
 BWD_CHAIN, BWD_BODY, BWD_HEAD, BWD_TAIL, BWD_ALL, BWD_NOFALLBACK = 1, 2, 4, 8, 15, 16
 

@@ -199,13 +199,7 @@ class R2LEngine:
         amax: largest |activation| the launches have seen (current scale epoch, else the previous one); scale: the power of
         two the stream is packed for; headroom: 32768 * scale / amax (x-fold growth the fp16 kernels still take before a
         launch has to be redone by the bf16x3 kernel); trips: launches that were redone; rescales: times the scale changed."""
-        w = self.status_words().cpu()
-        f = w.view(torch.float32)
-        scale = float(f[2]) if int(w[4]) == 0x52324c34 else 1.0
-        live = float(f[1]) * scale
-        amax = live if live > 0 else float(f[6])
-        return {"amax": amax, "scale": scale, "headroom": (32768.0 * scale / amax) if amax > 0 else float("inf"),
-                "trips": int(w[5]), "rescales": int(w[7]), "flag": int(w[0])}
+        return _lib.decode_range_words(self.status_words().cpu())
 
     # ---- sampler tables ---------------------------------------------------------------------------------------
     def ztab(self, z_vals, perturb):

@@ -130,13 +130,7 @@ class TeacherEngine:
         self.ensure_packed()
         word = ctypes.cast(self.lib.r2l_teacher_status_words(_ptr(self.wstream)), ctypes.c_void_p).value
         off = (word - self.wstream.data_ptr()) // 4
-        w = self.wstream[off:off + 16].view(torch.int32).cpu()
-        f = w.view(torch.float32)
-        scale = float(f[2]) if int(w[4]) == 0x52324c34 else 1.0
-        live = float(f[1]) * scale
-        amax = live if live > 0 else float(f[6])
-        return {"amax": amax, "scale": scale, "headroom": (32768.0 * scale / amax) if amax > 0 else float("inf"),
-                "trips": int(w[5]), "rescales": int(w[7]), "flag": int(w[0])}
+        return _lib.decode_range_words(self.wstream[off:off + 16].view(torch.int32).cpu())
 
 
 def teacher_engine(module):

@@ -213,7 +213,7 @@ class R2LTrainer:
         off = (word - self.wstream_bwd.data_ptr()) // 4
         w = self.wstream_bwd[off:off + 16].view(torch.int32).cpu()
         f = w.view(torch.float32)
-        if int(w[9]) == 0x52324c34:
+        if int(w[9]) == _lib.RANGE_MAGIC:
             gscale, scaled = float(f[4]), float(f[8])
             info.update(grad_scale=gscale, grad_amax=(scaled / gscale if gscale > 0 else 0.0),
                         grad_headroom=(32768.0 / scaled if scaled > 0 else float("inf")), bwd_trips=int(w[10]) + int(w[0] != 0))

@@ -640,3 +640,19 @@ def test_native_png_writer_round_trip(tmp_path):
                                      None, None) == 0
     assert lib.r2l_png_writer_close(h) != 0 and b"cannot open" in lib.r2l_last_error()
     assert lib.r2l_png_writer_submit(None, b"x", None, 1, 1, 3, None, None) != 0
+
+
+def test_range_words_decoding():
+    """_lib.decode_range_words: the telemetry of the fp16 kernels' range control from the 16 status words (layout in
+    include/r2l_hip.h); an area the library has not initialised yet (no magic word) reads as scale 1, nothing seen."""
+    import struct
+    from r2l_amd import _lib
+    bits = lambda x: struct.unpack("<i", struct.pack("<f", x))[0]
+    w = torch.zeros(16, dtype=torch.int32)
+    assert _lib.decode_range_words(w) == {"amax": 0.0, "scale": 1.0, "headroom": float("inf"), "trips": 0, "rescales": 0, "flag": 0}
+    w[1], w[2], w[3], w[4], w[5], w[6], w[7] = bits(5000.0), bits(16.0), bits(1 / 16.), _lib.RANGE_MAGIC, 1, bits(123.0), 2
+    info = _lib.decode_range_words(w)
+    assert info["amax"] == 80000.0 and info["scale"] == 16.0 and abs(info["headroom"] - 32768.0 * 16 / 80000.0) < 1e-9
+    assert info["trips"] == 1 and info["rescales"] == 2 and info["flag"] == 0
+    w[1] = 0  # nothing seen since the last commit: the previous epoch's peak is reported
+    assert _lib.decode_range_words(w)["amax"] == 123.0
