@@ -342,7 +342,7 @@ __device__ __forceinline__ void r2l_sincos(float x, float& s_out, float& c_out) 
 // r2l_coopf_fwd.hip — NOT the bf16x3 / fp32 kernels, whose families are held to fp32-exact bars) is derived from its predecessor.
 // Error: the inputs' 1.5 ulp doubled plus one rounding, <= 8e-7 absolute on values of magnitude <= 1 — the size of the fp16x2
 // products' own 2^-21, three orders of magnitude below what one ulp of the POINT already does to these features at the highest
-// frequency (1.2e-4): invisible at the 1e-4 RGB bar (measured: max |dRGB| vs the oracle unchanged at 1.5e-6).
+// frequency (1.2e-4): invisible at the 1e-4 RGB bar (measured: max |dRGB| against the CPU restatement of the reference unchanged at 1.5e-6).
 // Same-box A/B of the render launch: 37.10 -> 36.94 ms (-0.4 %); with the evaluation software-pipelined (r2l_f2.h F2TrigPre)
 // 37.93 -> 37.60 ms (-0.9 %).  (A timing build WITHOUT sin / cos ran in 36.2 ms, which first read as "4.8 % to gain": most of that
 // is the power cap again — garbage encodings make a net whose activations toggle fewer bits.)

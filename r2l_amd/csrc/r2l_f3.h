@@ -253,7 +253,7 @@ struct F3Trig2 {  // (sin, cos) of x * 2^f0 and x * 2^(f0+1)
 #else
         // (both pairs from r2l_sincos here: this gatherer serves the bf16x3 kernels, whose products are fp32-exact and whose
         // training family is held to the strict 2e-5 Adam bar — the angle doubling of the fp16x2 kernels' head, r2l_f2.h
-        // F2TrigPre, moved one weight of test_three_adam_steps_vs_oracle[main-bf16x3-trio] by 1.9e-4 when it was tried here)
+        // F2TrigPre, moved one weight of the three-Adam-steps parity test (bf16x3 trio) by 1.9e-4 when it was tried here)
         r2l_sincos(x * (float)(1 << f0), v[0], v[1]);
         r2l_sincos(x * (float)(1 << (f0 + 1)), v[2], v[3]);
 #endif
