@@ -32,7 +32,7 @@ rows = [
     ("end to end", "`render_path` with PSNR + SSIM 4.4 – 4.5 ms/frame; + prediction and ground-truth PNGs **4.8 – 4.9 ms/frame** over the 200-frame test set (round 3: 6.5; native encoder threads, `r04_e2e_render.txt`); CLI training loop **7.82 – 7.86 ms/iter** at 98 304 rays (round 3: 8.25; step alone 7.73; fused pool kernels, `r04_e2e_train.txt`)"),
     ("4096-ray step, per kernel (`r04_step4096_kernel_stats.txt`, under the profiler)", "chains 274 + 254 us, dW body 104, head 44, Adam 29, two re-packs 36, three reduces 34, nine idle / one-thread launches ~4.7 each"),
     ("multi-GPU pre-flight", "`tests/test_multirank_gpu.py` picks nccl when the box has >= 2 GPUs; `tests/test_multigpu_gpu.py` (C-ABI all-reduce between two ranks, `bench.py --gpus 2`) skips below 2 GPUs; its worker runs as one rank on every box"),
-    ("GPU test suite", "371 passed, 73 skipped (`-m gpu`, 163 – 197 s; CPU suite: 54 passed in 19 s); kernel families selected through `r2l_config` (`tests/conftest.py use_family`)"),
+    ("GPU test suite", "371 passed, 73 skipped (`-m gpu`, 163 – 197 s; CPU suite: 55 passed in 20 s); kernel families selected through `r2l_config` (`tests/conftest.py use_family`)"),
 ]
 head = '''# r04 — what changed and what was measured (one MI355X per `gpurun` call; boxes of the pool differ by ±3 % on the 16-bit kernels)
 
@@ -41,7 +41,7 @@ the same command), `r04_bench_pmc_summary.json` (separate `--pmc` passes, incl. 
 (`tools/cu_exchange_probe.hip`), `r04_exact_dw_ab.txt`, `r04_render_x0_park_ab.txt`, `r04_teacher_heads_ab.txt`,
 `r04_teacher_tiles_per_wave_ab.txt` (same-box A/Bs), `r04_e2e_render.txt`, `r04_e2e_train.txt`, `r04_e2e_train_kernels_before.txt`
 (kernel trace of the CLI loop before the fused pool kernels), `r04_step4096_kernel_stats.txt` (`tools/small_prof.sh 4096`),
-`r04_train_equivalence.txt` (12 000 / 30 000 / 100 000 training steps with range telemetry), `r04_e2e_create_data.txt`, `r04_kernel_resources.txt`.  This file and the table
+`r04_train_equivalence.txt` (12 000 / 30 000 / 100 000 training steps with range telemetry), `r04_e2e_create_data.txt`, `r04_kernel_resources.txt`, `r04_dw_body_spill_sites.txt`.  This file and the table
 of DESIGN.md §4 are generated from the JSONs by `tools/make_r04_summary.py`.
 
 | item | result |
