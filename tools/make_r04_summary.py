@@ -41,7 +41,7 @@ the same command), `r04_bench_pmc_summary.json` (separate `--pmc` passes, incl. 
 (`tools/cu_exchange_probe.hip`), `r04_exact_dw_ab.txt`, `r04_render_x0_park_ab.txt`, `r04_teacher_heads_ab.txt`,
 `r04_teacher_tiles_per_wave_ab.txt` (same-box A/Bs), `r04_e2e_render.txt`, `r04_e2e_train.txt`, `r04_e2e_train_kernels_before.txt`
 (kernel trace of the CLI loop before the fused pool kernels), `r04_step4096_kernel_stats.txt` (`tools/small_prof.sh 4096`),
-`r04_train_equivalence.txt` (12 000 / 30 000 / 100 000 training steps with range telemetry), `r04_e2e_create_data.txt`, `r04_kernel_resources.txt`, `r04_dw_body_spill_sites.txt`.  This file and the table
+`r04_train_equivalence.txt` (12 000 / 30 000 / 100 000 training steps with range telemetry), `r04_e2e_create_data.txt`, `r04_kernel_resources.txt`, `r04_spill_sites.txt`.  This file and the table
 of DESIGN.md §4 are generated from the JSONs by `tools/make_r04_summary.py`.
 
 | item | result |

@@ -27,8 +27,8 @@ def kernel_asm(src, kernel):
         raise SystemExit("no kernel matching %r in %s" % (kernel, src))
     out = []
     for s in start:
-        e = next(i for i in range(s, len(lines)) if "s_endpgm" in lines[i])
-        out.append((lines[s].split(":")[0], lines[s:e + 1]))
+        e = next(i for i in range(s, len(lines)) if lines[i].startswith(".Lfunc_end"))  # a kernel may hold several s_endpgm
+        out.append((lines[s].split(":")[0], lines[s:e]))
     return out
 
 
