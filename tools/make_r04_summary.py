@@ -22,7 +22,7 @@ traffic = (2 * r2["FETCH_SIZE"] + r2["WRITE_SIZE"]) * 1024 / 1e9
 g, gp, tl = o["graded"], o["graded_fp32_grade_products"], o["render_trained_like"]
 rows = [
     ("range control of the fp16 kernels (DESIGN §2)", "pack-time power-of-two activation scale chosen on the device from the recorded amax; guard per launch (redo once + re-scale); gradient scale from the last clean step.  Nets with |x| ~ 1e5: first launch redone, scale settles after the second (blind x256, then refined: 16 – 32), every later launch on the fp16 kernels, < 1e-4 of the oracle (forward, training step, teacher; `test_fp16_range_control*`, `test_teacher_range_control`).  Default nets: s = 1, bit-identical to round 3.  Launch count unchanged (the re-scale rides in the fallback pack kernel)."),
-    ("how far training moves the activations (`r04_train_equivalence.txt`: 12 000 steps x 4 families; 30 000, 100 000 and 300 000 steps, default trio; 16 384 rays per step, analytic scene)", "largest |activation| 7 – 11 at init -> 74 (1 500 steps) -> 262 (12 000) -> 740 (30 000) -> 2 150 (50 000) -> 6 460 (75 000) -> **8 310 at 87 500 steps: activation scale 2 -> 10 800 at 100 000: scale 4 -> (300 000-step run) 34 200 at 187 500: scale 8 -> 72 500 at 262 500: scale 16 (past fp16's 65 504)**, no launch and no step redone on the way (the scale moved at the packs, before the guard at 32 768 was ever met); chain gradient amax 2.5 – 4e-5 at gradient scale 2^23 throughout; held-out PSNR 25.74 / 25.82 / 25.81 / 25.89 dB at 12 000 steps (fp16 trio / exact dW / bf16x3 / fp32 MFMA), 26.58 at 30 000, 28.52 at 100 000, 30.42 at 300 000.  Rounds 2 – 3 would have run this student on the bf16x3 kernels (half speed) for good soon after; the reference trains for 1.2 M iterations."),
+    ("how far training moves the activations (`r04_train_equivalence.txt`: 12 000 steps x 4 families; 30 000, 100 000 and 300 000 steps, default trio; 16 384 rays per step, analytic scene)", "largest |activation| 7 – 11 at init -> 74 (1 500 steps) -> 262 (12 000) -> 740 (30 000) -> 2 150 (50 000) -> 6 460 (75 000) -> **8 310 at 87 500 steps: activation scale 2 -> 10 800 at 100 000: scale 4 -> (300 000-step run) 34 200 at 187 500: scale 8 -> 72 500 at 262 500: scale 16 (past fp16's 65 504)**, no launch and no step redone on the way (the scale moved at the packs, before the guard at 32 768 was ever met); chain gradient amax 2.5 – 4e-5 at gradient scale 2^23 throughout; held-out PSNR 25.74 / 25.82 / 25.81 / 25.89 dB at 12 000 steps (fp16 trio / exact dW / bf16x3 / fp32 MFMA), 26.58 at 30 000, 28.52 at 100 000, 30.42 at 300 000.  The student trained for 100 000 steps renders 4096 held-out rays within 7.3e-6 of the fp32 CPU restatement on the same weights (bar 1e-4).  Rounds 2 – 3 would have run this student on the bf16x3 kernels (half speed) for good soon after; the reference trains for 1.2 M iterations."),
     ("bench line (`r04_bench.json`; K = 20, W = 3 for EVERY leg, legs selected through `r2l_config`)", f"`value` (fp16x2 fast mode) **{o['value']/1e6:.1f} M rays/s**, {o['ms_per_step']:.2f} ms per 9-frame launch, {o['roofline']['frac']:.3f} of 833 TF; **`graded` (exact fp32 MFMA) {g['value']/1e6:.2f} M rays/s, {g['ms_per_step']:.1f} ms per launch, {g['roofline']['frac']:.3f} of 157.3 TF**; bf16x3 (fp32-exact products) {gp['value']/1e6:.1f} M, {gp['roofline']['frac']:.3f} of 417 TF; `render_trained_like` (|x| {tl['range']['amax']:.2g}, scale {tl['range']['scale']:g}) {tl['value']/1e6:.1f} M = {tl['rate_vs_default_weights']:.3f} of `value`; train {o['train']['ms_per_step']:.2f} ms ({o['train']['value']/1e6:.2f} M rays/s); exact dW {o['train_exact_dw']['ms_per_step']:.2f} ms; bf16x3 trio {o['train_bf16x3']['ms_per_step']:.2f} ms; fp32 MFMA {o['train_fp32_mfma']['ms_per_step']:.2f} ms ({o['train_fp32_mfma']['roofline']['frac']:.3f} of 157.3 TF; its `r2l_dw_body_kernel`, 374 spills, 8.4 ms = 132 TF = 0.84 of peak: VERDICT r3 #12 asked for its profile); 4096 rays {o['train_4096']['ms_per_step']:.3f} ms; teacher {o['teacher']['ms_per_frame']:.1f} ms/frame ({o['teacher']['roofline']['frac']:.3f}).  Boxes of the pool differ by ±3 %: an earlier run of this round on another box read 38.6 M / 0.547 for `value`."),
     ("kernel counters (`r04_bench_pmc_summary.json`)", f"render `r2l_fwd2_kernel<true>` per 9-frame launch: MFMA busy {b2:.1f} % (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs), HBM-side traffic {traffic:.1f} GB (2 x FETCH_SIZE + WRITE_SIZE: the per-workgroup weight re-stream + 0.87 GB of X0 scratch), SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE {r2['SQ_LDS_BANK_CONFLICT']/r2['SQ_LDS_IDX_ACTIVE']:.4f}; exact-fp32 kernel: {b1:.1f} % busy; teacher `r2l_teacher2_kernel` (192-sample chunks): {bt:.1f} % busy (round 3: 63 %)"),
     ("teacher point network (`r04_teacher_heads_ab.txt`, `r04_teacher_tiles_per_wave_ab.txt`)", "several tiles per wave with a wrapping weight pipeline: no effect for 1 .. 16 tiles (+1.6 % for the loop's spills): not the turnover; timing builds: the two VALU heads cost 6 – 7 %; shipped: alpha head rides on the feature layer's gathers, rgb head as packed FMAs, head weights / biases from LDS, wave-uniform branch between two gatherers: **109.3 -> 106.5 ms per frame (-2.6 %)**, -0.6 % more for the branch, same-box"),

@@ -5,7 +5,9 @@ the fp32-exact families?  The same W256 D88 student (seed 0), the same seeded ba
 on an analytic scene with silhouettes and shading (three lit spheres on white, rays from the r = 4 sphere like
 create_data's poses).  Held-out PSNR every 250 iterations.  Trajectories of a chaotic optimisation separate whatever the
 rounding (the two fp32-exact families differ only in summation order), so their mutual distance is the yardstick for the
-fp16 trio's distance to either.  GPU box:  python tools/train_equivalence.py [iters=1500] [rays=16384]"""
+fp16 trio's distance to either.  GPU box:  python tools/train_equivalence.py [iters=1500] [rays=16384]
+R2L_EQ_FAMILIES=0,3 keeps a subset of the families; R2L_EQ_PARITY=4096 also compares each TRAINED student's forward on that many
+held-out rays with the CPU restatement (fp32 torch ops)."""
 import os
 import sys
 import time
@@ -94,6 +96,16 @@ def main(iters=1500, n=16384):
                                      ri.get("bwd_trips", 0)))
         torch.cuda.synchronize()
         curves[name], finals[name] = curve, out.clone()
+        if os.environ.get("R2L_EQ_PARITY"):  # the TRAINED student against the CPU restatement (checker only; same rays, fp32 torch CPU ops)
+            k = int(os.environ["R2L_EQ_PARITY"])
+            sd_t = {key: v.detach().cpu().clone() for key, v in m.state_dict().items()}
+            ref = O.r2l_forward(sd_t, O.positional_embed(O.sample_train(test_o[:k].cpu(), test_d[:k].cpu(), O.z_vals(16, 2., 6.), 0.), 10))
+            with torch.no_grad():
+                got = m.forward_rays(test_o[:k], test_d[:k], ps, perturb=0.).cpu()
+            ri = tr.range_info()
+            print("%-22s trained weights after %d steps, %d held-out rays: max |rgb_hip - rgb_cpu_fp32| = %.3e (bar 1e-4); "
+                  "largest |activation| %.3g, scale %g, launches redone %d" % (name, iters, k, (got - ref).abs().max().item(),
+                                                                              ri["amax"], ri["scale"], ri["trips"]), flush=True)
         weights[name] = m.engine().flat.clone() if hasattr(m, "engine") else None
         print("%-22s %5.1f s  " % (name, time.time() - t0) + "  ".join("it %d: %.3f dB" % c for c in curve), flush=True)
     names = list(FAMILIES)
