@@ -89,7 +89,6 @@ struct r2l_png_writer {
     std::condition_variable cv_job, cv_done;
     std::deque<PngJob> queue;
     int64_t next_id = 0;
-    std::vector<int64_t> running;  // ids being encoded
     int64_t done_below = 0;        // every id < done_below is finished (ids finish out of order: see finished)
     std::vector<int64_t> finished; // finished ids >= done_below
     std::string error;             // first failure
@@ -161,7 +160,7 @@ extern "C" int r2l_png_writer_submit(r2l_png_writer* w, const char* path, const 
 extern "C" int r2l_png_writer_wait(r2l_png_writer* w, int64_t job_id) {
     R2L_REQUIRE(w != nullptr, "r2l_png_writer_wait: NULL writer");
     std::unique_lock<std::mutex> lk(w->mu);
-    const int64_t upto = job_id < 0 ? w->next_id : job_id + 1;
+    const int64_t upto = (job_id < 0 || job_id >= w->next_id) ? w->next_id : job_id + 1;  // (an id not handed out yet: everything so far)
     w->cv_done.wait(lk, [&] { return w->done_below >= upto; });
     if (!w->error.empty()) {
         r2l_set_error_msg(w->error.c_str());
