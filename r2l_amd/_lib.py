@@ -107,7 +107,8 @@ RANGE_MAGIC = 0x52324c34
 
 def decode_range_words(w):
     """w: the 16 status words as an int32 CPU tensor -> {'amax', 'scale', 'headroom', 'trips', 'rescales', 'flag'}."""
-    f = w.view(__import__("torch").float32)
+    import torch
+    f = w.view(torch.float32)
     scale = float(f[2]) if int(w[4]) == RANGE_MAGIC else 1.0
     live = float(f[1]) * scale
     amax = live if live > 0 else float(f[6])

@@ -97,12 +97,23 @@ def _compile(src):
     return obj, True
 
 
+def _require_zlib():
+    """csrc/r2l_png.hip (the native PNG encoder threads of the test-set loop) is part of the one library and needs zlib's
+    development files; say so by name instead of failing somewhere inside 24 hipcc jobs."""
+    probe = subprocess.run([HIPCC, "-x", "c++", "-E", "-"], input="#include <zlib.h>\n", capture_output=True, text=True)
+    if probe.returncode != 0:
+        raise RuntimeError("r2l_amd.build: <zlib.h> not found — libr2l_hip.so links zlib (-lz) for csrc/r2l_png.hip; install the "
+                           "zlib development package (zlib1g-dev / zlib-devel)")
+
+
 def build(verbose=True, force=False):
     os.makedirs(OBJDIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJDIR):
             os.remove(os.path.join(OBJDIR, f))
     srcs = _sources()
+    if any(not os.path.exists(os.path.join(OBJDIR, f.replace(".hip", ".o"))) for f in srcs):
+        _require_zlib()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(_compile, srcs))
     objs = [o for o, _ in results]

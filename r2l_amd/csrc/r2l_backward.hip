@@ -1130,7 +1130,8 @@ __global__ __launch_bounds__(64) void r2l_bwd_prepare_kernel(unsigned* status, c
     const float gs = fabsf(grad_scale);
     const bool valid = status[B2S_MAGIC] == F2_MAGIC;
     const bool clean = valid && status[B2S_FLAG] == 0u;
-    const float a = clean ? __builtin_bit_cast(float, status[B2S_AMAX]) : 0.f;
+    const float a_raw = valid ? __builtin_bit_cast(float, status[B2S_AMAX]) : 0.f;  // 0: the chain did not run (forward fell back)
+    const float a = clean ? a_raw : 0.f;
     const float g_prev = valid ? __builtin_bit_cast(float, status[B2S_GSCALE]) : 0.f;
     const float gs_prev = valid ? __builtin_bit_cast(float, status[B2S_GS]) : 0.f;
     int ex_prev = 0;
@@ -1138,12 +1139,21 @@ __global__ __launch_bounds__(64) void r2l_bwd_prepare_kernel(unsigned* status, c
     float peak = valid ? __builtin_bit_cast(float, status[B2S_PEAK]) : 0.f;
     unsigned trips = valid ? status[B2S_TRIPS] : 0u;
     if (valid && status[B2S_FLAG] != 0u) ++trips;
+    // a step whose CHAIN tripped the guard (round 5): its AMAX is the truth while every value stayed finite in fp32 — the guard
+    // trips at 32768, the fp32 B values are tracked before their fp16 conversion — so the next step re-centres on it instead of
+    // repeating the a-priori rule (and tripping again, step after step, on a net whose gradients grow through the body);
+    // AMAX = inf / NaN: only "too large" is known — the scale drops by 2^8 and the following step refines it
+    bool blind = false;
     if (clean && g_ok && a > 0.f && a < 3.0e38f) peak = a / g_prev;  // unscaled amax of the last clean step
-    else if (!clean) peak = 0.f;                                      // (a step that fell back says nothing reliable)
+    else if (!clean && valid && g_ok && a_raw > 0.f && a_raw < 3.0e38f) peak = a_raw / g_prev;
+    else if (!clean && valid && g_ok && !(a_raw <= 0.f) && !(a_raw < 3.0e38f)) { blind = true; peak = 0.f; }
+    else if (!clean) peak = 0.f;                                      // (a step whose forward fell back says nothing reliable)
     if (mse) {
         int ex = 0;
         const float est = (peak > 0.f && gs_prev > 0.f && gs > 0.f && g_ok) ? peak * (gs / gs_prev) : 0.f;
-        if (est > 0.f && est < 3.0e38f) {
+        if (blind) {
+            ex = (ex_prev - 1) - 8;
+        } else if (est > 0.f && est < 3.0e38f) {
             const float scaled = est * g_prev;
             if (scaled >= 0.25f && scaled <= 8192.f) {
                 ex = ex_prev - 1;
@@ -1168,6 +1178,7 @@ __global__ __launch_bounds__(64) void r2l_bwd_prepare_kernel(unsigned* status, c
     status[B2S_TRIPS] = trips;
     status[B2S_MAGIC] = F2_MAGIC;
     status[B2S_AMAX] = 0u;
+    status[B2S_EXPANDED] = 0u;
     status[B2S_FLAG] = 0u;
 }
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
@@ -1326,7 +1337,8 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             if (rc2) return rc2;
             if (!no_fallback) {
                 // the fallback's stream is packed in front of it, and only when it will run
-                const int rp = r2l_bwd3_pack(params, n_block, const_cast<float*>(w3), stream, bwd_status);
+                // (... and an fp16 forward stash is expanded for the bf16x3 kernels: a chain-only trip, r2l_bwd3.hip)
+                const int rp = r2l_bwd3_pack(params, n_block, const_cast<float*>(w3), stream, bwd_status, save_x, save_t, N);
                 if (rp) return rp;
             }
         }

@@ -24,9 +24,59 @@ __host__ __device__ static inline int64_t b3_off_tail_w(int n_block) { return b3
 // pack: stage g = 34 * slot + r, slot = n_block-1-b;  r = 0 / 17: zero stages;  r = 1..16: k-block r-1 of W2^T (layer 2b+1);
 // r = 18..33: k-block r-18 of W1^T (layer 2b).  Element (split, tile t, lane (i,h), slot s): (W^T)[32t+i][feature(kb,h,s)]
 // =================================================================================================================
+// When this pack runs as the FALLBACK of the fp16 dX chain (run_if = the step's status words, raised) and the forward of the step
+// stayed on the fp16 kernels (format word 0: only the gradient chain left fp16's range), the stash still holds fp16 stage pieces
+// of x / act_s and relu(t) / act_s (r2l_f2.h), which neither the bf16x3 chain behind this launch (x_0's ReLU mask) nor its
+// weight-gradient kernel (both operands chunked fp32) can read (round 4 read them as fp32 — garbage body dW, applied
+// silently).  The first 2 n_block workgroups therefore EXPAND one slot each to the chunked fp32 layout, in place and unscaled:
+// per 32-ray tile 16 KiB of hi halves at byte 16384 T become 32 KiB at 32768 T, which covers the pieces of tiles 2T and 2T + 1 —
+// so a slot's tiles are walked from the last to the first by ONE workgroup (a rare path: no parallelism spent on it).  The hi
+// halves are all the default trio stashes (its weight gradients take one fp16 product anyway); the mid halves of the exact-dW
+// mode lie where the expanded tiles go and are dropped: such a step's weight gradients are the default trio's.  The last
+// workgroup to finish flips the format word to 1, so that a second backward over the same stash goes straight to the bf16x3 kernels.
+__device__ __forceinline__ void b3_expand_h16_slot(float* __restrict__ base, int64_t n_tiles, float act_scale) {
+    const int t = (int)threadIdx.x;
+    const u32x4* in = reinterpret_cast<const u32x4*>(base);
+    for (int64_t T = n_tiles - 1; T >= 0; --T) {
+        f32x4 o[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 v = in[T * 1024 + t + 256 * j];  // (R2L_H16_TILE_UNITS of r2l_f2.h: 1024 16-byte units per tile)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                typedef _Float16 b3_h2 __attribute__((ext_vector_type(2)));
+                const b3_h2 p = __builtin_bit_cast(b3_h2, v[w]);
+                o[j][w >> 1][2 * (w & 1)] = (float)p[0] * act_scale;
+                o[j][w >> 1][2 * (w & 1) + 1] = (float)p[1] * act_scale;
+            }
+        }
+        __syncthreads();  // (fence + barrier: every lane's loads of this tile have landed before any lane overwrites them — T = 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = t + 256 * j, kb = u >> 6, lane = u & 63, i = lane & 31, h = lane >> 5;
+            float* dst = base + T * R2L_CHUNK_TILE + (int64_t)(2 * kb) * R2L_CHUNK_PIECE + i * 8 + 4 * h;
+            *reinterpret_cast<f32x4*>(dst) = o[j][0];                    // features 16 kb + 4 h .. + 3      (slots s = 0 .. 3)
+            *reinterpret_cast<f32x4*>(dst + R2L_CHUNK_PIECE) = o[j][1];  // features 16 kb + 8 + 4 h .. + 3  (slots s = 4 .. 7)
+        }
+    }
+}
 __global__ void r2l_pack_bwd3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
-                                     const unsigned* __restrict__ run_if) {
+                                     unsigned* __restrict__ run_if, float* save_x, float* save_t, int64_t Np) {
     if (run_if != nullptr && __builtin_nontemporal_load(run_if) == 0u) return;  // fallback stream: only packed when needed
+    if (run_if != nullptr && save_x != nullptr && (int)blockIdx.x < 2 * n_block) {
+        unsigned* fmt = reinterpret_cast<unsigned*>(save_x) + R2L_STASH_FMT_WORD(n_block, Np);
+        if (__builtin_nontemporal_load(fmt) == 0u) {  // (uniform: every workgroup reads it before the last one can flip it)
+            const float act_scale = reinterpret_cast<const float*>(fmt)[1];
+            const int b = (int)blockIdx.x >> 1;
+            b3_expand_h16_slot(((blockIdx.x & 1) ? save_t : save_x) + (int64_t)b * R2L_TRIO_SLOT(Np), Np / R2L_TILE_RAYS, act_scale);
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0 && atomicAdd(run_if + B2S_EXPANDED, 1u) == 2u * (unsigned)n_block - 1u) {
+                __threadfence();
+                *fmt = 1u;
+            }
+        }
+    }
     const int64_t stages = r2l_bwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -261,9 +311,12 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd3_kernel(const B3Args a) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if) {
+int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if,
+                  const float* save_x, const float* save_t, int64_t N) {
+    // (the status words and the stash are library-private contents of caller-owned buffers: written through, hence the casts)
     hipLaunchKernelGGL(r2l_pack_bwd3_kernel, dim3(2048), dim3(256), 0, stream, params,
-                       reinterpret_cast<unsigned short*>(wstream3), n_block, run_if);
+                       reinterpret_cast<unsigned short*>(wstream3), n_block, const_cast<unsigned*>(run_if),
+                       const_cast<float*>(save_x), const_cast<float*>(save_t), R2L_PAD_ROWS(N));
     R2L_CHECK(hipGetLastError());
     return 0;
 }

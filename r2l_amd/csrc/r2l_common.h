@@ -416,10 +416,13 @@ __host__ __device__ static inline int64_t r2l_bwd2_stream_floats(int n_block) { 
 // kernel of the step reads them here; AMAX: largest |B value| of the step's chain (scaled units, float bits); MAGIC / PEAK / GS:
 // history for the next step's scale (r2l_bwd_prepare_kernel, r2l_backward.hip): unscaled gradient amax and grad_scale of the
 // last clean step; TRIPS: steps that fell back (telemetry)
-enum { B2S_FLAG = 0, B2S_GSCALE = 4, B2S_GINV = 5, B2S_AMAX = 8, B2S_MAGIC = 9, B2S_TRIPS = 10, B2S_PEAK = 11, B2S_GS = 12 };
+// EXPANDED: workgroups of the fallback pack that have expanded their slot of an fp16 forward stash (r2l_bwd3.hip), per step
+enum { B2S_FLAG = 0, B2S_GSCALE = 4, B2S_GINV = 5, B2S_AMAX = 8, B2S_MAGIC = 9, B2S_TRIPS = 10, B2S_PEAK = 11, B2S_GS = 12, B2S_EXPANDED = 13 };
 // run_if: nullptr, or a device word — the pack returns at once while it is 0 (the bf16x3 stream as range-guard fallback of the
 // fp16 kernels is packed right in front of the fallback launch, and only when that launch will really run)
-int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if = nullptr);
+// save_x / save_t / N (fallback of a training step only): an fp16 forward stash is expanded to the chunked fp32 layout first
+int r2l_bwd3_pack(const float* params, int n_block, float* wstream3, hipStream_t stream, const unsigned* run_if = nullptr,
+                  const float* save_x = nullptr, const float* save_t = nullptr, int64_t N = 0);
 int r2l_bwd3_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                       const float* wstream_bwd3, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                       float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale = 1.0f,

@@ -191,13 +191,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         head_stage(std::integral_constant<int, 14>{}, c, rb);  head_stage(std::integral_constant<int, 15>{}, c, rb);
         if (c < 3) fc_barrier();
     }
+    // the head ran on unscaled weights (r2l_f2.h range control): the chain continues on X_0 / act_s (exact: a power of two)
+    const float act_inv = __builtin_bit_cast(float, a.status[F2S_INV]);
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                x[rt][tt][c] = fmaxf(x[rt][tt][c], 0.f);  // X_0 = relu(head)
+                x[rt][tt][c] = fmaxf(x[rt][tt][c], 0.f) * act_inv;  // X_0 = relu(head) / act_s
                 x0[rt][tt][c] = x[rt][tt][c];
             }
 

@@ -56,10 +56,13 @@ struct F2Split {
 
 // ---- range control of the fp16x2 forward (round 4) ---------------------------------------------------------------------------
 // fp16 ends at 65504, and a trained 88-layer residual stream is not bounded a priori.  A ReLU net is positively homogeneous:
-// dividing the head's weights and EVERY bias by s divides every activation (x_b and t_b alike) by s, with the body weights
-// untouched; the tail multiplies its dot products by s again.  For s a power of two all of this is exact in fp32, so the stage
-// stream is simply PACKED for the scale s the previous launches asked for, and the kernels multiply by s where they leave the
-// chain (tail, y slot of the stash; the weight-gradient GEMMs that read the stash of x / s multiply dW by s at their flush).
+// dividing X_0 = relu(head) and every BODY bias by s divides every activation (x_b and t_b alike) by s, with the body weights
+// untouched; the tail multiplies its dot products by s again.  For s a power of two all of this is exact in fp32, so the body
+// bias stages are PACKED for the scale s the previous launches asked for, the kernels multiply the head's fp32 accumulators by
+// 1 / s where X_0 is formed, and by s where values leave the chain (tail, y slot of the stash; the weight-gradient GEMMs that
+// read the stash of x / s multiply dW by s at their flush).  (Round 4 divided the head's WEIGHTS by s before their fp16 split:
+// fp16 has no spare exponent range — weights of ~0.03 lose their mid half from s = 2^4 on and flush to zero near 2^24, ADVICE
+// r4.  The head stages and the head bias are packed unscaled now: the head GEMM runs on the encoding, which is bounded.)
 // Everything lives in the 16 status words behind the stage stream, on the device — no host round trip:
 //   FLAG      != 0: the fp16x2 launch in flight saw |value| >= R2L_F2_RANGE (or s is exhausted): the bf16x3 kernel behind redoes it
 //   AMAX      largest |B value| (scaled units, float bits; atomicMax) of the launches since the scale was last committed
@@ -155,8 +158,9 @@ __device__ __forceinline__ void f2_report_amax(unsigned* st, float amax, int lan
 
 // ---- pack: flat fp32 parameters -> fp16x2 forward stage stream (shared by r2l_fwd2.hip's pack and the fallback pack of
 // r2l_fwd3.hip).  A stage is [split sp (2)][tile t][lane (i,h)][slot s] fp16; bias stage: split region 0 only, slots 0, 1 of
-// half 0 = hi, mid.  Head weights and all biases are multiplied by inv_s (a power of two: exact).  only_scaled: just the
-// stages that depend on the scale (head, bias stages).
+// half 0 = hi, mid.  The BODY biases are multiplied by inv_s (a power of two: exact); head weights and head bias are packed as
+// they are (the kernels scale the head's fp32 accumulators).  only_scaled: just the stages that depend on the scale (the body's
+// bias stages).
 __host__ __device__ static inline int64_t f2_off_head_b() { return (int64_t)R2L_IN * R2L_W; }
 __host__ __device__ static inline int64_t f2_off_body_w(int layer) {
     return (int64_t)R2L_IN * R2L_W + R2L_W + (int64_t)layer * (R2L_W * R2L_W + R2L_W);
@@ -172,7 +176,7 @@ __device__ __forceinline__ void f2_pack_fwd_elements(const float* __restrict__ p
     for (int64_t idx = first; idx < total; idx += stride) {
         const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
         const int64_t g = idx >> 12;
-        if (only_scaled && !(g < 64 || (g < stages && (g - 64) % 17 == 0))) continue;
+        if (only_scaled && !(g >= 64 && g < stages && (g - 64) % 17 == 0)) continue;
         const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
         unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
         unsigned short v0 = 0, v1 = 0;
@@ -181,7 +185,7 @@ __device__ __forceinline__ void f2_pack_fwd_elements(const float* __restrict__ p
             float w = 0.f;
             if (g == 0) {
                 bias_stage = true;
-                w = params[f2_off_head_b() + o] * inv_s;
+                w = params[f2_off_head_b() + o];
             } else if (g < 64) {
                 const int v = 8 * (int)(g - 1) + s;
                 int col;
@@ -192,7 +196,7 @@ __device__ __forceinline__ void f2_pack_fwd_elements(const float* __restrict__ p
                     const int e = v - 480;
                     col = 21 * (3 * (8 * h + e / 3) + e % 3) + 20;
                 }
-                w = params[(int64_t)o * R2L_IN + col] * inv_s;
+                w = params[(int64_t)o * R2L_IN + col];
             } else {
                 const int layer = (int)((g - 64) / 17), r17 = (int)((g - 64) % 17);
                 if (r17 == 0) {

@@ -220,11 +220,14 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     f2_stage<false, false, false>(x, P, F3Ident4{o, d, z, 8}, F3Ident4{o, d, z, 12});
     f2_stage<false, false, false>(x, P, F3Ident4{o, d, z, 16}, F3Ident4{o, d, z, 20});
     f2_stage<false, false, true>(x, P, F3None{}, F3None{});
+    // the head ran on unscaled weights (r2l_f2.h range control): the chain continues on X_0 / act_s — one fp32 multiply by a
+    // power of two per value (1.0 for every net below the guard: bit-identical to the unscaled chain)
+    const float act_inv = __builtin_bit_cast(float, a.status[F2S_INV]);
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            x[T][c] = fmaxf(x[T][c], 0.f);  // X_0 = relu(head)
+            x[T][c] = fmaxf(x[T][c], 0.f) * act_inv;  // X_0 = relu(head) / act_s
             x0[T][c] = x[T][c];
         }
 #if F2_PARK_X0 > 0

@@ -156,7 +156,8 @@ extern "C" int r2l_png_writer_submit(r2l_png_writer* w, const char* path, const 
 }
 
 // Blocks until job `job_id` (and every earlier one) is on disk; job_id < 0: every job submitted so far.  Returns non-zero if
-// any job failed so far (r2l_last_error: the first failure).
+// any job failed since the last wait that reported a failure (r2l_last_error: the first of them) — the error is handed over
+// ONCE and cleared, so one bad path does not fail every later evaluation of a long-lived shared writer.
 extern "C" int r2l_png_writer_wait(r2l_png_writer* w, int64_t job_id) {
     R2L_REQUIRE(w != nullptr, "r2l_png_writer_wait: NULL writer");
     std::unique_lock<std::mutex> lk(w->mu);
@@ -164,6 +165,7 @@ extern "C" int r2l_png_writer_wait(r2l_png_writer* w, int64_t job_id) {
     w->cv_done.wait(lk, [&] { return w->done_below >= upto; });
     if (!w->error.empty()) {
         r2l_set_error_msg(w->error.c_str());
+        w->error.clear();
         return (int)hipErrorUnknown;
     }
     return 0;

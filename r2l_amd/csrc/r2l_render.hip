@@ -34,14 +34,48 @@ __global__ void r2l_stratified_z_kernel(const float* __restrict__ near, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// raw2outputs: one wave per ray, lane l owns samples [l*CH, l*CH+CH).
+// raw2outputs: one wave per ray, lane l owns samples [l*CH, l*CH+CH).  HBM-bound: S*20 + 12 B read, 24 (+ 4 S) B written per
+// ray.  Round 5: a wave takes RPW rays and issues the loads of ALL of them before the first is composited
+// (round 4's one-ray waves spent half their life in the scan / reduction with nothing in flight: 2.7 - 4.4 TB/s), and the
+// scan and the five sums run on DPP row shifts / broadcasts (VALU, ~2 cycles each) instead of 37 ds_bpermute round trips per
+// ray through the LDS crossbar.  The association of the product scan and of the sums differs from round 4's (and from
+// torch's cumprod / sum) at the 1e-7 level, inside the 1e-4 bar (tests: rtol 2e-5).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float wave_sum(float v) {  // (sample_pdf kernel below: every lane needs the total)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
 
+// DPP controls (gfx9): row_shr:n = 0x110 + n (lane i reads lane i - n of its 16-lane row), row_bcast:15 = 0x142 (lane 15 of a
+// row -> every lane of the next row), row_bcast:31 = 0x143 (lane 31 -> rows 2, 3), wave_shr:1 = 0x138, wave_shl:1 = 0x130.
+// bound_ctrl = false: a lane without a source (or masked out by row_mask) receives `old` — the identity of the operation.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float r2l_dpp(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+// inclusive prefix over the 64 lanes (lane 63 = the total): the scan LLVM's own atomic optimiser emits for gfx9
+__device__ __forceinline__ float wave_scan_add(float v) {
+    v += r2l_dpp<0x111, 0xf>(0.f, v);
+    v += r2l_dpp<0x112, 0xf>(0.f, v);
+    v += r2l_dpp<0x114, 0xf>(0.f, v);
+    v += r2l_dpp<0x118, 0xf>(0.f, v);
+    v += r2l_dpp<0x142, 0xa>(0.f, v);
+    v += r2l_dpp<0x143, 0xc>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    v *= r2l_dpp<0x111, 0xf>(1.f, v);
+    v *= r2l_dpp<0x112, 0xf>(1.f, v);
+    v *= r2l_dpp<0x114, 0xf>(1.f, v);
+    v *= r2l_dpp<0x118, 0xf>(1.f, v);
+    v *= r2l_dpp<0x142, 0xa>(1.f, v);
+    v *= r2l_dpp<0x143, 0xc>(1.f, v);
+    return v;
+}
+
+template <int CH, int RPW>
 __global__ __launch_bounds__(256) void r2l_raw2outputs_kernel(const float* __restrict__ raw, const float* __restrict__ z,
                                                               const float* __restrict__ rays_d,
                                                               const float* __restrict__ noise, int white_bkgd,
@@ -49,65 +83,79 @@ __global__ __launch_bounds__(256) void r2l_raw2outputs_kernel(const float* __res
                                                               float* __restrict__ acc_map, float* __restrict__ weights,
                                                               float* __restrict__ depth_map, int64_t R, int S) {
     const int lane = threadIdx.x & 63;
-    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= R) return;
-    const int CH = (S + 63) / 64;
-    const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
-    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);  // torch.norm(rays_d[..., None, :], dim=-1)
-    const float* zr = z + ray * S;
-    const float* rr = raw + ray * (int64_t)S * 4;
-
-    float al[MAX_CH], col[MAX_CH][3], zz[MAX_CH], pl = 1.0f;  // pl = product of (1-alpha+1e-10) over this lane's chunk
+    const int64_t ray0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (ray0 >= R) return;
+    // ---- every load of the wave's RPW rays first (bytes in flight: RPW x (20 S + 12) per wave) ----
+    f32x4 v[RPW][CH];
+    float zz[RPW][CH], dd[RPW][3];
 #pragma unroll
-    for (int c = 0; c < MAX_CH; ++c) {
-        const int s = lane * CH + c;
-        al[c] = 0.f; zz[c] = 0.f; col[c][0] = col[c][1] = col[c][2] = 0.f;
-        if (c < CH && s < S) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rr + 4 * s);
-            const float z0 = zr[s];
-            float dist = (s + 1 < S) ? zr[s + 1] - z0 : 1e10f;
-            dist = dist * dn;
-            float sg = v[3];
-            if (noise != nullptr) sg += noise[ray * S + s];
-            al[c] = 1.0f - expf(-fmaxf(sg, 0.f) * dist);
-            zz[c] = z0;
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t ray = ray0 + r < R ? ray0 + r : R - 1;  // (a tail wave re-reads the last ray; nothing is stored for it)
+        const float* zr = z + ray * S;
+        const float* rr = raw + ray * (int64_t)S * 4;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) col[c][k] = 1.0f / (1.0f + expf(-v[k]));
-            pl *= (1.0f - al[c]) + 1e-10f;
+        for (int c = 0; c < CH; ++c) {
+            const int s = lane * CH + c;
+            v[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            zz[r][c] = 0.f;
+            if (s < S) {
+                v[r][c] = *reinterpret_cast<const f32x4*>(rr + 4 * s);
+                zz[r][c] = zr[s];
+                if (noise != nullptr) v[r][c][3] += noise[ray * S + s];
+            }
         }
-    }
-    // exclusive product scan across lanes
-    float incl = pl;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(incl, off);
-        if (lane >= off) incl *= o;
+        for (int k = 0; k < 3; ++k) dd[r][k] = rays_d[ray * 3 + k];
     }
-    float T = __shfl_up(incl, 1);
-    if (lane == 0) T = 1.0f;
-    float sr = 0.f, sg_ = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    // ---- composite ray by ray ----
 #pragma unroll
-    for (int c = 0; c < MAX_CH; ++c) {
-        const int s = lane * CH + c;
-        if (c < CH && s < S) {
-            const float w = al[c] * T;
-            if (weights != nullptr) weights[ray * S + s] = w;
-            sr += w * col[c][0]; sg_ += w * col[c][1]; sb += w * col[c][2];
-            sd += w * zz[c]; sa += w;
-            T *= (1.0f - al[c]) + 1e-10f;
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t ray = ray0 + r;
+        if (ray >= R) break;  // wave-uniform
+        const float dn = sqrtf(dd[r][0] * dd[r][0] + dd[r][1] * dd[r][1] + dd[r][2] * dd[r][2]);  // torch.norm(rays_d[..., None, :], dim=-1)
+        const float z_next_lane = r2l_dpp<0x130, 0xf>(0.f, zz[r][0]);  // lane l + 1's first sample = sample (l + 1) CH
+        float al[CH], col[CH][3], pl = 1.0f;  // pl = product of (1-alpha+1e-10) over this lane's chunk
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int s = lane * CH + c;
+            al[c] = 0.f; col[c][0] = col[c][1] = col[c][2] = 0.f;
+            if (s < S) {
+                const float z0 = zz[r][c];
+                const float zn = c + 1 < CH ? zz[r][c + 1 < CH ? c + 1 : c] : z_next_lane;
+                float dist = (s + 1 < S) ? zn - z0 : 1e10f;
+                dist = dist * dn;
+                al[c] = 1.0f - expf(-fmaxf(v[r][c][3], 0.f) * dist);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) col[c][k] = 1.0f / (1.0f + expf(-v[r][c][k]));
+                pl *= (1.0f - al[c]) + 1e-10f;
+            }
         }
-    }
-    sr = wave_sum(sr); sg_ = wave_sum(sg_); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
-    if (lane == 0) {
-        const float q = sd / sa;
-        const float m = (q != q) ? q : fmaxf(1e-10f, q);  // torch.max propagates NaN (empty ray: 0/0)
-        disp_map[ray] = 1.0f / m;
-        acc_map[ray] = sa;
-        depth_map[ray] = sd;
-        const float bg = white_bkgd ? (1.0f - sa) : 0.f;
-        rgb_map[ray * 3 + 0] = sr + bg;
-        rgb_map[ray * 3 + 1] = sg_ + bg;
-        rgb_map[ray * 3 + 2] = sb + bg;
+        // exclusive product scan across lanes
+        float T = r2l_dpp<0x138, 0xf>(1.0f, wave_scan_mul(pl));
+        float sr = 0.f, sg_ = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int s = lane * CH + c;
+            if (s < S) {
+                const float w = al[c] * T;
+                if (weights != nullptr) weights[ray * S + s] = w;
+                sr += w * col[c][0]; sg_ += w * col[c][1]; sb += w * col[c][2];
+                sd += w * zz[r][c]; sa += w;
+                T *= (1.0f - al[c]) + 1e-10f;
+            }
+        }
+        sr = wave_scan_add(sr); sg_ = wave_scan_add(sg_); sb = wave_scan_add(sb); sd = wave_scan_add(sd); sa = wave_scan_add(sa);
+        if (lane == 63) {  // (the inclusive scans' last lane holds the totals)
+            const float q = sd / sa;
+            const float m = (q != q) ? q : fmaxf(1e-10f, q);  // torch.max propagates NaN (empty ray: 0/0)
+            disp_map[ray] = 1.0f / m;
+            acc_map[ray] = sa;
+            depth_map[ray] = sd;
+            const float bg = white_bkgd ? (1.0f - sa) : 0.f;
+            rgb_map[ray * 3 + 0] = sr + bg;
+            rgb_map[ray * 3 + 1] = sg_ + bg;
+            rgb_map[ray * 3 + 2] = sb + bg;
+        }
     }
 }
 
@@ -239,8 +287,15 @@ extern "C" int r2l_raw2outputs(const float* raw, const float* z, const float* ra
     if (R <= 0) return 0;
     if (S < 1 || S > 64 * MAX_CH) { r2l_set_error("r2l_raw2outputs: S out of range [1,256]", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
     R2L_REQUIRE(raw && z && rays_d && rgb_map && disp_map && acc_map && depth_map, "r2l_raw2outputs: a required pointer is NULL (only noise and weights are optional)");
-    hipLaunchKernelGGL(r2l_raw2outputs_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z,
-                       rays_d, noise, white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map, R, S);
+    const int CH = (S + 63) / 64;
+#define R2O_LAUNCH(CH_, RPW_)                                                                                                  \
+    hipLaunchKernelGGL((r2l_raw2outputs_kernel<CH_, RPW_>), dim3((unsigned)((R + 4 * RPW_ - 1) / (4 * RPW_))), dim3(256), 0,     \
+                       (hipStream_t)stream, raw, z, rays_d, noise, white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map, R, S)
+    if (CH == 1) R2O_LAUNCH(1, 4);
+    else if (CH == 2) R2O_LAUNCH(2, 4);
+    else if (CH == 3) R2O_LAUNCH(3, 2);
+    else R2O_LAUNCH(4, 2);
+#undef R2O_LAUNCH
     R2L_CHECK(hipGetLastError());
     return 0;
 }

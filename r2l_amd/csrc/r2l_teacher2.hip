@@ -55,8 +55,12 @@ __host__ __device__ static inline int t2_emb_col(int v, int h, int nfreq_half) {
 // pack
 // =================================================================================================================
 // inv_s: 1 / activation scale (a power of two).  The hidden activations, the feature vector and the views layer's output are
-// all divided by s when layer 0 (whose input, the embedding, is not), the embedding column blocks of layer 5 and of the views
-// layer, and every bias are: kinds 0, 1, 4 below.
+// all divided by s when layer 0's OUTPUT is (the kernel multiplies its fp32 accumulators: layer 0's weights and bias are packed
+// as they are — dividing weights of O(0.1) by s before their fp16 split costs them their mid halves), and the
+// embedding column blocks of layer 5 and of the views layer and every other bias are: kinds 0 (layer > 0), 1 (layer 5), 4 below.
+// (Those two column blocks share their accumulators with the products of the hidden activations, so they stay weight-scaled:
+// their terms are O(|W| |pe|) / s against hidden terms of O(amax / s) >= 2^10 whenever s > 1 — what they lose below 2^-25
+// absolute is below 2^-35 of the layer's output.)
 __device__ __forceinline__ void t2_pack_elements(const float* __restrict__ params, unsigned short* __restrict__ out, float inv_s) {
     const T2Off off = t2_offsets();
     const int64_t total = (int64_t)(T2_STAGES + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
@@ -122,7 +126,7 @@ __device__ __forceinline__ void t2_pack_elements(const float* __restrict__ param
         }
         unsigned short v0 = 0, v1 = 0;
         if (have) {
-            if (kind == 0 || kind == 1 || kind == 4) w *= inv_s;
+            if ((kind == 0 && g != 0) || (kind == 1 && layer == 5) || kind == 4) w *= inv_s;
             const _Float16 hi = (_Float16)w;
             const _Float16 mid = (_Float16)(w - (float)hi);
             const unsigned short hb = __builtin_bit_cast(unsigned short, hi), mb = __builtin_bit_cast(unsigned short, mid);
@@ -396,6 +400,13 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
     f2_stage<false, false, false>(x, P, Xyz4{p, h, 16}, Xyz4{p, h, 20});
     f2_stage<false, false, false>(x, P, Xyz4{p, h, 24}, Xyz4{p, h, 28});
     f2_stage<false, false, true>(x, P, F3None{}, F3None{});
+    {   // layer 0 ran on unscaled weights: the chain continues on x / act_s (a power of two, 1.0 for every teacher in range)
+        const float act_inv = __builtin_bit_cast(float, a.status[F2S_INV]);
+#pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[T][c] *= act_inv;
+    }
 
     // ---- (L1,L2) (L3,L4) (L5,L6) (L7,feature): t = W_odd relu(x) [+ W5pe pe] + b ; x = W_even relu(t) + b -----------------
     float alpha = 0.f;

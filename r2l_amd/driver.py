@@ -221,9 +221,11 @@ class _FrameWriter:
     def _retire(self, n_keep):
         while len(self.inflight) > n_keep:
             job, _, host = self.inflight.pop(0)
-            self._lib.check(self.lib.r2l_png_writer_wait(self._h, job), "r2l_png_writer_wait")
-            if host is not None:
-                self.free.setdefault(tuple(host.shape), []).append(host)
+            try:
+                self._lib.check(self.lib.r2l_png_writer_wait(self._h, job), "r2l_png_writer_wait")
+            finally:  # (a failed write still returns its pinned staging slot: the writer stays usable)
+                if host is not None:
+                    self.free.setdefault(tuple(host.shape), []).append(host)
 
     def save(self, img, path):
         """img: float [H,W,3] in [0,1] (device or host tensor / array)."""

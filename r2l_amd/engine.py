@@ -85,6 +85,7 @@ class R2LEngine:
         self.flat = None
         self.wstream = None
         self._packed_version = None
+        self._status = None
         self._dirty = 0
         self._ztab_cache = {}
         # explicit dispatch handed to every call of this engine (include/r2l_hip.h r2l_config; all zero = AUTO: the library
@@ -183,6 +184,8 @@ class R2LEngine:
     # ---- range control telemetry (include/r2l_hip.h: "range control of the fp16 kernels") ---------------------------------
     def status_words(self):
         """The 16 status words of the fp16x2 forward stream as an int32 view of self.wstream (device; no sync)."""
+        if self.wstream is None or not self._aliased():  # an engine that has not been flattened / packed yet: neutral telemetry
+            self.ensure_packed()
         if self._status is None or self._status.data_ptr() < self.wstream.data_ptr():
             word = ctypes.cast(self.lib.r2l_forward_status_words(_ptr(self.wstream), self.n_block), ctypes.c_void_p).value
             off = (word - self.wstream.data_ptr()) // 4

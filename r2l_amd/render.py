@@ -157,9 +157,12 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
 # ---------------------------------------------------------------------------------------------------------------
 # raw2outputs / sample_pdf
 # ---------------------------------------------------------------------------------------------------------------
-def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None, **_ignored):
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None, need_weights=True,
+                **_ignored):
     """(rgb_map[R,3], disp_map[R], acc_map[R], weights[R,S], depth_map[R])   (create_data.py:335-402).
-    `noise` [R,S] (already scaled) replaces the internal draw of the reference when given (tests: same draw on both sides)."""
+    `noise` [R,S] (already scaled) replaces the internal draw of the reference when given (tests: same draw on both sides).
+    need_weights=False (GPU path): the [R,S] weights are not written to HBM and None is returned in their place — the fine
+    pass of render_rays never reads them (4 S of the 24 S + 36 bytes per ray the kernel moves)."""
     if noise is not None:
         noise = noise.to(raw.device).float().contiguous()
     elif raw_noise_std > 0.:
@@ -187,7 +190,7 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
     R, S = z_vals.shape
     f = dict(dtype=torch.float32, device=raw.device)
     rgb_map, disp, acc = torch.empty(R, 3, **f), torch.empty(R, **f), torch.empty(R, **f)
-    weights, depth = torch.empty(R, S, **f), torch.empty(R, **f)
+    weights, depth = (torch.empty(R, S, **f) if need_weights else None), torch.empty(R, **f)
     _lib.check(
         lib.r2l_raw2outputs(_ptr(raw.contiguous()), _ptr(z_vals.contiguous()), _ptr(rays_d.contiguous()), _ptr(noise),
                             int(bool(white_bkgd)), _ptr(rgb_map), _ptr(disp), _ptr(acc), _ptr(weights), _ptr(depth), R,
@@ -318,7 +321,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                                                    u=u)
         raw = query(z_vals, network_fn if network_fine is None else network_fine)
         rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd,
-                                                                     pytest=pytest)
+                                                                     pytest=pytest, need_weights=False)
     ret = {"rgb_map": rgb_map, "disp_map": disp_map, "acc_map": acc_map, "depth_map": depth_map}
     if retraw:
         ret["raw"] = raw

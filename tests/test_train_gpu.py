@@ -470,6 +470,51 @@ def test_fp16_range_control_in_training(chain_variant, calibrate):
             assert info["grad_scale"] > 2.0 ** 20, info  # a-priori rule x 2^17 for the 1e-5 tail
 
 
+def test_dx_chain_only_trip_expands_the_fp16_stash(chain_variant):
+    """a step whose FORWARD stays on the fp16 kernels (calibrated: the stream sits at s = 32 for this net) while its
+    dX CHAIN leaves fp16's range — default-size head, activations AND gradients growing ~4e4-fold through the body, so the
+    a-priori gradient scale of the first step puts chain values at ~4e5 (a CPU model of it: u of block 0).  The bf16x3 chain and
+    weight-gradient kernels behind the fp16 ones then meet an fp16 stage-piece stash of x / s: the fallback pack expands it in
+    place to the chunked fp32 layout they read (csrc/r2l_bwd3.hip; round 4 read the pieces as fp32 and applied garbage body
+    dW silently).  Every gradient of that step matches the oracle; the NEXT step re-centres the gradient scale on the tripped
+    step's amax (r2l_bwd_prepare_kernel) and runs on the fp16 chains again — no step after the first falls back."""
+    from model.nerf_raybased import PointSampler
+    from r2l_amd.train_step import R2LTrainer
+    from tests.test_forward_gpu import _body_amplified_net
+    sd = _body_amplified_net()
+    m = build_model(sd, 6)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    gen = torch.Generator().manual_seed(21)
+    n = 600
+    o = torch.randn(n, 3, generator=gen) * 1.5
+    d = torch.randn(n, 3, generator=gen)
+    tgt = torch.rand(n, 3, generator=gen)
+    emb = O.positional_embed(O.sample_train(o, d, O.z_vals(16, 2., 6.), 0.), 10)
+    loss, rgb_ref, gref = O.r2l_loss_and_grads(sd, emb, tgt)
+    tr = R2LTrainer(m, ps)  # calibrate = True: forward-only launches settle the activation scale before the first step
+    fp16 = chain_variant in ("main", "coopf", "coopf2", "main-exact", "coopf-exact")
+    fwd_trips = None
+    for it in range(3):
+        rgb = tr.forward_backward(o.cuda(), d.cuda(), tgt.cuda())
+        assert (rgb.cpu() - rgb_ref).abs().max().item() < 1e-4
+        grads = split_flat(tr.grads.cpu(), sd)
+        for k in sd:
+            assert torch.isfinite(grads[k]).all(), (it, k)
+            # (an amplifying net: the ReLU masks of near-zero pre-activations move the gradients of everything below them;
+            # garbage operands would be O(1))
+            assert rel_err(grads[k], gref[k]) < 1e-2, (it, k, rel_err(grads[k], gref[k]))
+        flat, ref = tr.grads.cpu(), torch.cat([gref[k].reshape(-1) for k in sd])
+        assert torch.nn.functional.cosine_similarity(flat, ref, dim=0).item() > 0.9999, it
+        info = tr.range_info()
+        if fp16:
+            if fwd_trips is None:
+                fwd_trips = info["trips"]
+            assert info["scale"] >= 16 and info["trips"] == fwd_trips, (it, info)  # no FORWARD of a step fell back
+            assert info["bwd_trips"] == 1, (it, info)  # the first step's chain, and only that one
+            if it > 0:
+                assert 2.0 ** 4 <= info["grad_amax"] * info["grad_scale"] <= 2.0 ** 10, (it, info)
+
+
 def test_gradient_scale_follows_the_gradients(chain_variant):
     """The power of two the fp16 dX chain runs on is chosen on the device, step to step, from the last clean step's largest
     chain value (r2l_bwd_prepare_kernel): kept while that lies in [2^-2, 2^13] scaled (so default nets run bit for bit on the
