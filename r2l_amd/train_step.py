@@ -34,13 +34,15 @@ class R2LTrainer:
     """
 
     def __init__(self, module, point_sampler, betas=(0.9, 0.999), eps=1e-8, lw_rgb=1.0, process_group=None, dw_mode=None,
-                 chain_segments=None):
+                 chain_segments=None, engine=None):
         """dw_mode: None (keep the engine's config: default 'auto' = fp16 weight-gradient operands unless R2L_DW_EXACT=1),
         'fp16' or 'exact' (weight-gradient GEMMs of the fp16 trio on hi + mid operands: fp32-grade dW, ~2x the stash
         traffic; README.md "Training modes")."""
         self.module = module
         self.ps = point_sampler
-        self.eng = get_engine(module)
+        # (engine: tests of the HOST logic at world sizes no box offers hand in a stand-in, tests/test_driver_cpu.py; the product
+        # always takes the module's HIP engine — every launch below goes through the four _launch hooks of this class)
+        self.eng = engine if engine is not None else get_engine(module)
         if dw_mode is not None:
             self.eng.set_config(dw_mode=dw_mode)
         self.lib = self.eng.lib
@@ -128,6 +130,25 @@ class R2LTrainer:
                                                          _stream()), "r2l_pack_backward_layout")
             self._bwd_packed[layout] = ver
 
+    # ---- the launches of a step (everything else in this class is host logic) --------------------------------------------------
+    def _stream(self):
+        return _stream()
+
+    def _launch_backward(self, args, parts, layer_lo, layer_hi, what="r2l_backward_part"):
+        """One call of the staged backward (include/r2l_hip.h r2l_backward_part_cfg) on the step's argument tuple."""
+        _lib.check(self.lib.r2l_backward_part_cfg(*args, parts, layer_lo, layer_hi, self.eng._cfg()), what)
+
+    def _launch_loss_finish(self, n):
+        _lib.check(self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
+                                            _ptr(self.loss_out), self._stream()), "r2l_loss_finish")
+
+    def _launch_adam(self, lr):
+        eng = self.eng
+        _lib.check(
+            self.lib.r2l_adam_step_guarded(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                           eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                           self.reducer.grad_scale(), _ptr(self._guard), self._stream()), "r2l_adam_step")
+
     # ---- one optimisation step --------------------------------------------------------------------------------------
     def forward_backward(self, rays_o, rays_d, target, perturb=0., t_rand=None, zero_grad=True, n_global=None):
         """Forward + backward on this rank's rays; leaves d(loss)/d(params) in self.grads. Returns rgb [N,3].
@@ -164,7 +185,8 @@ class R2LTrainer:
         args = (_ptr(rays_o), _ptr(rays_d), _ptr(t_rand), _ptr(ztab), None, _ptr(rgb), _ptr(target), None,
                 _ptr(self.save_x), _ptr(self.save_t), _ptr(self.wstream_bwd), _ptr(eng.flat), eng.n_block, grad_scale,
                 _ptr(self.dpre), _ptr(self.gx), _ptr(self.gt), _ptr(self.sqerr), _ptr(self.grads), _ptr(self.dw_slab), n,
-                _stream())
+                self._stream())
+        self._step_inputs = (rays_o, rays_d, target, t_rand, grad_scale)  # (what the launch hooks of this step work on)
         self._guard = None
         self._check_skipped()
         if (self.chain_segments > 1 and zero_grad and not self.segments_disabled and
@@ -173,19 +195,16 @@ class R2LTrainer:
         elif (self.world() > 1 or self.force_staged) and self.n_buckets > 0 and zero_grad:
             # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
             # blocks to the first, the head last; every finished range of the flat gradient goes to the collective at once
-            part, cfg = self.lib.r2l_backward_part_cfg, eng._cfg()
-            _lib.check(part(*args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0, cfg), "r2l_backward_part(chain, tail)")
+            self._launch_backward(args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0, "r2l_backward_part(chain, tail)")
             for lo, hi, flat_lo, flat_hi in bucket_plan(eng.n_block, self.n_buckets):
                 if flat_lo == 0:
-                    _lib.check(part(*args, _lib.BWD_HEAD, 0, 0, cfg), "r2l_backward_part(head)")
+                    self._launch_backward(args, _lib.BWD_HEAD, 0, 0, "r2l_backward_part(head)")
                 elif hi > lo:  # (a net without body blocks has one empty body bucket: only its tail range to exchange)
-                    _lib.check(part(*args, _lib.BWD_BODY, lo, hi, cfg), "r2l_backward_part(%d, %d)" % (lo, hi))
+                    self._launch_backward(args, _lib.BWD_BODY, lo, hi, "r2l_backward_part(%d, %d)" % (lo, hi))
                 self.reducer.submit(self.grads[flat_lo:flat_hi])
         else:
-            _lib.check(self.lib.r2l_backward_part_cfg(*args, _lib.BWD_ALL, 0, 2 * eng.n_block, eng._cfg()), "r2l_backward")
-        _lib.check(
-            self.lib.r2l_loss_finish(_ptr(self.sqerr), int(self.lib.r2l_num_tiles(n)), self.lw_rgb / (3.0 * n),
-                                     _ptr(self.loss_out), _stream()), "r2l_loss_finish")
+            self._launch_backward(args, _lib.BWD_ALL, 0, 2 * eng.n_block, "r2l_backward")
+        self._launch_loss_finish(n)
         return rgb
 
     # ---- range control ------------------------------------------------------------------------------------------------------
@@ -310,10 +329,7 @@ class R2LTrainer:
     def adam(self, lr):
         self.step_count += 1
         eng = self.eng
-        _lib.check(
-            self.lib.r2l_adam_step_guarded(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                           eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
-                                           self.reducer.grad_scale(), _ptr(self._guard), _stream()), "r2l_adam_step")
+        self._launch_adam(lr)
         if self._guard is not None:  # segmented step: its validity word goes to the host behind the update (checked next step)
             slot = self._status_slot
             self._status_slot = (slot + 1) % STATUS_LAG

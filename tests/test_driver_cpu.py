@@ -213,6 +213,178 @@ def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+WORKER8 = r"""
+import ctypes, os, sys, types
+sys.path.insert(0, %(root)r)
+os.environ["R2L_NO_DW_SLAB"] = "1"  # (134 MB of weight-gradient partials per rank: nothing here launches a kernel)
+import torch
+import torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+torch.set_num_threads(1)
+from oracle import r2l_oracle as O            # test infrastructure: stands in for the HIP kernels below
+from r2l_amd import _lib
+from r2l_amd.train_step import R2LTrainer, lr_schedule
+from r2l_amd.dist_utils import split_shards, bucket_plan, parameters_in_sync, HEAD_FLOATS, LAYER_FLOATS, TAIL_FLOATS
+
+NB, RAYS_PER_SHARD, N_RAND = 4, 16, 20
+Z = O.z_vals(16, 2., 6.)
+
+
+class HostEngine:
+    # the attribute surface of r2l_amd.engine.R2LEngine that R2LTrainer's HOST code touches; forward = the oracle on CPU tensors
+    def __init__(self, sd):
+        self.lib = _lib.load()  # the real library: its host-side queries (sizes, layouts) need no GPU
+        self.keys = list(sd)
+        self.shapes = [tuple(sd[k].shape) for k in self.keys]
+        self.n_block = NB
+        self.flat = torch.cat([sd[k].reshape(-1) for k in self.keys]).clone()
+        self.n_param = self.flat.numel()
+        assert self.n_param == self.lib.r2l_param_count(NB) == HEAD_FLOATS + 2 * NB * LAYER_FLOATS + TAIL_FLOATS
+        self.device = torch.device("cpu")
+        self.cfg = _lib.Config()
+        self.dirty = 0
+
+    def sd(self):
+        out, off = {}, 0
+        for k, shp in zip(self.keys, self.shapes):
+            n = 1
+            for q in shp:
+                n *= q
+            out[k] = self.flat[off:off + n].view(shp)
+            off += n
+        return out
+
+    def set_config(self, **kw):
+        for k, v in kw.items():
+            setattr(self.cfg, k, int(v))
+
+    def effective_config(self):
+        return self.cfg
+
+    def _cfg(self):
+        return ctypes.byref(self.cfg)
+
+    def ensure_packed(self, n=None, with_stash=True):
+        pass
+
+    def mark_dirty(self):
+        self.dirty += 1
+
+    def version(self):
+        return self.dirty
+
+    def layout_for(self, n, with_stash=True):
+        return 32
+
+    def range_info(self):
+        return {}
+
+    def ztab(self, z_vals, perturb):
+        return torch.zeros(32)
+
+    def forward_rays(self, o, d, z_vals, perturb=0., t_rand=None, save=None):
+        return O.r2l_forward(self.sd(), O.positional_embed(O.sample_train(o, d, Z, 0.), 10))
+
+
+class HostOnlyTrainer(R2LTrainer):
+    # R2LTrainer with its four launches replaced by the oracle: what runs here is the trainer's own host logic — replica sync,
+    # ray-share gradient weights, the staged backward's bucket order, submit / finish of the exchange, Adam's 1 / world
+    def _stream(self):
+        return None
+
+    def _pack_bwd(self, n):
+        pass
+
+    def _launch_backward(self, args, parts, lo, hi, what=""):
+        o, d, tgt, t_rand, grad_scale = self._step_inputs
+        n = o.shape[0]
+        if parts & _lib.BWD_CHAIN:
+            emb = O.positional_embed(O.sample_train(o, d, Z, 0.), 10)
+            loss, _, g = O.r2l_loss_and_grads(self.eng.sd(), emb, tgt)
+            # the oracle differentiates mean((rgb - t)^2) over the n rays; the kernels seed dL/drgb = grad_scale * (rgb - t)
+            self._g = torch.cat([g[k].reshape(-1) for k in self.eng.keys]) * (grad_scale / (2.0 / (3.0 * n)))
+            self._loss = loss
+            self.order = []
+        total = self.grads.numel()
+        if parts & _lib.BWD_TAIL:
+            self.grads[total - TAIL_FLOATS:] = self._g[total - TAIL_FLOATS:]
+            self.order.append("tail")
+        if parts & _lib.BWD_BODY:
+            a, b = HEAD_FLOATS + lo * LAYER_FLOATS, HEAD_FLOATS + hi * LAYER_FLOATS
+            self.grads[a:b] = self._g[a:b]
+            self.order.append((lo, hi))
+        if parts & _lib.BWD_HEAD:
+            self.grads[:HEAD_FLOATS] = self._g[:HEAD_FLOATS]
+            self.order.append("head")
+
+    def _launch_loss_finish(self, n):
+        self.loss_out[0] = self._loss
+
+    def _launch_adam(self, lr):
+        p, m, v = O.adam_step(self.eng.flat, self.grads * self.reducer.grad_scale(), self.exp_avg, self.exp_avg_sq,
+                              self.step_count, lr)
+        self.eng.flat.copy_(p); self.exp_avg.copy_(m); self.exp_avg_sq.copy_(v)
+
+
+# --N_rand 20 over 8 ranks: the README command's shape (reference main.py:802-805: shard files per step)
+shares = split_shards(N_RAND, world)
+assert shares == [3, 3, 3, 3, 2, 2, 2, 2]
+first = sum(shares[:rank])
+eng = HostEngine(O.make_state_dict(n_block=NB, seed=100 + rank))  # every rank starts from its OWN random weights ...
+tr = HostOnlyTrainer(None, types.SimpleNamespace(z_vals=Z), engine=eng)
+assert parameters_in_sync(eng.flat)                              # ... and continues with rank 0's (replica sync)
+ref_sd = {k: v.clone() for k, v in O.make_state_dict(n_block=NB, seed=100).items()}
+assert torch.equal(eng.flat, torch.cat([ref_sd[k].reshape(-1) for k in eng.keys]))
+assert tr.world() == 8 and tr.n_buckets == 4 and eng.cfg.reserve_cus == 8  # CUs left to the collective beside the dW kernels
+m = {k: torch.zeros_like(v) for k, v in ref_sd.items()}
+v2 = {k: torch.zeros_like(v) for k, v in ref_sd.items()}
+for it in range(1, 4):
+    g = torch.Generator().manual_seed(1000 + it)  # the step's 20 shard files, the same on every rank
+    o = torch.randn(N_RAND * RAYS_PER_SHARD, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])
+    d = torch.nn.functional.normalize(torch.randn(N_RAND * RAYS_PER_SHARD, 3, generator=g), dim=-1)
+    tgt = torch.rand(N_RAND * RAYS_PER_SHARD, 3, generator=g)
+    sl = slice(first * RAYS_PER_SHARD, (first + shares[rank]) * RAYS_PER_SHARD)
+    lr = lr_schedule(it, 5e-4, 500, "0.0001,200")
+    tr.step(o[sl], d[sl], tgt[sl], lr, perturb=0., n_global=[q * RAYS_PER_SHARD for q in shares])
+    # the staged backward completed and handed over its ranges in backward order: tail + last block first, the head last
+    assert tr.order == ["tail", (6, 8), (4, 6), (2, 4), (0, 2), "head"], tr.order
+    assert tr.reducer.pending() == 0
+    # single-process oracle on the FULL batch: one global mean (main.py:1377), one Adam
+    emb = O.positional_embed(O.sample_train(o, d, Z, 0.), 10)
+    _, _, gr = O.r2l_loss_and_grads(ref_sd, emb, tgt)
+    for k in ref_sd:
+        ref_sd[k], m[k], v2[k] = O.adam_step(ref_sd[k], gr[k], m[k], v2[k], it, lr)
+    # the all-reduced, share-weighted gradient IS the global mean's gradient
+    flat_ref = torch.cat([gr[k].reshape(-1) for k in eng.keys])
+    gerr = (tr.grads * tr.reducer.grad_scale() - flat_ref).abs().max().item() / flat_ref.abs().max().item()
+    assert gerr < 2e-6, (it, gerr)
+assert parameters_in_sync(eng.flat)
+err = (eng.flat - torch.cat([ref_sd[k].reshape(-1) for k in eng.keys])).abs().max().item()
+assert err < 2e-6, err
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok8", err)
+"""
+
+
+def test_eight_rank_gloo_trainer_host_logic(tmp_path):
+    """World = 8 without a node: EIGHT gloo processes run the real R2LTrainer — its host logic: replica sync from
+    rank 0, --N_rand 20 as 3/3/3/3/2/2/2/2 shard files with ray-share gradient weights, the staged backward's four body buckets +
+    head handed to the collective in backward order, one exchange per step, Adam with 1 / world — with the four kernel launches
+    of a step replaced by the CPU oracle (a test-side subclass: the product has no CPU path), on a 4-block net; three Adam steps
+    end within 2e-6 of the single-process oracle trained on the full batch (reference: main.py:472-479, 1371-1406)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29619", str(script)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok8") == 8
+
+
 def test_bench_launch_plan_spawns_or_refuses():
     """`python bench.py --gpus N`: bare with N > 1 -> becomes the launcher of N ranks; fewer visible GPUs than asked for,
     or a WORLD_SIZE that contradicts --gpus -> non-zero exit instead of a mislabelled single-GPU number."""

@@ -1,0 +1,115 @@
+"""World = 8 without an 8-GPU node: the real CLI under torchrun with EIGHT ranks sharing this one GPU over gloo
+(RCCL refuses a device twice) — the README's shape of BASELINE configs[3] / [4]: `--N_rand 20` over 8 ranks = 3/3/3/3/2/2/2/2
+shard files per rank and step (reference: main.py:472-479, 802-805), pseudo-data poses i % 8 with rank-disjoint index ranges
+(utils/create_data.py:297-299), test frames / video poses sharded over 8 ranks.  Not a measurement of anything: a walk of the
+host logic and the real kernels at the rank count the scaling run uses.  The CPU twin (no GPU, oracle gradients through the real
+R2LTrainer host code) is tests/test_driver_cpu.py::test_eight_rank_gloo_trainer_host_logic."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import r2l_oracle as O
+from tests.test_driver_cpu import ROOT, make_scene
+from tests.test_forward_gpu import build_model  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+WORLD = 8
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
+    env.update(MASTER_ADDR="127.0.0.1", R2L_DIST_BACKEND="gloo")
+    return env
+
+
+def _torchrun(port, script, args, tmp_path, env=None, timeout=1500):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(WORLD), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, script)] + args
+    r = subprocess.run(cmd, env=env or _env(), cwd=str(tmp_path), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    return r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def scene_and_teacher(tmp_path_factory):
+    root = tmp_path_factory.mktemp("w8")
+    scene = str(root / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=128)  # half_res -> 64x64 = 4096 rays per pose = one shard per pose
+    csd, fsd = O.make_teacher_state_dicts(5, 2, alpha_bias=0.5)
+    torch.save({"network_fn_state_dict": csd, "network_fine_state_dict": fsd}, str(root / "teacher.tar"))
+    return root, scene
+
+
+def test_create_data_then_train_eight_ranks(scene_and_teacher):
+    """configs[4] then configs[3] at world = 8: 21 poses over 8 ranks (shares 3/3/3/3/3/2/2/2 — poses i % 8, every rank's shards
+    inside its own index range, none overwritten), then 6 training iterations with --N_rand 20: 3/3/3/3/2/2/2/2 shard files per
+    rank and step, gradients weighted by ray share, per-rank hard-ray pools, the staged backward with 4 buckets in flight; the
+    replicas end bit-identical and rank 0 writes the checkpoint."""
+    from r2l_amd.checkpoint import load_ckpt
+    from r2l_amd.create_data import shard_index_base
+    root, scene = scene_and_teacher
+    kd = str(root / "pseudo8")
+    n_pose, chunk = 21, 2
+    args = ["--create_data", "rand", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene, "--teacher_ckpt",
+            str(root / "teacher.tar"), "--create_data_chunk", str(chunk), "--datadir_kd", scene + ":" + kd, "--experiment_name",
+            "cd8", "--n_pose_kd", str(n_pose)]
+    _torchrun(29651, os.path.join("utils", "create_data.py"), args, root)
+    fpf = (chunk * 64 * 64) // 4096
+    want = []
+    for rank in range(WORLD):
+        mine = [i for i in range(1, n_pose + 1) if i % WORLD == rank]
+        base = shard_index_base(rank, WORLD, n_pose, chunk, fpf)
+        want += list(range(base, base + len(mine)))  # one 4096-ray shard per 64x64 pose
+    idx = sorted(int(f[5:-4]) for f in os.listdir(kd))
+    assert idx == sorted(want) and len(idx) == n_pose, (idx, sorted(want))
+    for i in idx:
+        a = np.load(os.path.join(kd, "data_%d.npy" % i))
+        assert a.shape == (4096, 9) and np.isfinite(a).all()
+    env = _env()
+    env["R2L_CHECK_SYNC"] = "1"
+    out = _torchrun(29653, "main.py",
+                    ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene,
+                     "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "6", "--use_residual", "--trial.ON",
+                     "--trial.body_arch", "resmlp", "--testskip", "1", "--datadir_kd", kd, "--data_mode", "rays", "--N_rand", "20",
+                     "--hard_ratio", "0.2", "--hard_mul", "2", "--warmup_lr", "0.0001,200", "--i_print", "2", "--i_testset", "100",
+                     "--i_weights", "6", "--N_iters", "6", "--experiment_name", "dp8"], root, env=env)
+    assert "[3, 3, 3, 3, 2, 2, 2, 2] shard files per rank and step" in out, out[-3000:]
+    assert "replicas in sync after 6 iterations: True (skipped steps: 0)" in out, out[-3000:]
+    ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs if f == "ckpt.tar" and "dp8" in dp]
+    assert len(ckpts) == 1 and load_ckpt(ckpts[0])["global_step"] == 6
+
+
+def test_cli_render_eight_ranks(scene_and_teacher):
+    """`main.py --render_only` over 8 ranks: the test views (metrics all-reduced) and the 5-pose video (three ranks hold no pose
+    at all; frames gathered to rank 0 and re-interleaved) come out as from one process."""
+    from r2l_amd import driver
+    from r2l_amd.checkpoint import save_ckpt
+    root, scene = scene_and_teacher
+    sd = O.make_state_dict(n_block=2, seed=1)
+    ckpt = str(root / "SERVER-20260101-000000_iter7" / "weights" / "ckpt.tar")
+    save_ckpt(ckpt, 7, build_model(sd, 2).cpu(), {"state": {}, "param_groups": []}, 0., 0)
+    common = ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene,
+              "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "6", "--use_residual", "--trial.ON",
+              "--trial.body_arch", "resmlp", "--testskip", "1", "--pretrained_ckpt", ckpt, "--render_only", "--n_pose_video", "5"]
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        one_test = driver.main(common + ["--render_test", "--experiment_name", "one_test8"])
+        driver.main(common + ["--experiment_name", "one_video8"])
+    finally:
+        os.chdir(cwd)
+    out = _torchrun(29655, "main.py", common + ["--render_test", "--experiment_name", "eight_test"], root)
+    want = "[TEST] TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" % (one_test["misc"]["test_psnr"].item(),
+                                                                  one_test["misc"]["test_psnr_v2"].item(),
+                                                                  one_test["misc"]["test_ssim"].item())
+    assert want in out, (want, [l for l in out.splitlines() if "[TEST]" in l])
+    _torchrun(29657, "main.py", common + ["--experiment_name", "eight_video"], root)
+    avis = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs if f.endswith(".avi"))
+    assert len(avis) == 2, avis  # one from the single process, one from rank 0 of the eight
+    a, b = (open(f, "rb").read() for f in avis)
+    assert a == b and len(a) > 1000  # the same five frames in the same order
