@@ -32,7 +32,7 @@ enum { R2L_PRECISION_AUTO = 0,
        R2L_PRECISION_FP32_MFMA = 3   /* v_mfma_f32_32x32x2_f32 everywhere                                                  */ };
 enum { R2L_TILING_AUTO = 0,
        R2L_TILING_WAVE_PER_TILE = 1, /* one wavefront owns a 32-ray tile ("main")                                          */
-       R2L_TILING_COOP = 2,          /* fp32-MFMA cooperative kernels, 32-ray tile per workgroup                           */
+       R2L_TILING_COOP_RETIRED = 2,  /* (rounds 1 - 4: fp32-MFMA cooperative kernels, 32-ray tiles; retired: hipErrorInvalidValue) */
        R2L_TILING_COOP16 = 3,        /* fp32-MFMA cooperative kernels, 16-ray tile per workgroup                           */
        R2L_TILING_COOPF = 4          /* fp16x2 cooperative kernels (r2l_coopf_*), coop_tiles ray tiles per workgroup       */ };
 enum { R2L_DW_AUTO = 0,
@@ -64,12 +64,13 @@ int64_t r2l_bwd_stream_floats(int n_block);  /* size of the packed transposed (d
 /* Re-pack params into the MFMA A-operand weight streams the chain kernels read (call after every weight update). */
 int r2l_pack_forward(const float* params, int n_block, float* wstream, void* stream);
 int r2l_pack_backward(const float* params, int n_block, float* wstream_bwd, void* stream);
-/* Per-layout form: layout = 32 (fp32-MFMA one-wave-per-tile and 32-ray cooperative kernels), 16 (16-ray cooperative
+/* Per-layout form: layout = 32 (fp32-MFMA one-wave-per-tile kernels), 16 (16-ray cooperative
  * kernels), 3 (bf16 (hi, mid, lo) stages: r2l_fwd3.hip / r2l_bwd3.hip), 2 (fp16 (hi, mid) stages: r2l_fwd2.hip /
  * r2l_bwd2.hip and their cooperative forms r2l_coopf_*.hip; the bf16 stream behind them is their range-guard fallback and
  * is packed by the fallback launch itself when — and only when — it runs) or 0 (all parts, = r2l_pack_forward/backward).
  * r2l_variant_for(N) tells which chain variant a call with N rays will take (0 main — incl. the cooperative fp16x2 kernels
- * of small launches —, 1 coop: layout 32; 2 coop16: layout 16), honouring R2L_FORCE_VARIANT (main | coopf | coop | coop16). */
+ * of small launches —, 2 coop16: layout 16; 1 named the retired 32-ray cooperative family), honouring R2L_FORCE_VARIANT
+ * (main | coopf | coop16). */
 int r2l_variant_for(int64_t N);
 /* Within the fp16 trio (layout 2): 0 = the one-wave-per-tile chains serve a launch of N rays, 1 / 2 = the cooperative chains
  * with that many 32-ray tiles per workgroup (<= 16 384 rays, and 32 769 .. 49 152 rays: csrc/r2l_common.h r2l_use_coopf;
@@ -143,6 +144,11 @@ const unsigned* r2l_backward_status_words(const float* wstream_bwd, int n_block)
  * that still run their own sampler/embedder. */
 int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,
                     float* save_x, float* save_t, int64_t N, void* stream);
+/* ... with a config: precision = bf16x3 (fp16x2 is served by the same kernels: this path has no range-guard fallback) runs a
+ * forward-only launch (save_x == save_t == NULL) as head on the fp32 MFMA -> X_0 in x0_scratch (r2l_padded_rows(N) * 256 floats,
+ * caller-owned) -> body + tail on the bf16x3 chain; every other case is r2l_forward_emb (x0_scratch may then be NULL). */
+int r2l_forward_emb_cfg(const float* emb, const float* wstream, const float* params, int n_block, float* rgb, float* save_x,
+                        float* save_t, int64_t N, float* x0_scratch, void* stream, const r2l_config* cfg);
 
 /* ---- student backward + optimizer ------------------------------------------------------------------------------
  * Replaces loss.backward() of main.py:1377-1404 for the R2L branch (autograd over the ops above, anomaly mode on in the
@@ -231,6 +237,15 @@ int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int r2l_adam_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                           float beta1, float beta2, float eps, int step, float grad_scale, const unsigned* skip_if,
                           void* stream);
+/* The same update (bit for bit) with the re-pack of the fp16x2 weight streams folded in: what r2l_adam_step_guarded followed by
+ * r2l_pack_forward_layout(.., 2, ..) and r2l_pack_backward_layout(.., 2, ..) leave behind — the optimizer kernel writes the body
+ * weights' (hi, mid) stage pieces of both streams itself, a second small kernel packs the head / bias stages for the activation
+ * scale and commits it (range control) — in two launches instead of four.  wstream_fwd / wstream_bwd: the buffers of
+ * r2l_fwd_stream_floats / r2l_bwd_stream_floats; only their fp16x2 parts are written (the other layouts stay stale until packed).
+ * *skip_if != 0: nothing is touched.  The default trio's step (r2l_forward_layout_for_cfg == r2l_backward_layout_for_cfg == 2). */
+int r2l_adam_step_packed(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_block, float lr,
+                         float beta1, float beta2, float eps, int step, float grad_scale, const unsigned* skip_if,
+                         float* wstream_fwd, float* wstream_bwd, void* stream);
 
 /* out2[0] = inv_denom * sum(sqerr_partial) (= img2mse * lw_rgb, helpers:19), out2[1] = psnr (helpers:20). */
 int r2l_loss_finish(const float* sqerr_partial, int64_t n_partial, float inv_denom, float* out2, void* stream);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "r2l_forward_pose_cfg": (_i, [_p, _i, _i, _f, _p, _p, _p, _i, _p, _p, _cfgp]),
     "r2l_forward_poses_cfg": (_i, [_p, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p, _cfgp]),
     "r2l_forward_emb": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p]),
+    "r2l_forward_emb_cfg": (_i, [_p, _p, _p, _i, _p, _p, _p, _l, _p, _p, _cfgp]),
     "r2l_num_tiles": (_l, [_l]),
     "r2l_padded_rows": (_l, [_l]),
     "r2l_stash_slot_floats": (_l, [_l]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "r2l_allreduce_destroy": (_i, [_p]),
     "r2l_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p]),
     "r2l_adam_step_guarded": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p]),
+    "r2l_adam_step_packed": (_i, [_p, _p, _p, _p, _i, _f, _f, _f, _f, _i, _f, _p, _p, _p, _p]),
     "r2l_chain_segments_ok_cfg": (_i, [_l, _i, _cfgp]),
     "r2l_backward_status_word": (_p, [_p, _i]),
     "r2l_forward_status_words": (_p, [_p, _i]),

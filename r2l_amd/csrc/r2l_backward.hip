@@ -1305,10 +1305,6 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         const int rc = r2l_coop16_backward(rgb, target, drgb, save_x, save_t, wstream_bwd + r2l_bwd32_stream_floats(n_block),
                                            params, n_block, grad_scale, dpre, gx, gt, sqerr_partial, N, stream);
         if (rc) return rc;
-    } else if (variant == R2L_VARIANT_COOP) {
-        const int rc = r2l_coop_backward(rgb, target, drgb, save_x, save_t, wstream_bwd, params, n_block, grad_scale, dpre,
-                                         gx, gt, sqerr_partial, N, stream);
-        if (rc) return rc;
     } else if (split) {
         // one-wave-per-tile dX chain.  Default trio (MSE mode: scaled chain, values in fp16's range up to the guard): two-way fp16
         // splits, 3 fp16 products per fp32 product (r2l_bwd2.hip), stashing fp16 stage pieces for r2l_dw16.hip, with the
@@ -1412,7 +1408,16 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         R2LDwHeadArgs a{};
         a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab; a.emb = emb; a.gh = gx; a.grads = grads; a.N = N;
         int64_t slices = n_cu / 4;
-        if (slices > (N + 255) / 256) slices = (N + 255) / 256;  // small launches: >= 256 rays per slice (each slice costs a 1 MB partial)
+        // small launches: >= 128 rays per slice (each slice costs a 1 MB partial that r2l_head_reduce reads back; round 4 took >= 256
+        // rays: 16 slices = 64 workgroups for the 4096-ray step, a VALU-bound kernel on a quarter of the chip: 44 us + 7 us of
+        // reduce).  R2L_HEAD_SLICE_RAYS: tuning knob (tools/small_prof.sh)
+        static int64_t slice_rays = 0;
+        if (slice_rays == 0) {
+            const char* e = getenv("R2L_HEAD_SLICE_RAYS");
+            slice_rays = e ? atoll(e) : 128;
+            if (slice_rays < 32) slice_rays = 32;
+        }
+        if (slices > (N + slice_rays - 1) / slice_rays) slices = (N + slice_rays - 1) / slice_rays;
         if (slices < 1) slices = 1;
         int64_t per = (N + slices - 1) / slices;
         per = (per + 1) & ~(int64_t)1;  // even: a k-step pairs rays 2s, 2s+1
@@ -1454,7 +1459,9 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
     if (parts & R2L_BWD_TAIL) {
         int64_t wgs = 2 * n_cu;
         int64_t per = (N + wgs - 1) / wgs;
-        if (per < 1) per = 1;
+        // (>= 64 rays per workgroup: the 4096-ray step ran 512 workgroups of 8 rays, and r2l_tail_reduce then walks 512 partials per
+        // thread — 11 us of dependent loads for 3 KiB of gradient)
+        if (per < 64) per = 64;
         wgs = (N + per - 1) / per;
         // partials behind the head's slab region; summed in workgroup order
         float* part = (dw_slab != nullptr && DW_HEAD_SLAB_MAX + wgs * (4 * R2L_W) <= r2l_dw_slab_floats())

@@ -36,21 +36,18 @@ __host__ __device__ static inline int64_t b3_off_tail_w(int n_block) { return b3
 // workgroup to finish flips the format word to 1, so that a second backward over the same stash goes straight to the bf16x3 kernels.
 __device__ __forceinline__ void b3_expand_h16_slot(float* __restrict__ base, int64_t n_tiles, float act_scale) {
     const int t = (int)threadIdx.x;
-    const u32x4* in = reinterpret_cast<const u32x4*>(base);
+    typedef _Float16 b3_f16x8 __attribute__((ext_vector_type(8)));
+    const b3_f16x8* in = reinterpret_cast<const b3_f16x8*>(base);
     for (int64_t T = n_tiles - 1; T >= 0; --T) {
         f32x4 o[4][2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u32x4 v = in[T * 1024 + t + 256 * j];  // (R2L_H16_TILE_UNITS of r2l_f2.h: 1024 16-byte units per tile)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                typedef _Float16 b3_h2 __attribute__((ext_vector_type(2)));
-                const b3_h2 p = __builtin_bit_cast(b3_h2, v[w]);
-                o[j][w >> 1][2 * (w & 1)] = (float)p[0] * act_scale;
-                o[j][w >> 1][2 * (w & 1) + 1] = (float)p[1] * act_scale;
-            }
+            const b3_f16x8 v = in[T * 1024 + t + 256 * j];  // (R2L_H16_TILE_UNITS of r2l_f2.h: 1024 16-byte units per tile)
+            o[j][0] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]} * act_scale;
+            o[j][1] = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]} * act_scale;
         }
-        __syncthreads();  // (fence + barrier: every lane's loads of this tile have landed before any lane overwrites them — T = 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's loads of the tile have landed ...
+        __syncthreads();  // ... every lane's, before any lane overwrites them (T = 0: the output covers the tile's own pieces)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int u = t + 256 * j, kb = u >> 6, lane = u & 63, i = lane & 31, h = lane >> 5;

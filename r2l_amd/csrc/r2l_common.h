@@ -352,13 +352,6 @@ __device__ __forceinline__ void r2l_sincos_double(float s, float c, float& s2, f
     c2 = __builtin_fmaf(-t, s, 1.0f);
 }
 
-// ---- small-batch cooperative variants (r2l_coop.hip) ---------------------------------------------------------------------
-int r2l_coop_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
-                     const float* c2w_host12, int H, int W, float focal, const float* wstream, const float* params,
-                     int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream);
-int r2l_coop_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
-                      const float* wstream_bwd, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
-                      float* gt, float* sqerr_partial, int64_t N, hipStream_t stream);
 // ---- 16-ray cooperative variants (r2l_coop16.hip): their own packed streams, appended to the 32-layout ones ------------
 // group16 = [16 tiles of 16 output features][64 lanes][float4]: lane (i = l%16, kk = l/16) component e holds
 // W[16*tile + i][16*G + 4*kk + e] — the A operand of v_mfma_f32_16x16x4_f32 number e of k-group G.
@@ -470,6 +463,7 @@ static inline const char* r2l_cfg_check(const r2l_config* c) {
     if (c == nullptr) return nullptr;
     if (c->precision < 0 || c->precision > R2L_PRECISION_FP32_MFMA) return "r2l_config.precision: not an R2L_PRECISION_* value";
     if (c->tiling < 0 || c->tiling > R2L_TILING_COOPF) return "r2l_config.tiling: not an R2L_TILING_* value";
+    if (c->tiling == R2L_TILING_COOP_RETIRED) return "r2l_config.tiling: 2 (the 32-ray fp32-MFMA cooperative kernels) was retired in round 5 — R2L_TILING_COOP16 serves those launches";
     if (c->coop_tiles < 0 || c->coop_tiles > 2) return "r2l_config.coop_tiles: 0 (auto), 1 or 2";
     if (c->reserve_cus < -1) return "r2l_config.reserve_cus: -1 (none), 0 (auto) or a CU count";
     if (c->dw_mode < 0 || c->dw_mode > R2L_DW_EXACT) return "r2l_config.dw_mode: not an R2L_DW_* value";
@@ -526,7 +520,7 @@ int r2l_fwd2_fallback_pack(const float* params, int n_block, float* wstream3, fl
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,
                      int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream,
-                     const unsigned* run_if = nullptr);
+                     const unsigned* run_if = nullptr, const float* x0_in = nullptr);  // x0_in: body + tail from a given X_0
 
 // Which chain variant is fastest for N rays.  In units of one main-kernel round (1024 wave slots x 32 rays): main needs
 // ceil(N/32768) rounds; coop (4 waves share a 32-ray tile, 256 workgroups) ceil(N/8192) rounds of ~0.34 (measured: fwd
@@ -536,7 +530,7 @@ int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_ra
 #ifndef R2L_C16_ROUND
 #define R2L_C16_ROUND 0.174
 #endif
-enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP = 1, R2L_VARIANT_COOP16 = 2 };
+enum { R2L_VARIANT_MAIN = 0, R2L_VARIANT_COOP16 = 2 };  // (1: the 32-ray fp32-MFMA cooperative family, retired in round 5)
 // Cooperative fp16x2 kernels (r2l_coopf.h: one 32-ray tile per WORKGROUP): a sub-family of the MAIN variant — same streams,
 // stash and fallbacks as r2l_fwd2 / r2l_bwd2, taken instead of them for launches of at most R2L_COOPF_MAX_RAYS rays, and
 // for launches between one and one and a half ROUNDS of the one-wave-per-tile kernels (a round = 256 CUs x 128 rays): the
@@ -565,7 +559,7 @@ static inline int r2l_forced_tiling() {
     if (!e || !e[0]) return R2L_TILING_AUTO;
     if (e[0] == 'm') return R2L_TILING_WAVE_PER_TILE;
     if (e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return R2L_TILING_COOPF;
-    if (e[0] == 'c') return (e[1] && e[2] && e[3] && e[4] == '1') ? R2L_TILING_COOP16 : R2L_TILING_COOP;
+    if (e[0] == 'c') return R2L_TILING_COOP16;  // (coop16; "coop" named the retired 32-ray family: its launches are coop16's now)
     return R2L_TILING_WAVE_PER_TILE;  // (anything else used to mean "not the cooperative fp16 kernels")
 }
 static inline bool r2l_use_coopf(int64_t N, int n_block) {
@@ -579,16 +573,15 @@ static inline int r2l_chain_variant(int64_t N) {
     const int t = r2l_forced_tiling();
     if (t == R2L_TILING_WAVE_PER_TILE || t == R2L_TILING_COOPF) return R2L_VARIANT_MAIN;  // coopf: kernels of the MAIN family
     if (t == R2L_TILING_COOP16) return R2L_VARIANT_COOP16;
-    if (t == R2L_TILING_COOP) return R2L_VARIANT_COOP;
     if (r2l_fp16_trio_env() && N <= R2L_COOPF_MAX_RAYS) return R2L_VARIANT_MAIN;  // served by the cooperative fp16x2 kernels
     // (one main round on the fp16x2 kernels costs 0.30 of a round of the fp32-MFMA kernel the unit was defined on; measured,
     // tools/variant_sweep.py: 98 304-ray-style steps of 6144 rays 1.99 ms on the one-wave-per-tile kernels vs 2.11 ms on the
     // 16-ray cooperative ones, 20 480 rays 2.9 vs 5.9 ms; 4096 rays 1.94 vs 1.34 ms)
+    // (round 5: the 32-ray fp32-MFMA cooperative family — 0.34 per round of 8192 rays — is retired: AUTO reached it only under a
+    // pinned fp32_mfma precision, in the bands where it beat two 16-ray rounds by 2 %: profiles/r05_dispatch_table.md)
     const double main_t = (double)((N + 32767) / 32768) * (r2l_use_fwd3() ? 0.30 : 1.0);
-    const double coop_t = (double)((N + 8191) / 8192) * 0.34;
     const double c16_t = (double)((N + 4095) / 4096) * R2L_C16_ROUND;
-    if (c16_t < coop_t && c16_t < main_t) return R2L_VARIANT_COOP16;
-    return coop_t < main_t ? R2L_VARIANT_COOP : R2L_VARIANT_MAIN;
+    return c16_t < main_t ? R2L_VARIANT_COOP16 : R2L_VARIANT_MAIN;
 }
 
 // The one-wave-per-tile training trios keep their stash (save_x[0..n-1], save_t, gx[1..n], gt) in a private layout: fp16

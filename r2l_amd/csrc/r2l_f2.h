@@ -169,56 +169,72 @@ __host__ __device__ static inline int64_t f2_off_body_b(int layer) { return f2_o
 __host__ __device__ static inline int64_t f2_off_tail_w(int n_block) { return f2_off_body_w(2 * n_block); }
 __host__ __device__ static inline int64_t f2_off_tail_b(int n_block) { return f2_off_tail_w(n_block) + 3 * R2L_W; }
 __device__ __forceinline__ unsigned short f2_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+// one element (stage g, index `within` = ((tile * 64) + lane) * 8 + s of its 4096) of the stream
+__device__ __forceinline__ void f2_pack_fwd_element(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                                    float inv_s, int64_t stages, int64_t g, int within) {
+    const int s = within & 7, lane = (within >> 3) & 63, tile = (within >> 9) & 7;
+    const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
+    unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
+    unsigned short v0 = 0, v1 = 0;
+    if (g < stages) {
+        bool bias_stage = false;
+        float w = 0.f;
+        if (g == 0) {
+            bias_stage = true;
+            w = params[f2_off_head_b() + o];
+        } else if (g < 64) {
+            const int v = 8 * (int)(g - 1) + s;
+            int col;
+            if (v < 480) {
+                const int ci = v / 20, within20 = v % 20, f = within20 >> 1;
+                col = 21 * (3 * (8 * h + ci / 3) + ci % 3) + ((within20 & 1) ? 10 + f : f);
+            } else {
+                const int e = v - 480;
+                col = 21 * (3 * (8 * h + e / 3) + e % 3) + 20;
+            }
+            w = params[(int64_t)o * R2L_IN + col];
+        } else {
+            const int layer = (int)((g - 64) / 17), r17 = (int)((g - 64) % 17);
+            if (r17 == 0) {
+                bias_stage = true;
+                w = params[f2_off_body_b(layer) + o] * inv_s;
+            } else {
+                const int kb = r17 - 1, T = kb >> 1, r = kb & 1;
+                const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
+                w = params[f2_off_body_w(layer) + (int64_t)o * R2L_W + in];
+            }
+        }
+        const _Float16 hi = (_Float16)w;
+        const _Float16 mid = (_Float16)(w - (float)hi);
+        if (bias_stage) {
+            v0 = (h == 0) ? (s == 0 ? f2_bits(hi) : (s == 1 ? f2_bits(mid) : (unsigned short)0)) : (unsigned short)0;
+        } else {
+            v0 = f2_bits(hi); v1 = f2_bits(mid);
+        }
+    }
+    st[within] = v0;
+    st[8 * 64 * 8 + within] = v1;
+}
 __device__ __forceinline__ void f2_pack_fwd_elements(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
                                                      float inv_s, bool only_scaled, int64_t first, int64_t stride) {
     const int64_t stages = r2l_fwd3_stages(n_block);
     const int64_t total = (stages + R2L_F3_PAD_STAGES) * 8 * 64 * 8;
     for (int64_t idx = first; idx < total; idx += stride) {
-        const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), tile = (int)((idx >> 9) & 7);
         const int64_t g = idx >> 12;
         if (only_scaled && !(g >= 64 && g < stages && (g - 64) % 17 == 0)) continue;
-        const int i = lane & 31, h = lane >> 5, o = 32 * tile + i;
-        unsigned short* st = out + g * (F2_STAGE_BYTES / 2);
-        unsigned short v0 = 0, v1 = 0;
-        if (g < stages) {
-            bool bias_stage = false;
-            float w = 0.f;
-            if (g == 0) {
-                bias_stage = true;
-                w = params[f2_off_head_b() + o];
-            } else if (g < 64) {
-                const int v = 8 * (int)(g - 1) + s;
-                int col;
-                if (v < 480) {
-                    const int ci = v / 20, within = v % 20, f = within >> 1;
-                    col = 21 * (3 * (8 * h + ci / 3) + ci % 3) + ((within & 1) ? 10 + f : f);
-                } else {
-                    const int e = v - 480;
-                    col = 21 * (3 * (8 * h + e / 3) + e % 3) + 20;
-                }
-                w = params[(int64_t)o * R2L_IN + col];
-            } else {
-                const int layer = (int)((g - 64) / 17), r17 = (int)((g - 64) % 17);
-                if (r17 == 0) {
-                    bias_stage = true;
-                    w = params[f2_off_body_b(layer) + o] * inv_s;
-                } else {
-                    const int kb = r17 - 1, T = kb >> 1, r = kb & 1;
-                    const int in = 32 * T + 8 * (2 * r + (s >> 2)) + 4 * h + (s & 3);
-                    w = params[f2_off_body_w(layer) + (int64_t)o * R2L_W + in];
-                }
-            }
-            const _Float16 hi = (_Float16)w;
-            const _Float16 mid = (_Float16)(w - (float)hi);
-            if (bias_stage) {
-                v0 = (h == 0) ? (s == 0 ? f2_bits(hi) : (s == 1 ? f2_bits(mid) : (unsigned short)0)) : (unsigned short)0;
-            } else {
-                v0 = f2_bits(hi); v1 = f2_bits(mid);
-            }
-        }
-        const int64_t e = ((int64_t)tile * 64 + lane) * 8 + s;
-        st[e] = v0;
-        st[8 * 64 * 8 + e] = v1;
+        f2_pack_fwd_element(params, out, n_block, inv_s, stages, g, (int)(idx & 4095));
+    }
+}
+// the stages that hold no body WEIGHT: the head's 64 and the 2 n_block body bias stages (r2l_adam_step_packed: the body weight
+// stages were written by the optimizer kernel itself)
+__device__ __forceinline__ void f2_pack_fwd_nonbody(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
+                                                    float inv_s, int64_t first, int64_t stride) {
+    const int64_t stages = r2l_fwd3_stages(n_block);
+    const int64_t total = (int64_t)(64 + 2 * n_block) * 4096;
+    for (int64_t idx = first; idx < total; idx += stride) {
+        const int64_t sel = idx >> 12;
+        const int64_t g = sel < 64 ? sel : 64 + 17 * (sel - 64);
+        f2_pack_fwd_element(params, out, n_block, inv_s, stages, g, (int)(idx & 4095));
     }
 }
 

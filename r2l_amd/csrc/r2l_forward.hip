@@ -274,9 +274,6 @@ extern "C" int r2l_forward_rays_cfg(const float* rays_o, const float* rays_d, co
     if (variant == R2L_VARIANT_COOP16)
         return r2l_coop16_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream + r2l_fwd32_stream_floats(n_block),
                                   params, n_block, rgb, save_x, save_t, N, (hipStream_t)stream);
-    if (variant == R2L_VARIANT_COOP)
-        return r2l_coop_forward(rays_o, rays_d, t_rand, ztab, nullptr, 0, 0, 0.f, wstream, params, n_block, rgb, save_x,
-                                save_t, N, (hipStream_t)stream);
     // (with the training stash: only as part of the default fp16 trio, whose stash format it writes)
     if (N > 0 && (save_x != nullptr ? r2l_use_trio16() : r2l_use_fwd2())) {
         const float* w3 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
@@ -349,9 +346,6 @@ static int forward_pose_impl(const float* c2w_host12, int64_t n_frames, int H, i
         return r2l_coop16_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal,
                                   wstream + r2l_fwd32_stream_floats(n_block), params, n_block, rgb, nullptr, nullptr, a.N,
                                   (hipStream_t)stream);
-    if (variant == R2L_VARIANT_COOP)
-        return r2l_coop_forward(nullptr, nullptr, nullptr, ztab, c2w_host12, H, W, focal, wstream, params, n_block, rgb,
-                                nullptr, nullptr, a.N, (hipStream_t)stream);
     if (a.N > 0 && r2l_use_fwd2()) {
         const float* w3 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block);
         const float* w2 = w3 + r2l_fwd3_stream_floats(n_block);
@@ -376,6 +370,32 @@ extern "C" const unsigned* r2l_forward_status_words(const float* wstream, int n_
     if (wstream == nullptr || n_block < 0 || n_block > R2L_MAX_BLOCKS) return nullptr;
     const float* w2 = wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block) + r2l_fwd3_stream_floats(n_block);
     return reinterpret_cast<const unsigned*>(w2 + r2l_fwd2_status_offset(n_block));
+}
+
+// The module-boundary path with a config (round 5).  precision = bf16x3 (or fp16x2: this path has no range-guard
+// fallback, so the request is served by the bf16x3 chain), forward-only (no stash), x0_scratch given: the HEAD runs on the fp32-MFMA
+// kernel (its B operand is the caller's encoding, read from HBM — the 16-bit chains take their B operands from registers and
+// keep vmcnt for their weight DMA) as a zero-block launch that leaves X_0 = relu(head) row-major in x0_scratch, and the 86 body
+// layers + tail run on r2l_fwd3_kernel<X0> (six bf16 products per fp32 product: fp32-grade, 1.7x the fp32-MFMA rate).  Anything
+// else — AUTO / fp32_mfma, or a launch with the training stash (the backward of this path reads a row-major fp32 stash) — is
+// r2l_forward_emb.
+extern "C" int r2l_forward_emb_cfg(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,
+                                   float* save_x, float* save_t, int64_t N, float* x0_scratch, void* stream,
+                                   const r2l_config* cfg) {
+    R2L_CFG_ENTER(cfg);
+    const bool chain16 = g_r2l_cfg.precision == R2L_PRECISION_BF16X3 || g_r2l_cfg.precision == R2L_PRECISION_FP16X2;
+    if (!chain16 || save_x != nullptr || save_t != nullptr || x0_scratch == nullptr || n_block <= 0 || N <= 0)
+        return r2l_forward_emb(emb, wstream, params, n_block, rgb, save_x, save_t, N, stream);
+    R2L_REQUIRE(n_block <= R2L_MAX_BLOCKS, "r2l_forward_emb_cfg: n_block out of range");
+    R2L_REQUIRE(emb && wstream && params && rgb, "r2l_forward_emb_cfg: a required pointer is NULL");
+    R2LFwdArgs a{};
+    a.emb = emb; a.wstream = wstream; a.params = params; a.n_block = 0;  // head only: X_0 -> x0_scratch (rgb: overwritten below)
+    a.rgb = rgb; a.save_x = x0_scratch; a.save_t = nullptr; a.N = N;
+    const int rc = launch_fwd<MODE_EMB>(a, (hipStream_t)stream);
+    if (rc) return rc;
+    return r2l_fwd3_forward(nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f,
+                            wstream + r2l_fwd32_stream_floats(n_block) + r2l_fwd16_stream_floats(n_block), params, n_block, rgb,
+                            nullptr, nullptr, N, (hipStream_t)stream, nullptr, x0_scratch);
 }
 
 extern "C" int r2l_forward_emb(const float* emb, const float* wstream, const float* params, int n_block, float* rgb,

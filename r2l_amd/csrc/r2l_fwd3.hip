@@ -136,9 +136,13 @@ struct F3Args {
     float* save_x;  // training: [(n_block+1)][Np][256] X_0 .. X_n and [n_block][Np][256] relu(hidden) (r2l_forward.hip), or
     float* save_t;  //           nullptr
     int64_t N;
+    const float* x0_in;  // X0 instantiation: [Np][256] row-major X_0 = relu(head) from an earlier launch (r2l_forward_emb_cfg)
 };
 
-template <bool POSE, bool SAVE>
+// X0 (round 5, the module-boundary path on the bf16x3 chain): the head is NOT part of this launch — X_0 comes row-major from
+// memory (the fp32-MFMA kernel computed it from the caller's [N,1008] encoding, r2l_forward.hip) and `stream` points at the
+// FIRST BODY stage (64 stages into the packed stream): that stage is a bias stage like stage 0, so the staging prologue is the same.
+template <bool POSE, bool SAVE, bool X0 = false>
 __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char wbuf[F3_NBUF][F3_STAGE_BYTES];
 
@@ -155,8 +159,9 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     const int64_t rc = valid ? ray : a.N - 1;
 
     // ---- rays -----------------------------------------------------------------------------------------------------------
-    float o[3], d[3];
-    if constexpr (!POSE) {
+    float o[3], d[3];  // (X0: unused — the head is not part of the launch)
+    if constexpr (X0) {
+    } else if constexpr (!POSE) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             o[k] = a.rays_o[rc * 3 + k];
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
         }
     }
     float z[8];  // the 8 sample depths of this half-wave (samples 8h .. 8h+7)
-    {
+    if constexpr (!X0) {
         const f32x4 lo0 = *reinterpret_cast<const f32x4*>(a.ztab + 8 * h);
         const f32x4 lo1 = *reinterpret_cast<const f32x4*>(a.ztab + 8 * h + 4);
 #pragma unroll
@@ -223,58 +228,74 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd3_kernel(const F3Args a) {
     }
     P.sb = P.ones;
 
-    // ---- head ---------------------------------------------------------------------------------------------------------
-    // per coordinate pair (xa, xb) five k-blocks: [xa f0-3] [xa f4-7] [xa f8,9 | xb f0,1] [xb f2-5] [xb f6-9]
-    auto zsel = [&](int s) {
-        float zz = z[0];
+    if constexpr (X0) {
+        // X_0 from memory: lane (ray j, half h) holds features 32 T + 8 q + 4 h .. + 3 of its ray in fragment registers 4 q .. 4 q + 3
+        const float* xr = a.x0_in + ray * R2L_W + 4 * h;  // (rows of the padding rays of the last tile exist: Np rows)
 #pragma unroll
-        for (int k = 1; k < 8; ++k) zz = (s == k) ? z[k] : zz;
-        return zz;
-    };
-    float xc[6];
-    {
-        const float za = z[0], zb = z[1];
+        for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
-        for (int ci = 0; ci < 6; ++ci) xc[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
-    }
-    f3_stage<true, true, false>(x, P, F3Trig2{xc[0], 0}, F3Trig2{xc[0], 2});
-#pragma unroll 1
-    for (int it2 = 0; it2 < 4; ++it2) {  // two samples = six coordinates = three pairs = 15 k-blocks per trip
-        // coordinates of the NEXT trip (the last stage of this trip prepares the first B triple of the next one)
-        float xn[6];
-        {
-            const float za = zsel(2 * it2 + 2), zb = zsel(2 * it2 + 3);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 32 * T + 8 * q);
 #pragma unroll
-            for (int ci = 0; ci < 6; ++ci) xn[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const float xa = xc[2 * p], xb = xc[2 * p + 1];
-            f3_stage<false, false, false>(x, P, F3Trig2{xa, 4}, F3Trig2{xa, 6});
-            f3_stage<false, false, false>(x, P, F3Trig2{xa, 8}, F3Trig2{xb, 0});
-            f3_stage<false, false, false>(x, P, F3Trig2{xb, 2}, F3Trig2{xb, 4});
-            f3_stage<false, false, false>(x, P, F3Trig2{xb, 6}, F3Trig2{xb, 8});
-            if (p < 2) {
-                f3_stage<false, false, false>(x, P, F3Trig2{xc[2 * p + 2], 0}, F3Trig2{xc[2 * p + 2], 2});
-            } else {
-                f3_stage<false, false, false>(x, P, F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 0}, F3Ident4{o, d, z, 0}},
-                                              F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 2}, F3Ident4{o, d, z, 4}});
+                for (int e = 0; e < 4; ++e) {
+                    x[T][4 * q + e] = v[e];
+                    x0[T][4 * q + e] = v[e];
+                }
             }
+    } else {
+        // ---- head ---------------------------------------------------------------------------------------------------------
+        // per coordinate pair (xa, xb) five k-blocks: [xa f0-3] [xa f4-7] [xa f8,9 | xb f0,1] [xb f2-5] [xb f6-9]
+        auto zsel = [&](int s) {
+            float zz = z[0];
+    #pragma unroll
+            for (int k = 1; k < 8; ++k) zz = (s == k) ? z[k] : zz;
+            return zz;
+        };
+        float xc[6];
+        {
+            const float za = z[0], zb = z[1];
+    #pragma unroll
+            for (int ci = 0; ci < 6; ++ci) xc[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
         }
-#pragma unroll
-        for (int ci = 0; ci < 6; ++ci) xc[ci] = xn[ci];
+        f3_stage<true, true, false>(x, P, F3Trig2{xc[0], 0}, F3Trig2{xc[0], 2});
+    #pragma unroll 1
+        for (int it2 = 0; it2 < 4; ++it2) {  // two samples = six coordinates = three pairs = 15 k-blocks per trip
+            // coordinates of the NEXT trip (the last stage of this trip prepares the first B triple of the next one)
+            float xn[6];
+            {
+                const float za = zsel(2 * it2 + 2), zb = zsel(2 * it2 + 3);
+    #pragma unroll
+                for (int ci = 0; ci < 6; ++ci) xn[ci] = o[ci % 3] + d[ci % 3] * (ci / 3 == 0 ? za : zb);
+            }
+    #pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float xa = xc[2 * p], xb = xc[2 * p + 1];
+                f3_stage<false, false, false>(x, P, F3Trig2{xa, 4}, F3Trig2{xa, 6});
+                f3_stage<false, false, false>(x, P, F3Trig2{xa, 8}, F3Trig2{xb, 0});
+                f3_stage<false, false, false>(x, P, F3Trig2{xb, 2}, F3Trig2{xb, 4});
+                f3_stage<false, false, false>(x, P, F3Trig2{xb, 6}, F3Trig2{xb, 8});
+                if (p < 2) {
+                    f3_stage<false, false, false>(x, P, F3Trig2{xc[2 * p + 2], 0}, F3Trig2{xc[2 * p + 2], 2});
+                } else {
+                    f3_stage<false, false, false>(x, P, F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 0}, F3Ident4{o, d, z, 0}},
+                                                  F3TrigOrIdent{it2 == 3, F3Trig2{xn[0], 2}, F3Ident4{o, d, z, 4}});
+                }
+            }
+    #pragma unroll
+            for (int ci = 0; ci < 6; ++ci) xc[ci] = xn[ci];
+        }
+        // identity features: coordinates 8j .. 8j+7 of the half
+        f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 8}, F3Ident4{o, d, z, 12});
+        f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 16}, F3Ident4{o, d, z, 20});
+        f3_stage<false, false, true>(x, P, F3None{}, F3None{});
+    #pragma unroll
+        for (int T = 0; T < R2L_NT; ++T)
+    #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                x[T][c] = fmaxf(x[T][c], 0.f);  // X_0 = relu(head)
+                x0[T][c] = x[T][c];
+            }
     }
-    // identity features: coordinates 8j .. 8j+7 of the half
-    f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 8}, F3Ident4{o, d, z, 12});
-    f3_stage<false, false, false>(x, P, F3Ident4{o, d, z, 16}, F3Ident4{o, d, z, 20});
-    f3_stage<false, false, true>(x, P, F3None{}, F3None{});
-#pragma unroll
-    for (int T = 0; T < R2L_NT; ++T)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            x[T][c] = fmaxf(x[T][c], 0.f);  // X_0 = relu(head)
-            x0[T][c] = x[T][c];
-        }
 
     // ---- body -----------------------------------------------------------------------------------------------------------
     // training (SAVE): the B values of every stage are the layer's input, so the stash (x_b for the first layer of a block,
@@ -375,7 +396,7 @@ int r2l_fwd2_fallback_pack(const float* params, int n_block, float* wstream3, fl
 int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                      const float* c2w_host12, int H, int W, float focal, const float* wstream3, const float* params,
                      int n_block, float* rgb, float* save_x, float* save_t, int64_t N, hipStream_t stream,
-                     const unsigned* run_if) {
+                     const unsigned* run_if, const float* x0_in) {
     F3Args a{};
     a.run_if = run_if;
     a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab;
@@ -385,7 +406,11 @@ int r2l_fwd3_forward(const float* rays_o, const float* rays_d, const float* t_ra
     a.c2w_dev = c2w_host12 ? g_r2l_c2w_dev : nullptr;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-    if (c2w_host12) hipLaunchKernelGGL((r2l_fwd3_kernel<true, false>), grid, block, 0, stream, a);
+    if (x0_in != nullptr) {  // body + tail from a given X_0: the stream starts at the first body stage
+        a.x0_in = x0_in;
+        a.stream += (size_t)64 * F3_STAGE_BYTES;
+        hipLaunchKernelGGL((r2l_fwd3_kernel<false, false, true>), grid, block, 0, stream, a);
+    } else if (c2w_host12) hipLaunchKernelGGL((r2l_fwd3_kernel<true, false>), grid, block, 0, stream, a);
     else if (save_x) hipLaunchKernelGGL((r2l_fwd3_kernel<false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((r2l_fwd3_kernel<false, false>), grid, block, 0, stream, a);
     R2L_CHECK(hipGetLastError());

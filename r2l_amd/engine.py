@@ -285,9 +285,15 @@ class R2LEngine:
         n = emb.shape[0]
         rgb = torch.empty(n, 3, dtype=torch.float32, device=self.device)
         sx, st = (save if save is not None else (None, None))
+        # forward-only launches follow the engine's precision: bf16x3 (fp16x2 alike) = head on the fp32 MFMA, body + tail on the
+        # bf16x3 chain from X_0 in a scratch buffer (include/r2l_hip.h r2l_forward_emb_cfg); with the stash, or AUTO / fp32_mfma:
+        # the exact-fp32 kernel throughout (its backward reads a row-major fp32 stash)
+        x0 = None
+        if save is None and n > 0 and self.effective_config().precision in (_lib.PRECISION["bf16x3"], _lib.PRECISION["fp16x2"]):
+            x0 = torch.empty(int(self.lib.r2l_padded_rows(n)) * W, dtype=torch.float32, device=self.device)
         _lib.check(
-            self.lib.r2l_forward_emb(_ptr(emb), _ptr(self.wstream), _ptr(self.flat), self.n_block, _ptr(rgb), _ptr(sx),
-                                     _ptr(st), n, _stream()), "r2l_forward_emb")
+            self.lib.r2l_forward_emb_cfg(_ptr(emb), _ptr(self.wstream), _ptr(self.flat), self.n_block, _ptr(rgb), _ptr(sx),
+                                         _ptr(st), n, _ptr(x0), _stream(), self._cfg()), "r2l_forward_emb")
         return rgb
 
 

@@ -81,6 +81,7 @@ class R2LTrainer:
             self.eng.set_config(reserve_cus=int(os.environ.get("R2L_RESERVE_CUS", "8")))
         self.step_count = 0
         self.cap = 0
+        self._fused_repack = False
         self.dw_slab = None
         self._alloc_state()
 
@@ -144,6 +145,14 @@ class R2LTrainer:
 
     def _launch_adam(self, lr):
         eng = self.eng
+        if self._fused_repack:
+            # the default trio: Adam + the re-pack of both fp16x2 streams in two launches (include/r2l_hip.h r2l_adam_step_packed)
+            _lib.check(
+                self.lib.r2l_adam_step_packed(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                              eng.n_block, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                              self.reducer.grad_scale(), _ptr(self._guard), _ptr(eng.wstream),
+                                              _ptr(self.wstream_bwd), self._stream()), "r2l_adam_step_packed")
+            return
         _lib.check(
             self.lib.r2l_adam_step_guarded(_ptr(eng.flat), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                            eng.n_param, float(lr), self.betas[0], self.betas[1], self.eps, self.step_count,
@@ -164,6 +173,9 @@ class R2LTrainer:
         eng.ensure_packed(n)
         self._pack_bwd(n)
         self._ensure_capacity(n)
+        # steps of the default trio (both streams in the fp16x2 layout) get their re-pack from the optimizer kernel (adam())
+        self._fused_repack = (not os.environ.get("R2L_NO_ADAM_PACK") and eng.layout_for(n, True) == 2 and
+                              self.lib.r2l_backward_layout_for_cfg(int(n), eng._cfg()) == 2)
         rays_o = rays_o.contiguous().float()
         rays_d = rays_d.contiguous().float()
         target = target.contiguous().float()
@@ -329,6 +341,7 @@ class R2LTrainer:
     def adam(self, lr):
         self.step_count += 1
         eng = self.eng
+        fused = self._fused_repack
         self._launch_adam(lr)
         if self._guard is not None:  # segmented step: its validity word goes to the host behind the update (checked next step)
             slot = self._status_slot
@@ -339,6 +352,11 @@ class R2LTrainer:
             self._status_pending.append((ev, slot))
             self._guard = None
         eng.mark_dirty()
+        if fused and eng._packed_version is not None and self._bwd_packed is not None:
+            # the fp16x2 parts of both streams already hold the new weights: nothing to pack before the next launch of this layout
+            eff = eng.effective_config()
+            eng._packed_version[2] = eng.version()
+            self._bwd_packed[2] = (eng.version(), eff.precision, eff.tiling)
 
     def step(self, rays_o, rays_d, target, lr, perturb=0., t_rand=None, n_global=None):
         """zero_grad + forward + backward + all-reduce + Adam.  Returns (rgb[N,3], loss_out[2] = [loss, psnr]) on

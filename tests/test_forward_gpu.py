@@ -16,7 +16,6 @@ FAMILIES = {
     "coopf2": dict(tiling="coopf", coop_tiles=2),
     "main-bf16x3": dict(tiling="main", precision="bf16x3"),
     "main-f32mfma": dict(tiling="main", precision="fp32_mfma"),
-    "coop": dict(tiling="coop"),
     "coop16": dict(tiling="coop16"),
 }
 
@@ -26,7 +25,8 @@ def chain_variant(request, monkeypatch):
     """Every test runs under each forward kernel family, selected through r2l_config (tests/conftest.py use_family): one wave
     per tile on the fp16x2 matrix path (r2l_fwd2.hip, the default of forward-only launches), on the bf16x3 path (r2l_fwd3.hip)
     and on the fp32 MFMA (r2l_forward.hip), the cooperative fp16x2 kernels (r2l_coopf_fwd.hip: one tile per workgroup, the
-    default of small launches; coopf2: two) and the two cooperative fp32-MFMA small-batch families."""
+    default of small launches; coopf2: two) and the cooperative fp32-MFMA small-batch family (16-ray tiles; the 32-ray one was
+    retired in round 5: profiles/r05_dispatch_table.md)."""
     from tests.conftest import use_family
     use_family(monkeypatch, **FAMILIES[request.param])
     return request.param
@@ -67,19 +67,36 @@ def test_golden_w256d88_rays(golden_dir, model88):
     assert err < TOL
 
 
-def test_emb_path_matches_oracle(model88):
+def test_emb_path_matches_oracle(model88, chain_variant):
+    """`model(embedded)` — the reference's module-boundary idiom (model/nerf_raybased.py:539-544) — follows the engine's precision
+    (include/r2l_hip.h r2l_forward_emb_cfg, round 5): AUTO / fp32_mfma = the exact-fp32 kernel with the encoding as its B operand;
+    bf16x3 (fp16x2 alike: no range-guard fallback on this path) = head on the fp32 MFMA, the 86 body layers + tail on the bf16x3
+    chain from X_0.  Both within the parity bar of the oracle, bit-wise different from each other; ragged and one-tile sizes."""
+    if chain_variant != "main":
+        pytest.skip("configs set explicitly (one comparison)")
+    from r2l_amd.engine import get_engine
     sd, m = model88
+    eng = get_engine(m)
     torch.manual_seed(3)
-    o = torch.randn(1000, 3) * 2
-    d = torch.randn(1000, 3)
     z = O.z_vals(16, 2., 6.)
-    emb = O.positional_embed(O.sample_train(o, d, z, 0.), 10)
-    ref = O.r2l_forward(sd, emb)
-    with torch.no_grad():
-        out = m(emb.cuda())
-    err = (out.cpu() - ref).abs().max().item()
-    print("emb path max err", err)
-    assert err < TOL
+    for n in (1000, 31, 4097):
+        o = torch.randn(n, 3) * 2
+        d = torch.randn(n, 3)
+        emb = O.positional_embed(O.sample_train(o, d, z, 0.), 10)
+        ref = O.r2l_forward(sd, emb)
+        outs = {}
+        try:
+            for prec in ("auto", "fp32_mfma", "bf16x3", "fp16x2"):
+                eng.set_config(precision=prec, tiling="auto")
+                with torch.no_grad():
+                    outs[prec] = m(emb.cuda()).cpu()
+                err = (outs[prec] - ref).abs().max().item()
+                print("emb path, %d rays, precision %s: max err %.2e" % (n, prec, err))
+                assert err < TOL, (n, prec, err)
+        finally:
+            eng.set_config(precision="auto", tiling="auto")
+        assert torch.equal(outs["auto"], outs["fp32_mfma"]) and torch.equal(outs["bf16x3"], outs["fp16x2"])
+        assert not torch.equal(outs["bf16x3"], outs["fp32_mfma"])  # a different kernel did the body
 
 
 @pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 127, 4097])

@@ -60,12 +60,15 @@ def test_explicit_config_dispatch(monkeypatch):
     assert lib.r2l_coop_tiles_for_cfg(12288, 43, ref(_lib.make_config(coop_tiles=1))) == 1
     # explicit fields beat the environment; AUTO fields follow it; nothing sticks after the call
     monkeypatch.setenv("R2L_NO_FWD2", "1")
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "coop")
-    assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_variant_for(98304) == 1
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "coop16")
+    assert lib.r2l_forward_layout_for(98304, 1) == 16 and lib.r2l_variant_for(98304) == 2
     both = _lib.make_config(precision="fp16x2", tiling="main")
     assert lib.r2l_forward_layout_for_cfg(98304, 1, ref(both)) == 2 and lib.r2l_variant_for_cfg(98304, ref(both)) == 0
-    assert lib.r2l_variant_for_cfg(98304, ref(f16)) == 1  # tiling AUTO: the environment's coop
-    assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_variant_for(98304) == 1
+    assert lib.r2l_variant_for_cfg(98304, ref(f16)) == 2  # tiling AUTO: the environment's coop16
+    assert lib.r2l_forward_layout_for(98304, 1) == 16 and lib.r2l_variant_for(98304) == 2
+    # the 32-ray fp32-MFMA cooperative family (tiling value 2) was retired in round 5: the value stays reserved and is refused
+    assert lib.r2l_variant_for_cfg(4096, ref(_lib.make_config(tiling="coop"))) == -1
+    assert b"retired" in lib.r2l_last_error()
 
 
 def test_invalid_config_is_rejected():
@@ -187,8 +190,8 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     monkeypatch.setenv("R2L_NO_FWD3", "1")  # everything on the fp32 MFMA: the small-batch kernels win up to 20 480 rays again
     assert lib.r2l_forward_layout_for(98304, 1) == 32 and lib.r2l_backward_layout_for(98304) == 32
     assert lib.r2l_variant_for(20480) == 2 and lib.r2l_variant_for(24576) == 0
-    monkeypatch.setenv("R2L_FORCE_VARIANT", "coop")
-    assert lib.r2l_variant_for(98304) == 1 and lib.r2l_forward_layout_for(98304, 1) == 32
+    monkeypatch.setenv("R2L_FORCE_VARIANT", "coop16")
+    assert lib.r2l_variant_for(98304) == 2 and lib.r2l_forward_layout_for(98304, 1) == 16
     # buffer sizes: a stash slot holds 1 KiB + 32 B of mask words per (padded) ray; the streams hold every layout + status words
     assert lib.r2l_padded_rows(33) == 64 and lib.r2l_stash_slot_floats(33) == 64 * 264
     nb = 43

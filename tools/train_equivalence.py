@@ -7,7 +7,9 @@ create_data's poses).  Held-out PSNR every 250 iterations.  Trajectories of a ch
 rounding (the two fp32-exact families differ only in summation order), so their mutual distance is the yardstick for the
 fp16 trio's distance to either.  GPU box:  python tools/train_equivalence.py [iters=1500] [rays=16384]
 R2L_EQ_FAMILIES=0,3 keeps a subset of the families; R2L_EQ_PARITY=4096 also compares each TRAINED student's forward on that many
-held-out rays with the CPU restatement (fp32 torch ops)."""
+held-out rays with the CPU restatement (fp32 torch ops).  R2L_EQ_SEEDS=0,1,2,3 (round 5): the whole comparison
+once per seed — the seed moves the initial weights, the batches and the jitter; the held-out rays stay — and a table of
+mean +- sample standard deviation of the final held-out PSNR per family, with each family's distance to the fp32-MFMA mean."""
 import os
 import sys
 import time
@@ -63,8 +65,31 @@ def main(iters=1500, n=16384):
         keep = [int(v) for v in os.environ["R2L_EQ_FAMILIES"].split(",")]
         for k in [k for i, k in enumerate(list(FAMILIES)) if i not in keep]:
             del FAMILIES[k]
+    seeds = [int(v) for v in os.environ.get("R2L_EQ_SEEDS", "0").split(",")]
+    finals = {}
+    for seed in seeds:
+        if len(seeds) > 1:
+            print("\n=== seed %d ===" % seed, flush=True)
+        for name, psnr in run(iters, n, seed).items():
+            finals.setdefault(name, []).append(psnr)
+    if len(seeds) > 1:
+        import statistics
+        print("\n=== final held-out PSNR after %d steps of %d rays over seeds %s: mean +- sample std (min .. max) ===" % (iters, n, seeds))
+        ref = "fp32 MFMA" if "fp32 MFMA" in finals else list(finals)[-1]
+        mref = statistics.mean(finals[ref])
+        for name, v in finals.items():
+            sd_ = statistics.stdev(v)
+            print("  %-22s %.3f +- %.3f dB  (%.3f .. %.3f)   mean - mean(%s) = %+.3f dB = %+.2f of this family's seed std; per seed: %s"
+                  % (name, statistics.mean(v), sd_, min(v), max(v), ref, statistics.mean(v) - mref,
+                     (statistics.mean(v) - mref) / max(sd_, 1e-9), " ".join("%.3f" % q for q in v)))
+        pooled = statistics.mean([statistics.stdev(v) for v in finals.values()])
+        print("  mean seed std over the families: %.3f dB; standard error of a %d-seed mean: %.3f dB" % (pooled, len(seeds), pooled / len(seeds) ** 0.5))
+
+
+def run(iters, n, seed):
+    """One comparison of the families at one seed; returns {family: final held-out PSNR}."""
     ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
-    sd = O.make_state_dict(43, seed=0)
+    sd = O.make_state_dict(43, seed=seed)
     gen = torch.Generator(device="cuda").manual_seed(123)
     test_o, test_d = rays(65536, gen)
     test_rgb = scene(test_o, test_d)
@@ -76,8 +101,8 @@ def main(iters=1500, n=16384):
         m = build_model(sd, 43)
         tr = R2LTrainer(m, ps)
         ranges[name] = []
-        g = torch.Generator(device="cuda").manual_seed(7)       # batches
-        gj = torch.Generator(device="cuda").manual_seed(8)      # jitter
+        g = torch.Generator(device="cuda").manual_seed(7 + 1000 * seed)       # batches
+        gj = torch.Generator(device="cuda").manual_seed(8 + 1000 * seed)      # jitter
         curve = []
         torch.cuda.synchronize()
         t0 = time.time()
@@ -121,6 +146,7 @@ def main(iters=1500, n=16384):
     for name, rows in ranges.items():
         if rows and rows[-1][5]:
             print("  %-22s " % name + "  ".join("it %d: %.3g x%g (%d) | %.3g x%g (%d)" % r for r in rows))
+    return {k: v[-1][1] for k, v in curves.items()}
 
 
 if __name__ == "__main__":
