@@ -239,8 +239,10 @@ int r2l_adam_step_guarded(float* params, const float* grads, float* exp_avg, flo
                           void* stream);
 /* The same update (bit for bit) with the re-pack of the fp16x2 weight streams folded in: what r2l_adam_step_guarded followed by
  * r2l_pack_forward_layout(.., 2, ..) and r2l_pack_backward_layout(.., 2, ..) leave behind — the optimizer kernel writes the body
- * weights' (hi, mid) stage pieces of both streams itself, a second small kernel packs the head / bias stages for the activation
- * scale and commits it (range control) — in two launches instead of four.  wstream_fwd / wstream_bwd: the buffers of
+ * weights' (hi, mid) stage pieces of both streams itself and commits the activation scale (range control), a second small kernel
+ * packs the head / bias stages for it — two launches instead of four, 42 us of kernel time instead of 65.  (The trainer of this repo
+ * keeps the separate packs by default: packed a step early, the backward stream is cold when the dX chain reads it, which costs
+ * what the fusion saves; profiles/r05_small_step_ab.txt.)  wstream_fwd / wstream_bwd: the buffers of
  * r2l_fwd_stream_floats / r2l_bwd_stream_floats; only their fp16x2 parts are written (the other layouts stay stale until packed).
  * *skip_if != 0: nothing is touched.  The default trio's step (r2l_forward_layout_for_cfg == r2l_backward_layout_for_cfg == 2). */
 int r2l_adam_step_packed(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n_block, float lr,

@@ -1408,16 +1408,10 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         R2LDwHeadArgs a{};
         a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab; a.emb = emb; a.gh = gx; a.grads = grads; a.N = N;
         int64_t slices = n_cu / 4;
-        // small launches: >= 128 rays per slice (each slice costs a 1 MB partial that r2l_head_reduce reads back; round 4 took >= 256
-        // rays: 16 slices = 64 workgroups for the 4096-ray step, a VALU-bound kernel on a quarter of the chip: 44 us + 7 us of
-        // reduce).  R2L_HEAD_SLICE_RAYS: tuning knob (tools/small_prof.sh)
-        static int64_t slice_rays = 0;
-        if (slice_rays == 0) {
-            const char* e = getenv("R2L_HEAD_SLICE_RAYS");
-            slice_rays = e ? atoll(e) : 128;
-            if (slice_rays < 32) slice_rays = 32;
-        }
-        if (slices > (N + slice_rays - 1) / slice_rays) slices = (N + slice_rays - 1) / slice_rays;
+        // small launches: >= 256 rays per slice (each slice costs a 1 MB partial).  (Round 5 tried 128 and 64 rays per slice for the
+        // 4096-ray step — 32 / 64 slices instead of 16: 0.789 / 0.823 ms per step against 0.789, same box: what the wider grid gains
+        // the 1 MB-per-slice reduce gives back; profiles/r05_small_step_ab.txt)
+        if (slices > (N + 255) / 256) slices = (N + 255) / 256;
         if (slices < 1) slices = 1;
         int64_t per = (N + slices - 1) / slices;
         per = (per + 1) & ~(int64_t)1;  // even: a k-step pairs rays 2s, 2s+1
@@ -1459,9 +1453,7 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
     if (parts & R2L_BWD_TAIL) {
         int64_t wgs = 2 * n_cu;
         int64_t per = (N + wgs - 1) / wgs;
-        // (>= 64 rays per workgroup: the 4096-ray step ran 512 workgroups of 8 rays, and r2l_tail_reduce then walks 512 partials per
-        // thread — 11 us of dependent loads for 3 KiB of gradient)
-        if (per < 64) per = 64;
+        if (per < 1) per = 1;
         wgs = (N + per - 1) / per;
         // partials behind the head's slab region; summed in workgroup order
         float* part = (dw_slab != nullptr && DW_HEAD_SLAB_MAX + wgs * (4 * R2L_W) <= r2l_dw_slab_floats())

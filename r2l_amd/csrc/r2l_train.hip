@@ -44,11 +44,12 @@ __global__ void r2l_adam_kernel(float* __restrict__ p, const float* __restrict__
 // block b's W2^T stages 34 (n_block - 1 - b) + 1 + kb, W1^T stages + 18 + kb, kb = 2 To + r: element (tile Ti, lane (i, h), s) =
 // W[32 To + 16 r + 8 (s >> 2) + 4 h + (s & 3)][32 Ti + i]) as (hi, mid) fp16 halves, 8 bytes per thread and half: every piece
 // leaves as one contiguous KiB.  The remaining workgroups: every other parameter (head, biases, tail), plain update.
-#define AP_REST_WGS 128
+#define AP_REST_WGS 1024
 __global__ __launch_bounds__(256) void r2l_adam_pack_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                             float* __restrict__ v, int n_block, R2LAdamK k,
                                                             const unsigned* __restrict__ skip_if,
-                                                            unsigned short* __restrict__ out_f, unsigned short* __restrict__ out_b) {
+                                                            unsigned short* __restrict__ out_f, unsigned short* __restrict__ out_b,
+                                                            unsigned* status) {
     if (skip_if != nullptr && __builtin_nontemporal_load(skip_if) != 0u) return;
     __shared__ float tl[32][33];
     const int t = (int)threadIdx.x;
@@ -92,6 +93,10 @@ __global__ __launch_bounds__(256) void r2l_adam_pack_kernel(float* __restrict__ 
         *reinterpret_cast<ap_u16x4*>(sb + 8 * 64 * 8) = bm;
         return;
     }
+    // range control (r2l_f2.h): ONE thread of this launch closes the amax epoch and commits the activation scale the head / bias
+    // stages are packed for by the kernel behind this one (nothing in this launch reads the status words: a kernel boundary
+    // instead of the device-wide fence a "last workgroup commits" costs — measured: that fence made a 2400-workgroup pack 156 us)
+    if ((int)blockIdx.x == n_body && t == 0) f2_commit_scale(status, f2_next_scale(status), false);
     // everything that is not a body weight: [0, head) ++ the body biases ++ the tail
     const int64_t head = f2_off_body_w(0), n_bias = (int64_t)2 * n_block * R2L_W, tail = 3 * R2L_W + 3;
     const int64_t total = head + n_bias + tail;
@@ -105,18 +110,14 @@ __global__ __launch_bounds__(256) void r2l_adam_pack_kernel(float* __restrict__ 
         v[at] = vi;
     }
 }
-// behind it: the forward stream's head and bias stages for the activation scale the status words ask for (r2l_f2.h: range
-// control — the body's weight stages do not depend on it), the last workgroup to finish commits the scale (closes the amax epoch)
+// behind it: the forward stream's head and bias stages for the activation scale the optimizer kernel just committed (r2l_f2.h:
+// range control — the body's weight stages do not depend on it)
 __global__ void r2l_pack_fwd2_nonbody_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, int n_block,
-                                             unsigned* status, const unsigned* __restrict__ skip_if) {
+                                             const unsigned* __restrict__ status, const unsigned* __restrict__ skip_if) {
     if (skip_if != nullptr && __builtin_nontemporal_load(skip_if) != 0u) return;  // (parameters untouched: the stream stands)
-    const F2Next nx = f2_next_scale(status);
-    f2_pack_fwd_nonbody(params, out, n_block, nx.inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(status + F2S_DONE, 1u) == gridDim.x - 1u) f2_commit_scale(status, nx, false);
+    const float inv = status[F2S_MAGIC] == F2_MAGIC ? __builtin_bit_cast(float, status[F2S_INV]) : 1.0f;
+    f2_pack_fwd_nonbody(params, out, n_block, inv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
-
 extern "C" int r2l_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                              float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
     return r2l_adam_step_guarded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, nullptr, stream);
@@ -148,9 +149,10 @@ extern "C" int r2l_adam_step_packed(float* params, const float* grads, float* ex
     unsigned* status = reinterpret_cast<unsigned*>(w2f + r2l_fwd2_status_offset(n_block));
     hipLaunchKernelGGL(r2l_adam_pack_kernel, dim3((unsigned)(128 * n_block + AP_REST_WGS)), dim3(256), 0, (hipStream_t)stream, params,
                        grads, exp_avg, exp_avg_sq, n_block, k, skip_if, reinterpret_cast<unsigned short*>(w2f),
-                       reinterpret_cast<unsigned short*>(w2b));
+                       reinterpret_cast<unsigned short*>(w2b), status);
     R2L_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(r2l_pack_fwd2_nonbody_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, params,
+    // (one element per thread: the head's gather loads are latency-bound)
+    hipLaunchKernelGGL(r2l_pack_fwd2_nonbody_kernel, dim3((unsigned)((64 + 2 * n_block) * 16)), dim3(256), 0, (hipStream_t)stream, params,
                        reinterpret_cast<unsigned short*>(w2f), n_block, status, skip_if);
     R2L_CHECK(hipGetLastError());
     return 0;

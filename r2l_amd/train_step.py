@@ -173,8 +173,12 @@ class R2LTrainer:
         eng.ensure_packed(n)
         self._pack_bwd(n)
         self._ensure_capacity(n)
-        # steps of the default trio (both streams in the fp16x2 layout) get their re-pack from the optimizer kernel (adam())
-        self._fused_repack = (not os.environ.get("R2L_NO_ADAM_PACK") and eng.layout_for(n, True) == 2 and
+        # opt-in (R2L_ADAM_PACK=1): steps of the default trio (both streams in the fp16x2 layout) get their re-pack from the optimizer
+        # kernel (adam()).  Bit-identical and 23 us less kernel time per step (r2l_adam_pack_kernel 37 us against 60 for adam and
+        # the two pack kernels), but the dX chain then finds its stream cold — packed a whole step earlier instead of right in
+        # front of it: +15 us at 4096 rays, +33 us at 12 288 — so the step does not get faster: off by default
+        # (profiles/r05_small_step_ab.txt)
+        self._fused_repack = (bool(os.environ.get("R2L_ADAM_PACK")) and eng.layout_for(n, True) == 2 and
                               self.lib.r2l_backward_layout_for_cfg(int(n), eng._cfg()) == 2)
         rays_o = rays_o.contiguous().float()
         rays_d = rays_d.contiguous().float()

@@ -244,7 +244,7 @@ def test_distillation_converges_on_teacher_data(trained_student):
 VARIANTS = {"main-fp16x2": dict(tiling="main"), "coopf-fp16x2": dict(tiling="coopf"),
             "main-bf16x3": dict(tiling="main", precision="bf16x3"),
             "main-f32mfma": dict(tiling="main", precision="fp32_mfma"),
-            "coop": dict(tiling="coop"), "coop16": dict(tiling="coop16")}
+            "coop16": dict(tiling="coop16")}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))

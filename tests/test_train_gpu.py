@@ -158,13 +158,7 @@ def test_three_adam_steps_vs_oracle(chain_variant):
             a, b = (new[k].cpu() - sd[k]).flatten().double(), (ref[k] - sd[k]).flatten().double()
             assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.9998, k
         else:
-            # fp32-grade families: every entry within 2e-5 — except that an entry whose gradient CANCELS to within rounding takes
-            # its sign from the summation order, and Adam's first steps move it by ~lr either way (m / sqrt(v) = +-1 whatever
-            # |g|): one such entry is 2 lr = 1.9e-4 off (round 5: the 16-ray cooperative family met one in body.0.body.0.weight
-            # when the partial-sum shapes of the tail / head reductions changed — a different, equally valid fp32 sum).  So: at
-            # most two entries per tensor beyond 2e-5, none beyond what Adam can travel in three steps.
-            assert (diff > 2e-5).sum().item() <= 2, (k, (diff > 2e-5).sum().item())
-            assert diff.max().item() < 2 * travel, k
+            assert diff.max().item() < 2e-5, k
     # torch.optim.Adam-format state round trip
     osd = tr.optimizer_state_dict(lr)
     assert osd["state"][0]["exp_avg"].shape == sd["head.0.weight"].shape
@@ -476,7 +470,7 @@ def test_fp16_range_control_in_training(chain_variant, calibrate):
 
 
 def test_dx_chain_only_trip_expands_the_fp16_stash(chain_variant):
-    """a step whose FORWARD stays on the fp16 kernels (calibrated: the stream sits at s = 32 for this net) while its
+    """a step whose FORWARD stays on the fp16 kernels (calibrated: the stream sits at s = 8 for these 600 rays) while its
     dX CHAIN leaves fp16's range — default-size head, activations AND gradients growing ~4e4-fold through the body, so the
     a-priori gradient scale of the first step puts chain values at ~4e5 (a CPU model of it: u of block 0).  The bf16x3 chain and
     weight-gradient kernels behind the fp16 ones then meet an fp16 stage-piece stash of x / s: the fallback pack expands it in
@@ -514,14 +508,14 @@ def test_dx_chain_only_trip_expands_the_fp16_stash(chain_variant):
         if fp16:
             if fwd_trips is None:
                 fwd_trips = info["trips"]
-            assert info["scale"] >= 16 and info["trips"] == fwd_trips, (it, info)  # no FORWARD of a step fell back
+            assert info["scale"] >= 4 and info["trips"] == fwd_trips, (it, info)  # no FORWARD of a step fell back
             assert info["bwd_trips"] == 1, (it, info)  # the first step's chain, and only that one
             if it > 0:
                 assert 2.0 ** 4 <= info["grad_amax"] * info["grad_scale"] <= 2.0 ** 10, (it, info)
 
 
 def test_adam_packed_equals_adam_then_pack(chain_variant, monkeypatch):
-    """r2l_adam_step_packed (round 5: the optimizer kernel writes the body weights' stage pieces of both fp16x2 streams itself, a
+    """r2l_adam_step_packed (round 5, opt-in R2L_ADAM_PACK=1: the optimizer kernel writes the body weights' stage pieces of both fp16x2 streams itself, a
     small kernel packs head / bias stages and commits the activation scale) against the separate launches it replaces
     (r2l_adam_step_guarded, then r2l_pack_forward_layout / r2l_pack_backward_layout at the next step): three training steps,
     parameters, moments and BOTH packed streams bit for bit, and the renders that read them."""
@@ -539,9 +533,9 @@ def test_adam_packed_equals_adam_then_pack(chain_variant, monkeypatch):
     runs = []
     for fused in (True, False):
         if fused:
-            monkeypatch.delenv("R2L_NO_ADAM_PACK", raising=False)
+            monkeypatch.setenv("R2L_ADAM_PACK", "1")
         else:
-            monkeypatch.setenv("R2L_NO_ADAM_PACK", "1")
+            monkeypatch.delenv("R2L_ADAM_PACK", raising=False)
         m = build_model(sd, 5)
         tr = R2LTrainer(m, ps)
         for it in range(1, 4):
