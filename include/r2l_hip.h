@@ -161,9 +161,11 @@ int r2l_forward_emb_cfg(const float* emb, const float* wstream, const float* par
  * Head input: emb[N,1008] if given, else recomputed from (rays_o, rays_d, t_rand, ztab) exactly as the forward did.
  * save_x/save_t: the stash written by the forward of the same N (r2l_forward_rays, or r2l_forward_emb when emb is given).
  * Scratch owned by the caller: dpre[N,3], gx[(n_block+1) slots], gt[n_block slots] (slots of r2l_stash_slot_floats(N)
- * floats, like the stash), dw_slab[r2l_dw_slab_floats()] (per-workgroup partial body-layer
- * gradients, summed in a fixed order: bit-reproducible; NULL selects fp32 atomics instead, no scratch but run-to-run
- * rounding differences).  Gradients are ACCUMULATED into `grads` (flat, same layout as params): zero it first unless
+ * floats, like the stash), dw_slab[r2l_dw_slab_floats()] (204 MB: per-workgroup partial body-layer gradients, per-slice head
+ * partials and tail partials in disjoint regions, each summed in a fixed order: bit-reproducible; NULL selects fp32 atomics
+ * instead, no scratch but run-to-run rounding differences).  A call that computes body AND head gradients of a small launch
+ * (<= 16 384 rays) runs head + tail on a second stream of the library's own beside the body's, forked behind the dX chain and
+ * joined before the call returns: for the caller's stream nothing changes (R2L_NO_DW_OVERLAP=1 turns it off).  Gradients are ACCUMULATED into `grads` (flat, same layout as params): zero it first unless
  * accumulation is wanted. */
 int64_t r2l_num_tiles(int64_t N);
 int64_t r2l_padded_rows(int64_t N);

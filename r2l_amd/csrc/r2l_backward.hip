@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(64) void r2l_bwd_prepare_kernel(unsigned* status, c
 extern "C" int64_t r2l_num_tiles(int64_t N) { return (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS; }
 extern "C" int64_t r2l_padded_rows(int64_t N) { return R2L_PAD_ROWS(N); }
 // (+ 16 floats of status words behind the partials)
-extern "C" int64_t r2l_dw_slab_floats(void) { return (int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS + 16; }
+extern "C" int64_t r2l_dw_slab_floats(void) { return DW_TAIL_SLAB_BASE + DW_TAIL_SLAB + 16; }  // (r2l_dw.h: body | head | tail regions)
 extern "C" int64_t r2l_stash_slot_floats(int64_t N) { return R2L_TRIO_SLOT(R2L_PAD_ROWS(N)); }
 
 
@@ -1232,6 +1232,7 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
                                  grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, parts, layer_lo, layer_hi,
                                  nullptr);
 }
+static thread_local hipEvent_t g_r2l_join_ev = nullptr;  // (the join event of the call in flight: r2l_backward_part_cfg)
 extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                                      const float* emb, const float* rgb, const float* target, const float* drgb,
                                      const float* save_x, const float* save_t,
@@ -1352,6 +1353,35 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         hipLaunchKernelGGL(r2l_bwd_chain_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
         R2L_CHECK(hipGetLastError());
     }
+    // Small steps: the head / tail gradients BESIDE the body's (round 5).  At 4096 rays the body's weight-gradient kernel fills 172
+    // CUs for ~105 us and its reduce 19 us, then the head's (64 workgroups, VALU-bound: 54 us + 11 us of reduce) and the tail's
+    // (6 + 11 us) each run alone on a mostly idle chip.  They only share the dX chain's outputs as inputs and write disjoint ranges
+    // of the flat gradient and (since round 5) disjoint regions of dw_slab, so a call that does all of them puts head + tail on a
+    // second stream of the library's own between two events: fork behind the chain, join before returning — for the caller's
+    // stream nothing changes (capturable: the side stream joins the capture and leaves it at the join).  R2L_NO_DW_OVERLAP=1: off.
+    hipStream_t hstream = stream;
+    bool overlap = false;
+    {
+        static hipStream_t side[16] = {nullptr};
+        static hipEvent_t ev_fork[16], ev_join[16];
+        static int overlap_off = -1;
+        if (overlap_off < 0) overlap_off = r2l_env_on("R2L_NO_DW_OVERLAP") ? 1 : 0;
+        int dev = 0;
+        if (!overlap_off && (parts & R2L_BWD_BODY) && (parts & R2L_BWD_HEAD) && layer_hi > layer_lo && dw_slab != nullptr &&
+            N <= R2L_COOPF_MAX_RAYS && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+            if (side[dev] == nullptr) {
+                R2L_CHECK(hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking));
+                R2L_CHECK(hipEventCreateWithFlags(&ev_fork[dev], hipEventDisableTiming));
+                R2L_CHECK(hipEventCreateWithFlags(&ev_join[dev], hipEventDisableTiming));
+            }
+            R2L_CHECK(hipEventRecord(ev_fork[dev], stream));
+            R2L_CHECK(hipStreamWaitEvent(side[dev], ev_fork[dev], 0));
+            hstream = side[dev];
+            overlap = true;
+        }
+        // (the join at the end of this function needs the same objects)
+        if (overlap) { g_r2l_join_ev = ev_join[dev]; }
+    }
     // 2. body weight gradients
     if ((parts & R2L_BWD_BODY) && layer_hi > layer_lo) {
         R2LDwArgs a{};
@@ -1418,11 +1448,11 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         if (per < 2) per = 2;
         slices = (N + per - 1) / per;
         a.rays_per_wg = per;
-        // per-slice partials go to dw_slab (free again after the body reduce), else to the (by now dead) gt scratch when
+        // per-slice partials go to the head's region of dw_slab, else to the (by now dead) gt scratch when
         // it is large enough, else fp32 atomics
         const int64_t slab_floats = slices * (int64_t)(R2L_W * 1024);
         const int64_t gt_floats = (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W;
-        if (slices > 1 && dw_slab != nullptr && slab_floats <= DW_HEAD_SLAB_MAX) a.slab = dw_slab;
+        if (slices > 1 && dw_slab != nullptr && slab_floats <= DW_HEAD_SLAB_MAX) a.slab = dw_slab + DW_BODY_SLAB;
         else a.slab = (slices > 1 && slab_floats <= gt_floats) ? gt : nullptr;
         const dim3 hg((unsigned)(slices * 4)), hb(256);
         if (trio16 && emb == nullptr) {
@@ -1433,18 +1463,18 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             a.scale_dev = scale_dev;
             a.run_unless = bwd_status;
             a.exact = r2l_dw_exact();
-            const int rc = r2l_dw_head16_launch(a, slices, stream);
+            const int rc = r2l_dw_head16_launch(a, slices, hstream);
             if (rc) return rc;
             a.run_unless = nullptr;
             a.run_if = bwd_status;
         }
         if (trio16 && emb == nullptr && no_fallback) {
-        } else if (emb != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<true, false>), hg, hb, 0, stream, a);
-        else if (t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<false, true>), hg, hb, 0, stream, a);
-        else hipLaunchKernelGGL((r2l_dw_head_kernel<false, false>), hg, hb, 0, stream, a);
+        } else if (emb != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<true, false>), hg, hb, 0, hstream, a);
+        else if (t_rand != nullptr) hipLaunchKernelGGL((r2l_dw_head_kernel<false, true>), hg, hb, 0, hstream, a);
+        else hipLaunchKernelGGL((r2l_dw_head_kernel<false, false>), hg, hb, 0, hstream, a);
         R2L_CHECK(hipGetLastError());
         if (a.slab) {
-            hipLaunchKernelGGL(r2l_head_reduce_kernel, dim3(R2L_W * 1024 / 256), dim3(256), 0, stream, a.slab,
+            hipLaunchKernelGGL(r2l_head_reduce_kernel, dim3(R2L_W * 1024 / 256), dim3(256), 0, hstream, a.slab,
                                (int)slices, grads);
             R2L_CHECK(hipGetLastError());
         }
@@ -1455,18 +1485,21 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         int64_t per = (N + wgs - 1) / wgs;
         if (per < 1) per = 1;
         wgs = (N + per - 1) / per;
-        // partials behind the head's slab region; summed in workgroup order
-        float* part = (dw_slab != nullptr && DW_HEAD_SLAB_MAX + wgs * (4 * R2L_W) <= r2l_dw_slab_floats())
-                          ? dw_slab + DW_HEAD_SLAB_MAX : nullptr;
+        // partials in the tail's region of dw_slab; summed in workgroup order
+        float* part = (dw_slab != nullptr && wgs * (4 * R2L_W) <= DW_TAIL_SLAB) ? dw_slab + DW_TAIL_SLAB_BASE : nullptr;
         // (chunked stash: slot n of save_x holds y = x_n + x_0)
-        hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, dpre, split ? nullptr : save_x,
+        hipLaunchKernelGGL(r2l_dw_tail_kernel, dim3((unsigned)wgs), dim3(256), 0, hstream, dpre, split ? nullptr : save_x,
                            save_x + (int64_t)n_block * (split ? R2L_TRIO_SLOT(R2L_PAD_ROWS(N)) : R2L_PAD_ROWS(N) * (int64_t)R2L_W),
                            grads, part, n_block, N, per);
         R2L_CHECK(hipGetLastError());
         if (part != nullptr) {
-            hipLaunchKernelGGL(r2l_tail_reduce_kernel, dim3(R2L_W / 32, 4), dim3(256), 0, stream, part, wgs, grads, n_block);
+            hipLaunchKernelGGL(r2l_tail_reduce_kernel, dim3(R2L_W / 32, 4), dim3(256), 0, hstream, part, wgs, grads, n_block);
             R2L_CHECK(hipGetLastError());
         }
+    }
+    if (overlap) {  // join: the caller's stream continues when head + tail are done as well
+        R2L_CHECK(hipEventRecord(g_r2l_join_ev, hstream));
+        R2L_CHECK(hipStreamWaitEvent(stream, g_r2l_join_ev, 0));
     }
     return 0;
 }

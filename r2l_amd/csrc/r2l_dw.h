@@ -51,7 +51,15 @@ struct R2LDwArgs {
 
 #define DW_SLAB_FLOATS (R2L_W * R2L_W + R2L_W)  // one layer: dW[256][256] then db[256], as in the flat gradient
 #define DW_MAX_WGS 256
-#define DW_HEAD_SLAB_MAX ((int64_t)64 * R2L_W * 1024)  // head partials: up to 64 ray slices of [256][1024] at the slab start
+#define DW_HEAD_SLAB_MAX ((int64_t)64 * R2L_W * 1024)  // head partials: up to 64 ray slices of [256][1024]
+// Regions of dw_slab (round 5: disjoint, so that the head / tail gradients of a small step can run BESIDE the body's on a second
+// stream; rounds 2 - 4 let the head reuse the body's region once its reduce had consumed it):
+//   [0, DW_BODY_SLAB)                      body partials, [workgroup][2][DW_SLAB_FLOATS]
+//   [DW_BODY_SLAB, + DW_HEAD_SLAB_MAX)     head partials, [slice][256][1024]
+//   [DW_TAIL_SLAB_BASE, + DW_TAIL_SLAB)    tail partials, [workgroup <= 512][4][256]
+#define DW_BODY_SLAB ((int64_t)DW_MAX_WGS * 2 * DW_SLAB_FLOATS)
+#define DW_TAIL_SLAB_BASE (DW_BODY_SLAB + DW_HEAD_SLAB_MAX)
+#define DW_TAIL_SLAB ((int64_t)512 * 4 * R2L_W)
 
 // ---- head weight gradient (r2l_backward.hip: fp32 MFMA; r2l_dw_head16.hip: fp16 MFMA of the default trio) ----------------------
 struct R2LDwHeadArgs {

@@ -263,7 +263,12 @@ struct F2Hst {                   // where this lane's 16 B of the NEXT stage's B
 __device__ __forceinline__ void f2_hst_store(const F2Hst& h, u32x4 v) {
     // raw buffer store, no bounds (the padding rows of the last tile are written too).  Whole 128-byte lines, written once,
     // read back milliseconds later by another kernel: non-temporal (aux bit 1 = nt)
-    __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(h.slot, 0, -1, 0x00020000), h.voff, h.soff, 2);
+#ifndef F2_HST_AUX
+#define F2_HST_AUX 18  // cache policy of the stash stores: nt + sc1 (same-box A/B of 0 plain, 2 nt, 3 nt + sc0, 18: profiles/r05_stash_store_ab.txt)
+#endif
+#ifndef F2_HST_OFF    // (timing build: no stash store at all — the MFMA operands are unchanged, the gradients are garbage)
+    __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(h.slot, 0, -1, 0x00020000), h.voff, h.soff, F2_HST_AUX);
+#endif
 }
 struct F2A4 {  // A operands (fp16 pairs) of four output tiles
     f16x8 h[4], m[4];

@@ -198,7 +198,8 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     stages_f, stages_b, pad = 64 + 34 * nb, 34 * nb, 8
     assert lib.r2l_fwd_stream_floats(nb) >= (stages_f + pad) * (24576 + 16384) // 4 + 16
     assert lib.r2l_bwd_stream_floats(nb) >= (stages_b + pad) * (24576 + 16384) // 4 + 16
-    assert lib.r2l_dw_slab_floats() == 256 * 2 * (256 * 256 + 256) + 16
+    # body partials | head partials (64 slices) | tail partials (512 workgroups) | status words: disjoint regions (round 5)
+    assert lib.r2l_dw_slab_floats() == 256 * 2 * (256 * 256 + 256) + 64 * 256 * 1024 + 512 * 4 * 256 + 16
 
 
 def test_options_readme_command(tmp_path):
