@@ -254,26 +254,24 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
     """The teacher's alpha-composite kernel (r2l_raw2outputs_kernel, create_data.py:335-402) against the HBM roofline, at the two
     shapes render_rays launches it with per 32 768-ray chunk: S = 64 (coarse pass: weights emitted for sample_pdf) and S = 192
     (fine pass: no weights).  ALGORITHMIC bytes per ray: S x (16 B raw + 4 B z) + 12 B rays_d read, 24 B of maps
-    written (rgb 12, disp, acc, depth), + 4 S when the weights are emitted.  HIP events on the launch stream around K launches."""
+    written (rgb 12, disp, acc, depth), + 4 S when the weights are emitted.  Device time per launch: the K launches are captured
+    into one hipGraph and the replay is timed with HIP events (a 10 - 30 us kernel behind five output allocations and a ctypes call
+    is HOST-bound when launched eagerly); several input sets are cycled (one set, 42 / 126 MB, would sit in the 256 MB Infinity
+    Cache from the second launch on and the "HBM" rate would be the cache's).  `at_262144_rays`: the same kernel on a launch eight
+    times the reference's --chunk, where ramp-up and tail no longer weigh (what the kernel itself sustains)."""
     from r2l_amd.render import raw2outputs
     g = torch.Generator(device="cpu").manual_seed(5)
     out = {"bound": "hbm", "peak": 8.0, "unit": "TB/s", "rays_per_launch": n_rays, "kernel": "r2l_raw2outputs_kernel",
            "peak_note": "HBM3E 8 TB/s spec (6.3 TB/s is what a plain copy achieves: /opt/skills/guides/MI355X_MICROARCH.md)"}
-    for S, need_w in ((64, True), (192, False)):
-        # several input sets, cycled: one set (42 / 126 MB) would sit in the 256 MB Infinity Cache from the second launch on and
-        # the "HBM" rate would be the cache's
-        n_sets = 8 if S <= 64 else 4
-        raws = [torch.randn(n_rays, S, 4, generator=g).to(device) for _ in range(n_sets)]
-        zs = [(torch.sort(torch.rand(n_rays, S, generator=g), -1)[0] * 4. + 2.).to(device) for _ in range(n_sets)]
-        d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1).to(device)
+
+    def measure(S, need_w, rays, n_sets, k):
+        raws = [torch.randn(rays, S, 4, generator=g).to(device) for _ in range(n_sets)]
+        zs = [(torch.sort(torch.rand(rays, S, generator=g), -1)[0] * 4. + 2.).to(device) for _ in range(n_sets)]
+        d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1).to(device)
         for i in range(max(2, warmup)):
             raw2outputs(raws[i % n_sets], zs[i % n_sets], d, 0., True, need_weights=need_w)
-        k = max(20, steps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        # a 10 - 30 us kernel behind five output allocations and a ctypes call is HOST-bound when launched eagerly (call 1 of round 5
-        # read 21 / 33 us per eager launch): the K launches are captured into one hipGraph and the replay is timed — device time
-        # per launch, back to back.  Eager fallback if the capture is refused.
         method = "hipGraph replay of %d captured launches" % k
         try:
             graph = torch.cuda.CUDAGraph()
@@ -299,9 +297,15 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / k * 1e3
         bpr = S * 20 + 12 + 24 + (4 * S if need_w else 0)
-        tbs = n_rays * bpr / (us * 1e-6) / 1e12
-        out["S%d" % S] = {"bytes_per_ray": bpr, "weights_emitted": need_w, "us_per_launch": us, "timing": method, "input_sets_cycled": n_sets, "achieved": tbs,
-                          "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3}
+        tbs = rays * bpr / (us * 1e-6) / 1e12
+        return {"bytes_per_ray": bpr, "weights_emitted": need_w, "us_per_launch": us, "timing": method, "input_sets_cycled": n_sets,
+                "achieved": tbs, "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3}
+
+    for S, need_w in ((64, True), (192, False)):
+        r = measure(S, need_w, n_rays, 8 if S <= 64 else 4, max(20, steps))
+        big = measure(S, need_w, 8 * n_rays, 2, 8)
+        r["at_262144_rays"] = {k: big[k] for k in ("us_per_launch", "achieved", "frac", "input_sets_cycled")}
+        out["S%d" % S] = r
     return out
 
 
@@ -327,6 +331,7 @@ def summary_of(out):
     if r2o:
         sm["raw2outputs_frac_of_8TBs"] = {k: round(v["frac"], 4) for k, v in r2o.items() if isinstance(v, dict)}
         sm["raw2outputs_TBs"] = {k: round(v["achieved"], 3) for k, v in r2o.items() if isinstance(v, dict)}
+        sm["raw2outputs_TBs_at_262144_rays"] = {k: round(v["at_262144_rays"]["achieved"], 3) for k, v in r2o.items() if isinstance(v, dict)}
     cb = out.get("cpu_baseline")
     if cb:
         sm["cpu_baseline_rays_per_s"] = {"forward": round(cb["value"]), "train": round(cb["train"]["value"]), "cores": cb["cores"]}

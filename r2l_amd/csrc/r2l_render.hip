@@ -65,6 +65,28 @@ __device__ __forceinline__ float wave_scan_add(float v) {
     v += r2l_dpp<0x143, 0xc>(0.f, v);
     return v;
 }
+// five sums at once (rgb, depth, acc of one ray): the same six steps as v_add_f32 WITH the DPP modifier (one instruction per step
+// and value instead of v_mov_b32_dpp + v_add_f32), step-major over the five values so that a register written by one step is read
+// by DPP four instructions later (the VALU-write -> DPP-read hazard needs two wait states; the hazard recognizer does not look into
+// inline asm: s_nop in front for the values the compiler wrote last).  bound_ctrl: lanes without a source add 0.
+__device__ __forceinline__ void wave_scan_add5(float& a, float& b, float& c, float& d, float& e) {
+#define R2O_STEP(CTRL)                                \
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"           \
+    "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"           \
+    "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"           \
+    "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"           \
+    "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 R2O_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 R2O_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 R2O_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 R2O_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 R2O_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 R2O_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+#undef R2O_STEP
+}
 __device__ __forceinline__ float wave_scan_mul(float v) {
     v *= r2l_dpp<0x111, 0xf>(1.f, v);
     v *= r2l_dpp<0x112, 0xf>(1.f, v);
@@ -124,9 +146,12 @@ __global__ __launch_bounds__(256) void r2l_raw2outputs_kernel(const float* __res
                 const float zn = c + 1 < CH ? zz[r][c + 1 < CH ? c + 1 : c] : z_next_lane;
                 float dist = (s + 1 < S) ? zn - z0 : 1e10f;
                 dist = dist * dn;
-                al[c] = 1.0f - expf(-fmaxf(v[r][c][3], 0.f) * dist);
+                // (round 5: v_exp_f32 / v_rcp_f32 — 1 ulp each — instead of expf and IEEE division: the kernel was VALU-bound,
+                // 1200 VALU instructions per wave of four rays, 80 of them division steps, 17 us for 51 MB; the results move by
+                // ~1e-7, the parity bar on the maps is 1e-4)
+                al[c] = 1.0f - __expf(-fmaxf(v[r][c][3], 0.f) * dist);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) col[c][k] = 1.0f / (1.0f + expf(-v[r][c][k]));
+                for (int k = 0; k < 3; ++k) col[c][k] = __builtin_amdgcn_rcpf(1.0f + __expf(-v[r][c][k]));
                 pl *= (1.0f - al[c]) + 1e-10f;
             }
         }
@@ -144,11 +169,11 @@ __global__ __launch_bounds__(256) void r2l_raw2outputs_kernel(const float* __res
                 T *= (1.0f - al[c]) + 1e-10f;
             }
         }
-        sr = wave_scan_add(sr); sg_ = wave_scan_add(sg_); sb = wave_scan_add(sb); sd = wave_scan_add(sd); sa = wave_scan_add(sa);
+        wave_scan_add5(sr, sg_, sb, sd, sa);
         if (lane == 63) {  // (the inclusive scans' last lane holds the totals)
-            const float q = sd / sa;
+            const float q = sd * __builtin_amdgcn_rcpf(sa);   // (0 * inf = NaN for the empty ray, as 0 / 0)
             const float m = (q != q) ? q : fmaxf(1e-10f, q);  // torch.max propagates NaN (empty ray: 0/0)
-            disp_map[ray] = 1.0f / m;
+            disp_map[ray] = __builtin_amdgcn_rcpf(m);
             acc_map[ray] = sa;
             depth_map[ray] = sd;
             const float bg = white_bkgd ? (1.0f - sa) : 0.f;
