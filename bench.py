@@ -305,6 +305,12 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
         r = measure(S, need_w, n_rays, 8 if S <= 64 else 4, max(20, steps))
         big = measure(S, need_w, 8 * n_rays, 2, 8)
         r["at_262144_rays"] = {k: big[k] for k in ("us_per_launch", "achieved", "frac", "input_sets_cycled")}
+        # HBM-side bytes per launch from the committed PMC summary (2 x FETCH_SIZE + WRITE_SIZE; separate rocprofv3 --pmc passes of
+        # tools/r2o_time.py): the kernel is templated on <samples per lane, rays per wave>
+        ch, rpw = (S + 63) // 64, (4 if S <= 128 else 2)
+        r["traffic"], r["traffic_source"] = pmc_traffic("void r2l_raw2outputs_kernel<%d, %d>" % (ch, rpw),
+                                                        grid_threads=(n_rays + 4 * rpw - 1) // (4 * rpw) * 256)
+        r["algorithmic_bytes"] = n_rays * r["bytes_per_ray"]
         out["S%d" % S] = r
     return out
 
