@@ -251,7 +251,7 @@ def teacher_leg(device, world, rank, distributed, frames=2, precision="fp16x2"):
 
 
 def raw2outputs_leg(device, steps, warmup, n_rays=32768):
-    """The teacher's alpha-composite kernel (r2l_raw2outputs_kernel, create_data.py:335-402) against the HBM roofline, at the two
+    """The teacher's alpha-composite kernel (r2l_raw2outputs16_kernel, create_data.py:335-402) against the HBM roofline, at the two
     shapes render_rays launches it with per 32 768-ray chunk: S = 64 (coarse pass: weights emitted for sample_pdf) and S = 192
     (fine pass: no weights).  ALGORITHMIC bytes per ray: S x (16 B raw + 4 B z) + 12 B rays_d read, 24 B of maps
     written (rgb 12, disp, acc, depth), + 4 S when the weights are emitted.  Device time per launch: the K launches are captured
@@ -261,7 +261,7 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
     times the reference's --chunk, where ramp-up and tail no longer weigh (what the kernel itself sustains)."""
     from r2l_amd.render import raw2outputs
     g = torch.Generator(device="cpu").manual_seed(5)
-    out = {"bound": "hbm", "peak": 8.0, "unit": "TB/s", "rays_per_launch": n_rays, "kernel": "r2l_raw2outputs_kernel",
+    out = {"bound": "hbm", "peak": 8.0, "unit": "TB/s", "rays_per_launch": n_rays, "kernel": "r2l_raw2outputs16_kernel",
            "peak_note": "HBM3E 8 TB/s spec (6.3 TB/s is what a plain copy achieves: /opt/skills/guides/MI355X_MICROARCH.md)"}
 
     def measure(S, need_w, rays, n_sets, k):
@@ -306,10 +306,9 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
         big = measure(S, need_w, 8 * n_rays, 2, 8)
         r["at_262144_rays"] = {k: big[k] for k in ("us_per_launch", "achieved", "frac", "input_sets_cycled")}
         # HBM-side bytes per launch from the committed PMC summary (2 x FETCH_SIZE + WRITE_SIZE; separate rocprofv3 --pmc passes of
-        # tools/r2o_time.py): the kernel is templated on <samples per lane, rays per wave>
-        ch, rpw = (S + 63) // 64, (4 if S <= 128 else 2)
-        r["traffic"], r["traffic_source"] = pmc_traffic("void r2l_raw2outputs_kernel<%d, %d>" % (ch, rpw),
-                                                        grid_threads=(n_rays + 4 * rpw - 1) // (4 * rpw) * 256)
+        # tools/r2o_time.py): the quarter-wave-per-ray kernel is templated on <S / 16, weights emitted>
+        r["traffic"], r["traffic_source"] = pmc_traffic("void r2l_raw2outputs16_kernel<%d, %s>" % (S // 16, "true" if need_w else "false"),
+                                                        grid_threads=(n_rays + 15) // 16 * 256)
         r["algorithmic_bytes"] = n_rays * r["bytes_per_ray"]
         out["S%d" % S] = r
     return out

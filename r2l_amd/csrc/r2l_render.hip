@@ -185,6 +185,135 @@ __global__ __launch_bounds__(256) void r2l_raw2outputs_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// raw2outputs for S = 16 * ROWS (64, 128, 192, 256: every sample count the teacher path uses): a QUARTER wave per ray.
+// The 64-lanes-per-ray kernel above is VALU-issue bound, not HBM bound (round-5 PMC: 649 VALU instructions per wave of four
+// rays, two thirds of them the 6-step wave scans and their register moves, HBM traffic = the algorithmic bytes at 0.44 of
+// peak).  Here lane l of a 16-lane DPP row owns samples l, l + 16, l + 32 ... of its ray, so that
+//   * every load / store instruction of the wave still covers whole 64 B .. 256 B runs (row c of a ray = 16 consecutive samples),
+//   * the transmittance is a 4-step scan INSIDE a DPP row (row_shr never crosses a row: no masks, no identity moves) times a
+//     carry that every lane of the row holds (row total by 4 butterfly steps: quad_perm, row_half_mirror, row_mirror),
+//   * the five sums are reduced once per ray over 16 lanes instead of 64,
+//   * the scans of the ROWS rows are independent of each other: issued step-major over four rows at a time, so that no DPP
+//     instruction reads a register written less than two instructions earlier (the VALU-write -> DPP-read hazard).
+// ~230 VALU instructions per wave of four rays at S = 64 instead of 649.  Association of products / sums differs from the
+// kernel above and from torch at the 1e-7 level (tests: rtol 2e-5 on the maps, the bar is 1e-4).
+// ---------------------------------------------------------------------------------------------------------------
+#define R2O_DPP4(OP, CTRL)                                                                   \
+    OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                 \
+    OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                 \
+    OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                 \
+    OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define R2O_DPP4B(OP, CTRL)                                                                  \
+    OP " %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                 \
+    OP " %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                 \
+    OP " %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                 \
+    OP " %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+// e[0..3]: in-row inclusive product scan (a lane without a source keeps its value: no bound_ctrl); t[0..3]: in-row product of
+// all 16 lanes, left in every lane.
+__device__ __forceinline__ void r2o_row_scan_total4(float* e, float* t) {
+    asm volatile("s_nop 1\n\t"
+                 R2O_DPP4("v_mul_f32_dpp", "row_shr:1") R2O_DPP4B("v_mul_f32_dpp", "quad_perm:[1,0,3,2]")
+                 R2O_DPP4("v_mul_f32_dpp", "row_shr:2") R2O_DPP4B("v_mul_f32_dpp", "quad_perm:[2,3,0,1]")
+                 R2O_DPP4("v_mul_f32_dpp", "row_shr:4") R2O_DPP4B("v_mul_f32_dpp", "row_half_mirror")
+                 R2O_DPP4("v_mul_f32_dpp", "row_shr:8") R2O_DPP4B("v_mul_f32_dpp", "row_mirror")
+                 "s_nop 1"
+                 : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+}
+// five in-row sums, left in every lane of the row
+__device__ __forceinline__ void r2o_row_total5(float& a, float& b, float& c, float& d, float& e) {
+#define R2O_STEP5(CTRL)                                                    \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"     \
+    "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t"
+                 R2O_STEP5("quad_perm:[1,0,3,2]") R2O_STEP5("quad_perm:[2,3,0,1]") R2O_STEP5("row_half_mirror") R2O_STEP5("row_mirror")
+                 "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+#undef R2O_STEP5
+}
+#undef R2O_DPP4
+#undef R2O_DPP4B
+
+template <int ROWS, bool WEIGHTS>
+__global__ __launch_bounds__(256) void r2l_raw2outputs16_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                const float* __restrict__ rays_d,
+                                                                const float* __restrict__ noise, int white_bkgd,
+                                                                float* __restrict__ rgb_map, float* __restrict__ disp_map,
+                                                                float* __restrict__ acc_map, float* __restrict__ weights,
+                                                                float* __restrict__ depth_map, int64_t R) {
+    static_assert(ROWS % 4 == 0, "rows are scanned four at a time");
+    constexpr int S = 16 * ROWS;
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    const int64_t ray_w = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = ray_w < R;
+    const int64_t ray = live ? ray_w : R - 1;  // (a tail row re-reads the last ray; nothing is stored for it)
+    // ---- every load of the wave's four rays first ----
+    const float* zr = z + ray * S + l16;
+    const float* rr = raw + (ray * S + l16) * 4;
+    f32x4 v[ROWS];
+    float zz[ROWS];
+#pragma unroll
+    for (int c = 0; c < ROWS; ++c) {
+        v[c] = *reinterpret_cast<const f32x4*>(rr + 64 * c);
+        zz[c] = zr[16 * c];
+    }
+    if (noise != nullptr) {  // (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < ROWS; ++c) v[c][3] += noise[ray * S + l16 + 16 * c];
+    }
+    const float d0 = rays_d[ray * 3 + 0], d1 = rays_d[ray * 3 + 1], d2 = rays_d[ray * 3 + 2];
+    const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);  // torch.norm(rays_d[..., None, :], dim=-1)
+    // ---- alpha and the per-sample transmittance factor of every row ----
+    float al[ROWS], e[ROWS], tot[ROWS];
+#pragma unroll
+    for (int c = 0; c < ROWS; ++c) {
+        // z of sample s + 1: the next lane of the row; for lane 15 the row's lane 0 of the NEXT row of samples (row_ror:15)
+        float zn = r2l_dpp<0x12f, 0xf>(0.f, zz[c]);
+        if (c + 1 < ROWS) {
+            const float zw = r2l_dpp<0x12f, 0xf>(0.f, zz[c + 1]);
+            zn = l16 == 15 ? zw : zn;
+        }
+        float dist = zn - zz[c];
+        if (c + 1 == ROWS) dist = l16 == 15 ? 1e10f : dist;
+        dist = dist * dn;
+        al[c] = 1.0f - __expf(-fmaxf(v[c][3], 0.f) * dist);
+        tot[c] = (1.0f - al[c]) + 1e-10f;
+        e[c] = r2l_dpp<0x111, 0xf>(1.0f, tot[c]);  // shifted by one lane: the scan below comes out EXCLUSIVE
+    }
+#pragma unroll
+    for (int c = 0; c < ROWS; c += 4) r2o_row_scan_total4(e + c, tot + c);
+    // ---- weights and the five sums ----
+    float carry = 1.0f, sr = 0.f, sg_ = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+    for (int c = 0; c < ROWS; ++c) {
+        const float w = al[c] * (carry * e[c]);
+        carry *= tot[c];
+        if (WEIGHTS) {
+            if (live) weights[ray * S + l16 + 16 * c] = w;
+        }
+        sr += w * __builtin_amdgcn_rcpf(1.0f + __expf(-v[c][0]));
+        sg_ += w * __builtin_amdgcn_rcpf(1.0f + __expf(-v[c][1]));
+        sb += w * __builtin_amdgcn_rcpf(1.0f + __expf(-v[c][2]));
+        sd += w * zz[c];
+        sa += w;
+    }
+    r2o_row_total5(sr, sg_, sb, sd, sa);
+    if (l16 == 0 && live) {
+        const float q = sd * __builtin_amdgcn_rcpf(sa);   // (0 * inf = NaN for the empty ray, as 0 / 0)
+        const float m = (q != q) ? q : fmaxf(1e-10f, q);  // torch.max propagates NaN (empty ray: 0/0)
+        disp_map[ray] = __builtin_amdgcn_rcpf(m);
+        acc_map[ray] = sa;
+        depth_map[ray] = sd;
+        const float bg = white_bkgd ? (1.0f - sa) : 0.f;
+        rgb_map[ray * 3 + 0] = sr + bg;
+        rgb_map[ray * 3 + 1] = sg_ + bg;
+        rgb_map[ray * 3 + 2] = sb + bg;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // sample_pdf + sort-merge.  One wave per ray.  S coarse samples (S <= 64), NI new samples (NI <= 192, S+NI <= 256).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* __restrict__ z, const float* __restrict__ wts,
@@ -312,6 +441,20 @@ extern "C" int r2l_raw2outputs(const float* raw, const float* z, const float* ra
     if (R <= 0) return 0;
     if (S < 1 || S > 64 * MAX_CH) { r2l_set_error("r2l_raw2outputs: S out of range [1,256]", hipErrorInvalidValue); return (int)hipErrorInvalidValue; }
     R2L_REQUIRE(raw && z && rays_d && rgb_map && disp_map && acc_map && depth_map, "r2l_raw2outputs: a required pointer is NULL (only noise and weights are optional)");
+    if (S % 64 == 0) {  // the teacher path's sample counts: a quarter wave per ray
+#define R2O16_LAUNCH(ROWS_, W_)                                                                                                 \
+    hipLaunchKernelGGL((r2l_raw2outputs16_kernel<ROWS_, W_>), dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, \
+                       raw, z, rays_d, noise, white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map, R)
+#define R2O16_BOTH(ROWS_) do { if (weights != nullptr) R2O16_LAUNCH(ROWS_, true); else R2O16_LAUNCH(ROWS_, false); } while (0)
+        if (S == 64) R2O16_BOTH(4);
+        else if (S == 128) R2O16_BOTH(8);
+        else if (S == 192) R2O16_BOTH(12);
+        else R2O16_BOTH(16);
+#undef R2O16_BOTH
+#undef R2O16_LAUNCH
+        R2L_CHECK(hipGetLastError());
+        return 0;
+    }
     const int CH = (S + 63) / 64;
 #define R2O_LAUNCH(CH_, RPW_)                                                                                                  \
     hipLaunchKernelGGL((r2l_raw2outputs_kernel<CH_, RPW_>), dim3((unsigned)((R + 4 * RPW_ - 1) / (4 * RPW_))), dim3(256), 0,     \

@@ -42,7 +42,9 @@ def test_raw2outputs_golden(golden_dir, S, wb):
         np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(ref), rtol=2e-5, atol=2e-6, err_msg=name)
 
 
-@pytest.mark.parametrize("S,R", [(2, 3), (16, 5), (65, 7), (200, 9), (256, 1000)])  # S=1 is degenerate in the reference (empty dists)
+# S = 64 / 128 / 192 / 256 take the quarter-wave-per-ray kernel (r2l_raw2outputs16_kernel: 16 rays per workgroup, so R = 37 / 21 / 5
+# leave tail rows and tail waves), every other S the one-ray-per-wave kernel.  S=1 is degenerate in the reference (empty dists).
+@pytest.mark.parametrize("S,R", [(2, 3), (16, 5), (65, 7), (200, 9), (256, 1000), (64, 37), (128, 21), (192, 5), (64, 4099)])
 def test_raw2outputs_shapes_vs_oracle(S, R):
     from r2l_amd.render import raw2outputs
     g = torch.Generator().manual_seed(S)
@@ -59,6 +61,11 @@ def test_raw2outputs_shapes_vs_oracle(S, R):
     got = raw2outputs(raw.cuda(), z.cuda(), d.cuda(), 1.0, False, noise=noise.cuda())
     for a, b in zip(got, ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=3e-5, atol=3e-6)
+    # the fine pass's form: no weights written, the four maps unchanged bit for bit
+    lean = raw2outputs(raw.cuda(), z.cuda(), d.cuda(), 1.0, False, noise=noise.cuda(), need_weights=False)
+    assert lean[3] is None
+    for a, b in zip(lean[:3] + lean[4:], got[:3] + got[4:]):  # (disp is NaN on an empty ray: compare the bits)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 def _sample_pdf_last_admissible(bins, weights, got_last):
