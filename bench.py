@@ -250,16 +250,51 @@ def teacher_leg(device, world, rank, distributed, frames=2, precision="fp16x2"):
                          "flop_per_ray": flop_per_ray}}
 
 
+def graph_us(launch, k, warmup):
+    """Device time per launch of `launch(i)`, i = 0 .. k-1: the k launches are captured into one hipGraph and the replay is timed with
+    HIP events (a 10 - 30 us kernel behind output allocations and a ctypes call is HOST-bound when launched eagerly)."""
+    for i in range(max(2, warmup)):
+        launch(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    method = "hipGraph replay of %d captured launches" % k
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(k):
+                launch(i)
+        graph.replay()
+        torch.cuda.synchronize()
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / (k * reps) * 1e3
+    except Exception as exc:  # noqa: BLE001
+        method = "eager launches (graph capture failed: %s)" % type(exc).__name__
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(k):
+            launch(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / k * 1e3
+    return us, method
+
+
 def raw2outputs_leg(device, steps, warmup, n_rays=32768):
     """The teacher's alpha-composite kernel (r2l_raw2outputs16_kernel, create_data.py:335-402) against the HBM roofline, at the two
     shapes render_rays launches it with per 32 768-ray chunk: S = 64 (coarse pass: weights emitted for sample_pdf) and S = 192
     (fine pass: no weights).  ALGORITHMIC bytes per ray: S x (16 B raw + 4 B z) + 12 B rays_d read, 24 B of maps
-    written (rgb 12, disp, acc, depth), + 4 S when the weights are emitted.  Device time per launch: the K launches are captured
-    into one hipGraph and the replay is timed with HIP events (a 10 - 30 us kernel behind five output allocations and a ctypes call
-    is HOST-bound when launched eagerly); several input sets are cycled (one set, 42 / 126 MB, would sit in the 256 MB Infinity
-    Cache from the second launch on and the "HBM" rate would be the cache's).  `at_262144_rays`: the same kernel on a launch eight
-    times the reference's --chunk, where ramp-up and tail no longer weigh (what the kernel itself sustains)."""
-    from r2l_amd.render import raw2outputs
+    written (rgb 12, disp, acc, depth), + 4 S when the weights are emitted.  Device time per launch: graph_us; several input sets
+    are cycled (one set, 42 / 126 MB, would sit in the 256 MB Infinity Cache from the second launch on and the "HBM" rate would be
+    the cache's).  `at_262144_rays`: the same kernel on a launch eight times the reference's --chunk, where ramp-up and tail no
+    longer weigh (what the kernel itself sustains).  `sample_pdf_sort`: the hierarchical-sampling kernel between the two passes
+    (r2l_sample_pdf_sort16_kernel, helpers:283-330 + create_data.py:505-515; S = 64 coarse depths + weights and 128 uniforms in,
+    128 new depths + the 192 merged and sorted depths + z_std out: 2308 B per ray), measured the same way."""
+    from r2l_amd.render import raw2outputs, sample_pdf_sort
     g = torch.Generator(device="cpu").manual_seed(5)
     out = {"bound": "hbm", "peak": 8.0, "unit": "TB/s", "rays_per_launch": n_rays, "kernel": "r2l_raw2outputs16_kernel",
            "peak_note": "HBM3E 8 TB/s spec (6.3 TB/s is what a plain copy achieves: /opt/skills/guides/MI355X_MICROARCH.md)"}
@@ -268,38 +303,22 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
         raws = [torch.randn(rays, S, 4, generator=g).to(device) for _ in range(n_sets)]
         zs = [(torch.sort(torch.rand(rays, S, generator=g), -1)[0] * 4. + 2.).to(device) for _ in range(n_sets)]
         d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1).to(device)
-        for i in range(max(2, warmup)):
-            raw2outputs(raws[i % n_sets], zs[i % n_sets], d, 0., True, need_weights=need_w)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        method = "hipGraph replay of %d captured launches" % k
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for i in range(k):
-                    raw2outputs(raws[i % n_sets], zs[i % n_sets], d, 0., True, need_weights=need_w)
-            graph.replay()
-            torch.cuda.synchronize()
-            reps = 5
-            e0.record()
-            for _ in range(reps):
-                graph.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / (k * reps) * 1e3
-        except Exception as exc:  # noqa: BLE001
-            method = "eager launches (graph capture failed: %s)" % type(exc).__name__
-            torch.cuda.synchronize()
-            e0.record()
-            for i in range(k):
-                raw2outputs(raws[i % n_sets], zs[i % n_sets], d, 0., True, need_weights=need_w)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / k * 1e3
+        us, method = graph_us(lambda i: raw2outputs(raws[i % n_sets], zs[i % n_sets], d, 0., True, need_weights=need_w), k, warmup)
         bpr = S * 20 + 12 + 24 + (4 * S if need_w else 0)
         tbs = rays * bpr / (us * 1e-6) / 1e12
         return {"bytes_per_ray": bpr, "weights_emitted": need_w, "us_per_launch": us, "timing": method, "input_sets_cycled": n_sets,
                 "achieved": tbs, "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3}
+
+    def measure_pdf(rays, n_sets, k, S=64, NI=128):
+        zs = [(torch.sort(torch.rand(rays, S, generator=g), -1)[0] * 4. + 2.).to(device) for _ in range(n_sets)]
+        ws = [(torch.rand(rays, S, generator=g) ** 4).to(device) for _ in range(n_sets)]
+        us_ = [torch.rand(rays, NI, generator=g).to(device) for _ in range(n_sets)]
+        us, method = graph_us(lambda i: sample_pdf_sort(zs[i % n_sets], ws[i % n_sets], NI, u=us_[i % n_sets]), k, warmup)
+        bpr = 4 * (S + S + NI) + 4 * (NI + S + NI) + 4
+        tbs = rays * bpr / (us * 1e-6) / 1e12
+        return {"bytes_per_ray": bpr, "us_per_launch": us, "timing": method, "input_sets_cycled": n_sets, "achieved": tbs,
+                "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3, "kernel": "r2l_sample_pdf_sort16_kernel",
+                "bound_note": "2308 B per ray would make it HBM-bound; the 256-element sorting network per ray (4608 compare-exchanges) makes it VALU-issue bound"}
 
     for S, need_w in ((64, True), (192, False)):
         r = measure(S, need_w, n_rays, 8 if S <= 64 else 4, max(20, steps))
@@ -311,6 +330,12 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
                                                         grid_threads=(n_rays + 15) // 16 * 256)
         r["algorithmic_bytes"] = n_rays * r["bytes_per_ray"]
         out["S%d" % S] = r
+    r = measure_pdf(n_rays, 8, max(20, steps))
+    big = measure_pdf(8 * n_rays, 2, 8)
+    r["at_262144_rays"] = {k: big[k] for k in ("us_per_launch", "achieved", "frac", "input_sets_cycled")}
+    r["traffic"], r["traffic_source"] = pmc_traffic("r2l_sample_pdf_sort16_kernel", grid_threads=(n_rays + 15) // 16 * 256)
+    r["algorithmic_bytes"] = n_rays * r["bytes_per_ray"]
+    out["sample_pdf_sort"] = r
     return out
 
 

@@ -315,42 +315,74 @@ __global__ __launch_bounds__(256) void r2l_raw2outputs16_kernel(const float* __r
 
 // ---------------------------------------------------------------------------------------------------------------
 // sample_pdf + sort-merge.  One wave per ray.  S coarse samples (S <= 64), NI new samples (NI <= 192, S+NI <= 256).
+// Round 5 (second form).  The first form did everything through LDS behind block barriers — the cdf as a 62-step loop of ONE lane
+// over LDS, the merge as a 36-stage bitonic network of LDS compare-exchanges with a __syncthreads per stage — and took 90 us per
+// 32 768-ray chunk (2.3 KB per ray: 0.65 TB/s), every step latency-bound.  Now:
+//   * cdf: torch.cumsum's left-to-right fp32 order is kept (the det sample at u = 1 sits on cdf[-1] to the ulp: tests), as 63
+//     dependent `v_add_f32 ... wave_shr:1` steps in registers — lane k ends with ((p0 + p1) + p2) ... + pk — ~8 clocks a step
+//     instead of an LDS round trip;
+//   * the sort runs in registers: lane l holds elements 4l .. 4l+3 of the 256-element network (all comparisons "lower index gets the
+//     smaller": each merge phase opens with the mirror step i <-> i ^ (k - 1)); partners in other lanes come through DPP
+//     (quad_perm, row_half_mirror, row_mirror, row_ror:8) and, for the three lane distances that leave a 16-lane row, ds_bpermute:
+//     12 LDS-crossbar operations per ray instead of ~600 LDS accesses, no barrier;
+//   * the sorted row leaves as one 16-byte store per lane.
+// Only the inverse-cdf search still reads LDS (cdf and bin edges of the wave's own ray; one block barrier in front of it).
 // ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float r2o_perm(float v) {  // (every lane has a source: no `old` operand to set up)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float r2o_xlane(int byte_addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float r2o_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float r2o_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void r2o_ce(float& a, float& b) {
+    const float lo = r2o_min(a, b), hi = r2o_max(a, b);
+    a = lo; b = hi;
+}
+__device__ __forceinline__ float r2o_keep(bool keep_min, float a, float p) {
+    const float lo = r2o_min(a, p), hi = r2o_max(a, p);  // (both, then a select: a ternary over the asm statements becomes branches)
+    return keep_min ? lo : hi;
+}
+
 __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* __restrict__ z, const float* __restrict__ wts,
                                                                   const float* __restrict__ u, int64_t u_stride,
                                                                   float* __restrict__ z_samples, float* __restrict__ z_all,
                                                                   float* __restrict__ z_std, int64_t R, int S, int NI) {
     __shared__ float s_cdf[4][64];
     __shared__ float s_bins[4][64];
-    __shared__ float s_sort[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int64_t ray = (int64_t)blockIdx.x * 4 + wv;
-    const bool live = ray < R;  // idle waves of the last block keep hitting the block barriers on a clamped ray
+    const bool live = ray < R;  // idle waves of the last block run on a clamped ray (they meet the block barrier) and store nothing
     if (!live) ray = R - 1;
     const float* zr = z + ray * S;
     const int nb = S - 1;   // bins = z_mid (S-1 edges)
     const int nw = S - 2;   // weights[..., 1:-1]
     float* cdf = s_cdf[wv];
     float* bins = s_bins[wv];
-    // bins and (weights + 1e-5)
-    float wl = 0.f;
-    if (lane < nb) bins[lane] = .5f * (zr[lane + 1] + zr[lane]);
+    // ---- loads: this lane's coarse depth, inner weight and its (up to three) u's ----
+    const float z0 = lane < S ? zr[lane] : INFINITY;
+    float wl = 0.f, uu[3];
     if (lane < nw) wl = wts[ray * S + lane + 1] + 1e-5f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) uu[m] = lane + 64 * m < NI ? u[ray * u_stride + lane + 64 * m] : 0.f;
+    // ---- bins, pdf, cdf ----
+    const float z1 = r2l_dpp<0x130, 0xf>(0.f, z0);  // wave_shl:1: the next lane's depth
+    if (lane < nb) bins[lane] = .5f * (z1 + z0);
     const float total = wave_sum(wl);
-    cdf[lane] = wl / total;  // pdf, staged
+    const float pdf = wl / total;
+    float run = pdf;  // -> inclusive prefix, summed left to right like torch.cumsum (lanes >= nw add 0)
+    asm volatile("s_nop 1\n\t"
+                 ".rept 63\n\t"
+                 "v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 ".endr"
+                 : "+&v"(run) : "v"(pdf));  // (early clobber: `run` starts as a copy of `pdf` and would share its register)
+    if (lane == 0) cdf[0] = 0.f;
+    if (lane < nw) cdf[lane + 1] = run;
     __syncthreads();
-    if (lane == 0) {  // torch.cumsum is a left-to-right fp32 sum; keep that order (cdf[0] = 0)
-        float run = 0.f, prev = 0.f;
-        for (int k = 0; k < nw; ++k) {
-            const float pk = cdf[k];
-            cdf[k] = prev;
-            run += pk;
-            prev = run;
-        }
-        cdf[nw] = prev;
-    }
-    __syncthreads();
-    // inverse CDF for this lane's u's
+    // ---- inverse CDF for this lane's u's ----
     float sum1 = 0.f;
     float samp[3];
 #pragma unroll
@@ -358,12 +390,11 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* _
         const int i = lane + 64 * m;
         samp[m] = 0.f;
         if (i < NI) {
-            const float uu = u[ray * u_stride + i];
             // searchsorted(cdf[0..nb), uu, right=True): number of entries <= uu
             int lo = 0, hi = nb;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+                if (cdf[mid] <= uu[m]) lo = mid + 1; else hi = mid;
             }
             const int below = lo - 1 > 0 ? lo - 1 : 0;
             const int above = lo < nb - 1 ? lo : nb - 1;
@@ -371,7 +402,7 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* _
             const float b0 = bins[below], b1 = bins[above];
             float denom = c1 - c0;
             denom = denom < 1e-5f ? 1.0f : denom;
-            const float t = (uu - c0) / denom;
+            const float t = (uu[m] - c0) / denom;
             samp[m] = b0 + t * (b1 - b0);
             if (live) z_samples[ray * NI + i] = samp[m];
             sum1 += samp[m];
@@ -385,40 +416,219 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* _
         if (lane + 64 * m < NI) sq += (samp[m] - mean) * (samp[m] - mean);
     sq = wave_sum(sq);
     if (live && lane == 0 && z_std != nullptr) z_std[ray] = sqrtf(sq / (float)NI);
-    // bitonic sort of [z (S), samples (NI), +inf padding] in LDS
-    float* ss = s_sort[wv];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int i = lane + 64 * m;
-        ss[i] = i < S ? zr[i] : INFINITY;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        const int i = lane + 64 * m;
-        if (i < NI) ss[S + i] = samp[m];
-    }
-    __syncthreads();
-    for (int k = 2; k <= 256; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int tix = lane + 64 * m;                  // 128 compare-exchange pairs
-                const int i = ((tix & ~(j - 1)) << 1) | (tix & (j - 1));
-                const int p = i | j;
-                const float a0 = ss[i], a1 = ss[p];
-                const bool up = (i & k) == 0;
-                if ((a0 > a1) == up) { ss[i] = a1; ss[p] = a0; }
-            }
-            __syncthreads();
-        }
+    // ---- sort [z (S), samples (NI), +inf padding]: 256-element network, element 4 lane + r in register v_r ----
+    float v0 = z0;
+    float v1 = lane < NI ? samp[0] : INFINITY;
+    float v2 = lane + 64 < NI ? samp[1] : INFINITY;
+    float v3 = lane + 128 < NI ? samp[2] : INFINITY;
+    const bool k0 = (lane & 1) == 0, k1 = (lane & 2) == 0, k2 = (lane & 4) == 0, k3 = (lane & 8) == 0, k4 = (lane & 16) == 0,
+               k5 = (lane & 32) == 0;
+    const int a16 = (lane ^ 16) << 2, a31 = (lane ^ 31) << 2, a63 = (lane ^ 63) << 2;
+#define R2O_TAIL() r2o_ce(v0, v2); r2o_ce(v1, v3); r2o_ce(v0, v1); r2o_ce(v2, v3)   /* partner distances 2, 1: inside the lane */
+#define R2O_MIRROR(F, KM)  /* i <-> i ^ (k - 1): the other lane's registers in reverse */                  \
+    { const float p0 = F(v3), p1 = F(v2), p2 = F(v1), p3 = F(v0);                                           \
+      v0 = r2o_keep(KM, v0, p0); v1 = r2o_keep(KM, v1, p1); v2 = r2o_keep(KM, v2, p2); v3 = r2o_keep(KM, v3, p3); }
+#define R2O_XOR(F, KM)     /* i <-> i ^ j, j >= 4: the same register of lane ^ (j / 4) */                  \
+    { const float p0 = F(v0), p1 = F(v1), p2 = F(v2), p3 = F(v3);                                           \
+      v0 = r2o_keep(KM, v0, p0); v1 = r2o_keep(KM, v1, p1); v2 = r2o_keep(KM, v2, p2); v3 = r2o_keep(KM, v3, p3); }
+#define X1(x) r2o_perm<0xB1>(x)                   /* quad_perm:[1,0,3,2]  lane ^ 1  */
+#define X2(x) r2o_perm<0x4E>(x)                   /* quad_perm:[2,3,0,1]  lane ^ 2  */
+#define X3(x) r2o_perm<0x1B>(x)                   /* quad_perm:[3,2,1,0]  lane ^ 3  */
+#define X7(x) r2o_perm<0x141>(x)                  /* row_half_mirror      lane ^ 7  */
+#define X4(x) r2o_perm<0x1B>(r2o_perm<0x141>(x))  /* (lane ^ 3) ^ 7                 */
+#define X8(x) r2o_perm<0x128>(x)                  /* row_ror:8            lane ^ 8  */
+#define X15(x) r2o_perm<0x140>(x)                 /* row_mirror           lane ^ 15 */
+#define X16(x) r2o_xlane(a16, x)
+#define X31(x) r2o_xlane(a31, x)
+#define X63(x) r2o_xlane(a63, x)
+    r2o_ce(v0, v1); r2o_ce(v2, v3);                                                           // k = 2
+    r2o_ce(v0, v3); r2o_ce(v1, v2); r2o_ce(v0, v1); r2o_ce(v2, v3);                           // k = 4
+    R2O_MIRROR(X1, k0) R2O_TAIL();                                                            // k = 8
+    R2O_MIRROR(X3, k1) R2O_XOR(X1, k0) R2O_TAIL();                                            // k = 16
+    R2O_MIRROR(X7, k2) R2O_XOR(X2, k1) R2O_XOR(X1, k0) R2O_TAIL();                            // k = 32
+    R2O_MIRROR(X15, k3) R2O_XOR(X4, k2) R2O_XOR(X2, k1) R2O_XOR(X1, k0) R2O_TAIL();           // k = 64
+    R2O_MIRROR(X31, k4) R2O_XOR(X8, k3) R2O_XOR(X4, k2) R2O_XOR(X2, k1) R2O_XOR(X1, k0) R2O_TAIL();                    // k = 128
+    R2O_MIRROR(X63, k5) R2O_XOR(X16, k4) R2O_XOR(X8, k3) R2O_XOR(X4, k2) R2O_XOR(X2, k1) R2O_XOR(X1, k0) R2O_TAIL();   // k = 256
+#undef X1
+#undef X2
+#undef X3
+#undef X4
+#undef X7
+#undef X8
+#undef X15
+#undef X16
+#undef X31
+#undef X63
+#undef R2O_XOR
+#undef R2O_MIRROR
+#undef R2O_TAIL
     const int tot = S + NI;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int i = lane + 64 * m;
-        if (live && i < tot) z_all[ray * tot + i] = ss[i];
+    if (live) {
+        float* out = z_all + ray * tot + 4 * lane;
+        if ((tot & 3) == 0) {  // (wave-uniform) rows are 16-byte aligned: one store per lane
+            if (4 * lane < tot) *reinterpret_cast<f32x4*>(out) = f32x4{v0, v1, v2, v3};
+        } else {
+            if (4 * lane + 0 < tot) out[0] = v0;
+            if (4 * lane + 1 < tot) out[1] = v1;
+            if (4 * lane + 2 < tot) out[2] = v2;
+            if (4 * lane + 3 < tot) out[3] = v3;
+        }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// sample_pdf + sort-merge for the reference's configuration (S = 64 coarse depths, NI = 128 new ones): a QUARTER wave per ray.
+// The one-ray-per-wave kernel above is VALU-issue bound (~900 instructions per ray: 47 us per 32 768-ray chunk, 0.2 of the HBM
+// roofline its 2.3 KB per ray would allow).  With 16 lanes per ray and 16 elements of the 256-element network per lane,
+//   * 26 of the 36 network stages are min / max pairs between a lane's own registers (2 instructions per compare-exchange instead
+//     of 4 + a cross-lane move for each of the two partners), the other 10 reach their partner inside the 16-lane DPP row
+//     (quad_perm, row_half_mirror, row_mirror): no ds_bpermute at all, a compare + select per element;
+//   * the left-to-right cdf runs for four rays at once: 16 steps of (carry from the previous lane by row_shr:1, four dependent
+//     adds) — the same association as torch.cumsum, element for element;
+//   * sums over a ray (pdf normalisation, z_std) follow wave_sum's butterfly association (k ^ 32, 16, ... 1 over the 64 positions),
+//     so this kernel and the generic one return the same bits.
+// Loads and stores are 16 bytes per lane, contiguous per ray.
+// ---------------------------------------------------------------------------------------------------------------
+#define X1(x) r2o_perm<0xB1>(x)                   /* quad_perm:[1,0,3,2]  lane ^ 1  */
+#define X2(x) r2o_perm<0x4E>(x)                   /* quad_perm:[2,3,0,1]  lane ^ 2  */
+#define X3(x) r2o_perm<0x1B>(x)                   /* quad_perm:[3,2,1,0]  lane ^ 3  */
+#define X7(x) r2o_perm<0x141>(x)                  /* row_half_mirror      lane ^ 7  */
+#define X4(x) r2o_perm<0x1B>(r2o_perm<0x141>(x))  /* (lane ^ 3) ^ 7                 */
+#define X8(x) r2o_perm<0x128>(x)                  /* row_ror:8            lane ^ 8  */
+#define X15(x) r2o_perm<0x140>(x)                 /* row_mirror           lane ^ 15 */
+// sum over the 64 positions k = 4 l16 + j of a ray in wave_sum's association; every lane of the row gets the total
+__device__ __forceinline__ float r2o_row_sum64(float a0, float a1, float a2, float a3) {
+    a0 += X8(a0); a1 += X8(a1); a2 += X8(a2); a3 += X8(a3);  // k ^ 32
+    a0 += X4(a0); a1 += X4(a1); a2 += X4(a2); a3 += X4(a3);  // k ^ 16
+    a0 += X2(a0); a1 += X2(a1); a2 += X2(a2); a3 += X2(a3);  // k ^ 8
+    a0 += X1(a0); a1 += X1(a1); a2 += X1(a2); a3 += X1(a3);  // k ^ 4
+    const float b0 = a0 + a2, b1 = a1 + a3;                  // k ^ 2
+    return b0 + b1;                                          // k ^ 1
+}
+template <int MASK>
+__device__ __forceinline__ void r2o_inlane(float (&v)[16]) {  // compare-exchange r <-> r ^ MASK inside the lane, smaller first
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r ^ MASK) > r) r2o_ce(v[r], v[r ^ MASK]);
+}
+__device__ __forceinline__ void r2o_tail16(float (&v)[16]) { r2o_inlane<8>(v); r2o_inlane<4>(v); r2o_inlane<2>(v); r2o_inlane<1>(v); }
+// `take`: this lane holds the LARGER index of the pair (it keeps the larger value)
+#define R2O_TAKE(v_, p_, upper_) { const float pp = (p_); const bool c = (pp < (v_)) != (upper_); (v_) = c ? pp : (v_); }
+#define R2O_MIRROR16(F, UPPER) { float q[16];                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) q[r] = F(v[15 - r]);                       \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) R2O_TAKE(v[r], q[r], UPPER) }
+#define R2O_XOR16(F, UPPER) { _Pragma("unroll") for (int r = 0; r < 16; ++r) R2O_TAKE(v[r], F(v[r]), UPPER) }
+
+__global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float* __restrict__ z, const float* __restrict__ wts,
+                                                                    const float* __restrict__ u, int64_t u_stride,
+                                                                    float* __restrict__ z_samples, float* __restrict__ z_all,
+                                                                    float* __restrict__ z_std, int64_t R) {
+    constexpr int S = 64, NI = 128, NB = S - 1, NW = S - 2;
+    __shared__ float s_cdf[16][64];
+    __shared__ float s_bins[16][64];
+    const int lane = threadIdx.x & 63, l16 = lane & 15, slot = threadIdx.x >> 4;
+    int64_t ray = (int64_t)blockIdx.x * 16 + slot;
+    const bool live = ray < R;  // rows past the end run on a clamped ray (they meet the block barrier) and store nothing
+    if (!live) ray = R - 1;
+    float* cdf = s_cdf[slot];
+    float* bins = s_bins[slot];
+    // ---- loads: four coarse depths, four weights and eight u's per lane ----
+    const f32x4 z4 = *reinterpret_cast<const f32x4*>(z + ray * S + 4 * l16);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wts + ray * S + 4 * l16);
+    const f32x4 ua = *reinterpret_cast<const f32x4*>(u + ray * u_stride + 4 * l16);
+    const f32x4 ub = *reinterpret_cast<const f32x4*>(u + ray * u_stride + 64 + 4 * l16);
+    // ---- bins (position k = 4 l16 + j: .5 (z[k+1] + z[k]); k = 63 is never read) ----
+    const float zn = r2l_dpp<0x101, 0xf>(0.f, z4[0]);  // row_shl:1: the next lane's first depth
+    *reinterpret_cast<f32x4*>(bins + 4 * l16) = f32x4{.5f * (z4[1] + z4[0]), .5f * (z4[2] + z4[1]), .5f * (z4[3] + z4[2]), .5f * (zn + z4[3])};
+    // ---- pdf of the inner weights: position k holds weights[k + 1] + 1e-5 for k < NW ----
+    const float wn = r2l_dpp<0x101, 0xf>(0.f, w4[0]);
+    float wl[4] = {w4[1] + 1e-5f, w4[2] + 1e-5f, w4[3] + 1e-5f, wn + 1e-5f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * l16 + j >= NW) wl[j] = 0.f;
+    const float total = r2o_row_sum64(wl[0], wl[1], wl[2], wl[3]);
+    const float p0 = wl[0] / total, p1 = wl[1] / total, p2 = wl[2] / total, p3 = wl[3] / total;
+    // ---- cdf: inclusive prefix, summed left to right like torch.cumsum.  Step t makes lane t final (its carry, lane t - 1's last
+    //      prefix, became final in step t - 1); a lane that is final recomputes the same values.  (s_nop: VALU write -> DPP read) ----
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    asm volatile("s_nop 1\n\t"
+                 ".rept 16\n\t"
+                 "v_add_f32_dpp %0, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_add_f32 %1, %0, %5\n\t"
+                 "v_add_f32 %2, %1, %6\n\t"
+                 "v_add_f32 %3, %2, %7\n\t"
+                 "s_nop 1\n\t"
+                 ".endr"
+                 : "+&v"(c0), "+&v"(c1), "+&v"(c2), "+&v"(c3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+    if (l16 == 0) cdf[0] = 0.f;
+    {
+        const float cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * l16 + j < NW) cdf[4 * l16 + j + 1] = cc[j];
+    }
+    __syncthreads();
+    // ---- inverse CDF: sample i = 4 l16 + 64 m + j ----
+    float samp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float uu = q < 4 ? ua[q & 3] : ub[q & 3];
+        // searchsorted(cdf[0..NB), uu, right=True) = number of entries <= uu (NB = 63 = 32 + 16 + ... + 1: six fixed steps)
+        int pos = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            pos += cdf[pos + step - 1] <= uu ? step : 0;
+        const int below = pos - 1 > 0 ? pos - 1 : 0;
+        const int above = pos < NB - 1 ? pos : NB - 1;
+        const float k0 = cdf[below], k1 = cdf[above];
+        const float b0 = bins[below], b1 = bins[above];
+        float denom = k1 - k0;
+        denom = denom < 1e-5f ? 1.0f : denom;
+        const float t = (uu - k0) / denom;
+        samp[q] = b0 + t * (b1 - b0);
+    }
+    if (live) {
+        *reinterpret_cast<f32x4*>(z_samples + ray * NI + 4 * l16) = f32x4{samp[0], samp[1], samp[2], samp[3]};
+        *reinterpret_cast<f32x4*>(z_samples + ray * NI + 64 + 4 * l16) = f32x4{samp[4], samp[5], samp[6], samp[7]};
+    }
+    // ---- z_std = std(z_samples, unbiased=False), in the generic kernel's association (position k sums its samples k, k + 64) ----
+    const float mean = r2o_row_sum64(samp[0] + samp[4], samp[1] + samp[5], samp[2] + samp[6], samp[3] + samp[7]) / (float)NI;
+    float sq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d0 = (samp[j] - mean) * (samp[j] - mean), d1 = (samp[4 + j] - mean) * (samp[4 + j] - mean);
+        sq[j] = d0 + d1;
+    }
+    const float sqs = r2o_row_sum64(sq[0], sq[1], sq[2], sq[3]);
+    if (live && l16 == 0 && z_std != nullptr) z_std[ray] = sqrtf(sqs / (float)NI);
+    // ---- sort [z (64), samples (128), +inf (64)]: element 16 l16 + r of the 256-element network in register v[r] ----
+    float v[16] = {z4[0], z4[1], z4[2], z4[3], samp[0], samp[1], samp[2], samp[3], samp[4], samp[5], samp[6], samp[7],
+                   INFINITY, INFINITY, INFINITY, INFINITY};
+    const bool u0 = (l16 & 1) != 0, u1 = (l16 & 2) != 0, u2 = (l16 & 4) != 0, u3 = (l16 & 8) != 0;
+    r2o_inlane<1>(v);                                                                     // k = 2
+    r2o_inlane<3>(v); r2o_inlane<1>(v);                                                   // k = 4
+    r2o_inlane<7>(v); r2o_inlane<2>(v); r2o_inlane<1>(v);                                 // k = 8
+    r2o_inlane<15>(v); r2o_inlane<4>(v); r2o_inlane<2>(v); r2o_inlane<1>(v);              // k = 16
+    R2O_MIRROR16(X1, u0) r2o_tail16(v);                                                   // k = 32
+    R2O_MIRROR16(X3, u1) R2O_XOR16(X1, u0) r2o_tail16(v);                                 // k = 64
+    R2O_MIRROR16(X7, u2) R2O_XOR16(X2, u1) R2O_XOR16(X1, u0) r2o_tail16(v);               // k = 128
+    R2O_MIRROR16(X15, u3) R2O_XOR16(X4, u2) R2O_XOR16(X2, u1) R2O_XOR16(X1, u0) r2o_tail16(v);   // k = 256
+    if (live && l16 < 12) {  // 192 = 12 lanes x 16 sorted depths
+        float* out = z_all + ray * (S + NI) + 16 * l16;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) *reinterpret_cast<f32x4*>(out + r) = f32x4{v[r], v[r + 1], v[r + 2], v[r + 3]};
+    }
+}
+#undef X1
+#undef X2
+#undef X3
+#undef X4
+#undef X7
+#undef X8
+#undef X15
+#undef R2O_TAKE
+#undef R2O_MIRROR16
+#undef R2O_XOR16
 
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
@@ -477,8 +687,13 @@ extern "C" int r2l_sample_pdf_sort(const float* z, const float* weights, const f
         return (int)hipErrorInvalidValue;
     }
     R2L_REQUIRE(z && weights && u && z_samples && z_all && u_stride >= 0, "r2l_sample_pdf_sort: a required pointer is NULL (only z_std is optional) or u_stride < 0");
-    hipLaunchKernelGGL(r2l_sample_pdf_sort_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z,
-                       weights, u, u_stride, z_samples, z_all, z_std, R, S, NI);
+    const bool aligned = ((((uintptr_t)z | (uintptr_t)weights | (uintptr_t)u | (uintptr_t)z_samples | (uintptr_t)z_all) & 15) == 0) && (u_stride & 3) == 0;
+    if (S == 64 && NI == 128 && aligned)  // the reference's configuration: a quarter wave per ray
+        hipLaunchKernelGGL(r2l_sample_pdf_sort16_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, z,
+                           weights, u, u_stride, z_samples, z_all, z_std, R);
+    else
+        hipLaunchKernelGGL(r2l_sample_pdf_sort_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z,
+                           weights, u, u_stride, z_samples, z_all, z_std, R, S, NI);
     R2L_CHECK(hipGetLastError());
     return 0;
 }

@@ -128,6 +128,44 @@ def test_sample_pdf_sort_golden(golden_dir):
         np.testing.assert_allclose(z_std.cpu().numpy(), torch.std(zs.cpu(), dim=-1, unbiased=False).numpy(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("S,NI,R", [(64, 128, 37), (64, 128, 4099), (64, 64, 9), (33, 77, 21), (16, 192, 5), (5, 3, 7)])
+def test_sample_pdf_sort_shapes_vs_oracle(S, NI, R):
+    """(64, 128): the quarter-wave-per-ray kernel (r2l_sample_pdf_sort16_kernel; 16 rays per workgroup: R = 37 / 4099 leave tail
+    rows), every other shape the one-ray-per-wave kernel: per-ray random u, samples vs the oracle's sample_pdf (helpers:283-330),
+    the merged depths exactly torch.sort's, z_std."""
+    from r2l_amd.render import sample_pdf_sort
+    g = torch.Generator().manual_seed(S * 1000 + NI)
+    z = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, -1)[0]
+    w = torch.rand(R, S, generator=g) ** 3
+    w[R // 2] = 0.  # an empty ray: uniform pdf from the 1e-5 floor
+    u = torch.rand(R, NI, generator=g)
+    mids = .5 * (z[:, 1:] + z[:, :-1])
+    ref = O.sample_pdf(mids, w[:, 1:-1], NI, det=False, u=u)
+    zs, z_all, z_std = sample_pdf_sort(z.cuda(), w.cuda(), NI, det=False, u=u)
+    # Conditioning: sample = b0 + (u - c0) / (c1 - c0) * (b1 - b0).  torch's CPU cumsum accumulates in double, the kernels sum
+    # left to right in fp32 (as torch's fp32 semantics say): c0 differs by up to 2 ulp at ~1 (2.4e-7), which a narrow cdf step
+    # (a bin holding 1e-4 of the ray's weight) amplifies by 1 / step — an fp32 emulation of the kernel's order on the CPU
+    # reproduces both the count (38 of 524 672 at R = 4099) and the size of the deviations.  Bar: 1e-5 + that term with margin.
+    # helpers:325 also replaces a step below 1e-5 by 1 — a discontinuity of the reference's own formula: where the step sits
+    # within rounding of 1e-5 the sample only has to stay in its bin.
+    pdf = (w[:, 1:-1] + 1e-5) / torch.sum(w[:, 1:-1] + 1e-5, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(pdf, -1)], -1)
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    below, above = (inds - 1).clamp(min=0), inds.clamp(max=cdf.shape[-1] - 1)
+    step = (torch.gather(cdf, 1, above) - torch.gather(cdf, 1, below)).numpy()
+    lo_edge, hi_edge = torch.gather(mids, 1, below).numpy(), torch.gather(mids, 1, above).numpy()
+    knife = np.abs(step - 1e-5) < 3e-7
+    assert knife.mean() < 1e-3
+    got = zs.cpu().numpy()
+    allowed = 1e-5 + 1e-5 * np.abs(ref.numpy()) + (hi_edge - lo_edge) * 4e-7 / np.maximum(step, 1e-5)
+    close = np.abs(got - ref.numpy()) <= allowed
+    assert (close | knife).all(), np.argwhere(~(close | knife))[:10]
+    assert (np.abs(got - ref.numpy()) > 1e-5 + 1e-5 * np.abs(ref.numpy())).mean() < 3e-4  # (and the amplified ones are rare)
+    assert ((got >= lo_edge - 1e-5) & (got <= hi_edge + 1e-5))[knife].all()
+    assert torch.equal(z_all.cpu(), torch.sort(torch.cat([z, zs.cpu()], -1), -1)[0])  # sorting is exact
+    np.testing.assert_allclose(z_std.cpu().numpy(), torch.std(zs.cpu(), dim=-1, unbiased=False).numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_teacher_mlp_vs_oracle():
     from r2l_amd.render import teacher_engine
     coarse, _ = O.make_teacher_state_dicts(11, 2, alpha_bias=0.5)
