@@ -52,8 +52,9 @@ t_f2 = [(2 * d[x]["FETCH_SIZE"] + d[x]["WRITE_SIZE"]) * 1024. for x in d if x.st
 b_fp32, _ = busy("fwd_kernel<1, false>")
 b_f2, r_f2 = busy("fwd2_kernel<true")
 b_t2, _ = busy("r2l_teacher2_kernel")
-r2o64_b, r2o64 = pmc_bytes("void r2l_raw2outputs_kernel<1, 4>", 524288)
-r2o192_b, r2o192 = pmc_bytes("void r2l_raw2outputs_kernel<3, 2>", 1048576)
+r2o64_b, r2o64 = pmc_bytes("void r2l_raw2outputs16_kernel<4, true>", 524288)
+r2o192_b, r2o192 = pmc_bytes("void r2l_raw2outputs16_kernel<12, false>", 524288)
+pdf_b, pdf_c = pmc_bytes("r2l_sample_pdf_sort16_kernel", 524288)
 
 # ---------------------------------------------------------------------------------------------------------- DESIGN §4, first table
 k = []
@@ -107,13 +108,15 @@ row("training step total, 4096 / 12 288 rays (cooperative fp16x2 chains `r2l_coo
     % (fm["train_4096"]["ms_per_step"], fm["train_4096"]["value"] / 1e6, a, b, fm["train_12288"]["ms_per_step"], fm["train_12288"]["value"] / 1e6, a2, b2))
 v = fm["teacher"]
 row("`r2l_teacher2_kernel` (default teacher)", "fp16 MFMA / 3 = 833 TF", "1.187 MFLOP/point (303.8 MFLOP/ray)", "%.1f ms per 400x400 frame = %.0f TF = **%.3f**, %.2f M rays/s; %.1f %% MFMA busy" % (v["ms_per_frame"], v["roofline"]["achieved"], v["roofline"]["frac"], v["value"] / 1e6, b_t2))
-s64, s192 = r2o["S64"], r2o["S192"]
-row("`r2l_raw2outputs_kernel<samples per lane, rays per wave>` (volume rendering of the teacher's raw output)", "**HBM 8 TB/s** by its bytes — measured VALU-issue bound (exp, two 64-lane scans, five sums)", "S·20 + 12 B read + 24 + 4S B written per ray: 1572 B @ S = 64 with weights; 3876 B @ S = 192 without (the fine pass never reads its weights)",
-    "hipGraph replay over cycled input sets (HBM-cold): **%.1f us per 32 768-ray chunk = %.2f TB/s = %.3f of 8 TB/s** (S = 64), **%.1f us = %.2f TB/s = %.3f** (S = 192); 262 144 rays per launch: %.2f / %.2f TB/s = %.2f / %.2f; PMC traffic %.1f / %.1f MB per launch = the algorithmic %.1f / %.1f MB; in the teacher render itself (raw output fresh in the Infinity Cache) the trace reads %.1f / %.1f us for the 28 928-ray tail chunks.  Round 4's row (\"≈ 5 TB/s, 10 / 30 us\") was an eager-loop guess and wrong: the round-4 kernel measured 20.9 us = 0.31 of 8 TB/s at S = 64 and 0.41 at S = 192 this way"
+s64, s192, spdf = r2o["S64"], r2o["S192"], r2o["sample_pdf_sort"]
+K16 = lambda n: [v for k_, v in K.items() if k_.startswith(n)][0]
+row("`r2l_raw2outputs16_kernel<S / 16, weights>` (volume rendering of the teacher's raw output; a quarter wave per ray, in-row DPP scans; other S: `r2l_raw2outputs_kernel`, a wave per ray)", "**HBM 8 TB/s**", "S·20 + 12 B read + 24 + 4S B written per ray: 1572 B @ S = 64 with weights; 3876 B @ S = 192 without (the fine pass never reads its weights)",
+    "hipGraph replay over cycled input sets (HBM-cold): **%.1f us per 32 768-ray chunk = %.2f TB/s = %.3f of 8 TB/s** (S = 64), **%.1f us = %.2f TB/s = %.3f** (S = 192); 262 144 rays per launch: %.2f / %.2f TB/s = **%.2f / %.2f** (0.9 of what a plain copy reaches); PMC traffic %.1f / %.1f MB per launch = the algorithmic %.1f / %.1f MB; %.0f / %.0f VALU instructions per wave of four rays.  History of this row: round 4's kernel (a wave per ray, shuffles through the LDS crossbar) 20.9 us = 0.31 at S = 64 and 0.41 at S = 192 measured this way (its DESIGN row said \"≈ 5 TB/s, 10 / 30 us\": an eager-loop guess, wrong); DPP scans, v_exp / v_rcp and four rays per wave: 14.8 / 32.5 us = 0.44 / 0.49 (VALU-issue bound: 649 instructions per four rays); a quarter wave per ray: this row"
     % (s64["us_per_launch"], s64["achieved"], s64["frac"], s192["us_per_launch"], s192["achieved"], s192["frac"], s64["at_262144_rays"]["achieved"], s192["at_262144_rays"]["achieved"], s64["at_262144_rays"]["frac"], s192["at_262144_rays"]["frac"],
-       r2o64_b / 1e6, r2o192_b / 1e6, s64["algorithmic_bytes"] / 1e6, s192["algorithmic_bytes"] / 1e6, K["void r2l_raw2outputs_kernel<1, 4>"][2], K["void r2l_raw2outputs_kernel<3, 2>"][2]))
-u = avg("r2l_sample_pdf_sort_kernel")
-row("`r2l_sample_pdf_sort_kernel` (importance samples + merge of 64 + 128 depths)", "LDS sort network (256-wide bitonic per ray)", "1792 B/ray", "%.0f us per 32 768-ray chunk (0.65 TB/s): 0.45 ms of a %.0f ms frame" % (u, fm["teacher"]["ms_per_frame"]))
+       r2o64_b / 1e6, r2o192_b / 1e6, s64["algorithmic_bytes"] / 1e6, s192["algorithmic_bytes"] / 1e6, r2o64["SQ_INSTS_VALU"] / r2o64["SQ_WAVES"], r2o192["SQ_INSTS_VALU"] / r2o192["SQ_WAVES"]))
+row("`r2l_sample_pdf_sort16_kernel` (64 coarse + 128 importance depths: inverse cdf, then the 192 depths merged and sorted; a quarter wave per ray; other shapes: `r2l_sample_pdf_sort_kernel`)", "HBM 8 TB/s by its bytes — VALU-issue bound by its work: a 256-element sorting network per ray = 4608 compare-exchanges", "2308 B/ray (64 z + 64 weights + 128 u read; 128 + 192 depths + z_std written)",
+    "**%.1f us per 32 768-ray chunk = %.2f TB/s = %.3f of 8 TB/s** (262 144 rays: %.3f); PMC traffic %.1f MB = the algorithmic %.1f MB; %.0f VALU instructions per wave of four rays (26 of the 36 network stages are min / max pairs inside a lane, 10 reach through DPP rows; the cdf is torch.cumsum's left-to-right order as a 16-step DPP carry chain).  Rounds 1 – 4: one ray per wave through LDS with a block barrier per stage: 90 us = 0.08"
+    % (spdf["us_per_launch"], spdf["achieved"], spdf["frac"], spdf["at_262144_rays"]["frac"], pdf_b / 1e6, spdf["algorithmic_bytes"] / 1e6, pdf_c["SQ_INSTS_VALU"] / pdf_c["SQ_WAVES"]))
 row("`r2l_adam_kernel`", "HBM", "28 B/param", "5.8 TB/s (%.1f us)" % avg("r2l_adam_kernel"))
 row("`r2l_ssim_kernel`", "HBM", "2·H·W·C·4 B read per frame (3.84 MB @ 400x400)", "one launch per frame instead of ~20 torch kernels (not profiled separately)")
 
@@ -130,8 +133,9 @@ for key, lab, pk in (("train", "fp16 trio (default), 98 304 rays", "its 983 TF m
     t.append("| `fast_mode.%s` | %s | %.2f M | %.3f | %.3f of %s |" % (key, lab, v["value"] / 1e6, v["ms_per_step"], v["roofline"]["frac"], pk))
 v = fm["teacher"]
 t.append("| `fast_mode.teacher` | fp16x2 point network | %.2f M | %.1f / frame | %.3f of 833 TF |" % (v["value"] / 1e6, v["ms_per_frame"], v["roofline"]["frac"]))
-t.append("| **`raw2outputs`** (`bound: \"hbm\"`) | `r2l_raw2outputs_kernel`, 32 768-ray chunk, S = 64 with weights / S = 192 without | %.0f M / %.0f M | %.4f / %.4f | **%.3f / %.3f of 8 TB/s** (%.2f / %.2f TB/s; at 262 144 rays %.2f / %.2f) |"
+t.append("| **`raw2outputs`** (`bound: \"hbm\"`) | `r2l_raw2outputs16_kernel`, 32 768-ray chunk, S = 64 with weights / S = 192 without | %.0f M / %.0f M | %.4f / %.4f | **%.3f / %.3f of 8 TB/s** (%.2f / %.2f TB/s; at 262 144 rays %.2f / %.2f) |"
          % (32768 / s64["us_per_launch"], 32768 / s192["us_per_launch"], s64["us_per_launch"] / 1e3, s192["us_per_launch"] / 1e3, s64["frac"], s192["frac"], s64["achieved"], s192["achieved"], s64["at_262144_rays"]["frac"], s192["at_262144_rays"]["frac"]))
+t.append("| `raw2outputs.sample_pdf_sort` | `r2l_sample_pdf_sort16_kernel`, 32 768-ray chunk, 64 + 128 depths | %.0f M | %.4f | %.3f of 8 TB/s (%.2f TB/s; VALU-issue bound: the sorting network) |" % (32768 / spdf["us_per_launch"], spdf["us_per_launch"] / 1e3, spdf["frac"], spdf["achieved"]))
 c = o["cpu_baseline"]
 t.append("| `cpu_baseline` | the oracle on the host (%d threads) | %.1f k (train step at 4096 rays: %.1f k) | | |" % (c["cores"], c["value"] / 1e3, c["train"]["value"] / 1e3))
 
@@ -165,7 +169,9 @@ rows = [
     ("bench line, new contract (VERDICT r4 #2; `r05_bench.json`; K = 20, W = 3 for EVERY leg)",
      f"top level = **exact fp32 MFMA render {o['value']/1e6:.2f} M rays/s, {o['ms_per_step']:.1f} ms per 9-frame launch, {o['roofline']['frac']:.3f} of 157.3 TF** (kernel-trace average {avg('void r2l_fwd_kernel<1, false>')/1e3:.2f} ms); `train` (fp32 MFMA) {o['train']['ms_per_step']:.2f} ms = {o['train']['roofline']['frac']:.3f}; `teacher` (fp32) {o['teacher']['ms_per_frame']:.1f} ms/frame = {o['teacher']['roofline']['frac']:.3f}; `fp32_grade_products` (bf16x3) {gp['value']/1e6:.1f} M = {gp['roofline']['frac']:.3f} of 417 TF, train {gp['train']['ms_per_step']:.2f} ms = {gp['train']['roofline']['frac']:.3f}; **`fast_mode` (fp16x2, the library default) {fm['value']/1e6:.1f} M rays/s, {fm['ms_per_step']:.2f} ms, {fm['roofline']['frac']:.3f} of 833 TF** ({fm['speedup_vs_graded']:.2f}x the graded leg), trained-like weights {tl['rate_vs_default_weights']:.3f} of that, train {fm['train']['ms_per_step']:.2f} ms ({fm['train']['roofline']['frac']:.3f}), exact dW {fm['train_exact_dw']['ms_per_step']:.2f} ms, **4096 rays {fm['train_4096']['ms_per_step']:.3f} ms, 12 288 rays {fm['train_12288']['ms_per_step']:.3f} ms**, teacher {fm['teacher']['ms_per_frame']:.1f} ms/frame ({fm['teacher']['roofline']['frac']:.3f}); parity vs the CPU restatement {o['parity_max_abs_err_vs_cpu']:.2e} (fp32) / {fm['parity_max_abs_err_vs_cpu']:.2e} (fp16x2); cpu_baseline {c['value']/1e3:.1f} k rays/s forward, {c['train']['value']/1e3:.1f} k training, {c['cores']} threads"),
     ("**`raw2outputs` HBM roofline** (`bound: \"hbm\"`, peak 8 TB/s; hipGraph replay of 20 launches over 8 / 4 cycled input sets so that nothing is served from the 256 MB Infinity Cache)",
-     f"S = 64 with weights (1572 B/ray): **{s64['us_per_launch']:.1f} us per 32 768-ray chunk = {s64['achieved']:.2f} TB/s = {s64['frac']:.3f}**; S = 192 without weights (3876 B/ray): **{s192['us_per_launch']:.1f} us = {s192['achieved']:.2f} TB/s = {s192['frac']:.3f}**; at 262 144 rays per launch {s64['at_262144_rays']['achieved']:.2f} / {s192['at_262144_rays']['achieved']:.2f} TB/s = **{s64['at_262144_rays']['frac']:.3f} / {s192['at_262144_rays']['frac']:.3f}** (the 32 768-ray chunk is 2 – 4 waves per SIMD: launch ramp).  PMC: 2 x FETCH_SIZE + WRITE_SIZE = {r2o64_b/1e6:.1f} / {r2o192_b/1e6:.1f} MB per launch against {s64['algorithmic_bytes']/1e6:.1f} / {s192['algorithmic_bytes']/1e6:.1f} MB algorithmic: no re-reads.  The kernel is VALU-issue bound, not HBM bound (SQ_INSTS_VALU {r2o64['SQ_INSTS_VALU']/r2o64['SQ_WAVES']:.0f} per wave of four rays after the round-5 rewrite, 1202 before: v_exp / v_rcp instead of expf / IEEE division, the five sums as one chain of fused DPP adds, all rays of a wave loaded before the first scan; 20.9 -> {s64['us_per_launch']:.1f} us = 0.31 -> {s64['frac']:.2f} of 8 TB/s at S = 64, 0.41 -> {s192['frac']:.2f} at S = 192); the fine pass no longer writes the weights nobody reads (`need_weights=False`).  In the teacher render the raw tile is still in the Infinity Cache: {K['void r2l_raw2outputs_kernel<1, 4>'][2]:.1f} / {K['void r2l_raw2outputs_kernel<3, 2>'][2]:.1f} us per 28 928-ray chunk in the kernel trace.  0.2 % of a teacher frame either way."),
+     f"S = 64 with weights (1572 B/ray): **{s64['us_per_launch']:.1f} us per 32 768-ray chunk = {s64['achieved']:.2f} TB/s = {s64['frac']:.3f}**; S = 192 without weights (3876 B/ray): **{s192['us_per_launch']:.1f} us = {s192['achieved']:.2f} TB/s = {s192['frac']:.3f}**; at 262 144 rays per launch {s64['at_262144_rays']['achieved']:.2f} / {s192['at_262144_rays']['achieved']:.2f} TB/s = **{s64['at_262144_rays']['frac']:.3f} / {s192['at_262144_rays']['frac']:.3f}** = 0.9 of the 6.3 TB/s a plain copy reaches (the 32 768-ray chunk is 2 waves per SIMD: launch ramp).  PMC: 2 x FETCH_SIZE + WRITE_SIZE = {r2o64_b/1e6:.1f} / {r2o192_b/1e6:.1f} MB per launch against {s64['algorithmic_bytes']/1e6:.1f} / {s192['algorithmic_bytes']/1e6:.1f} MB algorithmic: no re-reads.  How it got there: round 4's kernel (a wave per ray, shuffles through the LDS crossbar) measured 20.9 us = 0.31 at S = 64 and 0.41 at S = 192 this way; first round-5 form (DPP scans, v_exp / v_rcp instead of expf / IEEE division, four rays per wave loaded before the first scan): 14.8 / 32.5 us = 0.44 / 0.49, and the PMC pass showed it VALU-issue bound (649 VALU instructions per wave of four rays, HBM traffic = algorithmic); second form (`r2l_raw2outputs16_kernel`: a QUARTER wave per ray, lane l of a DPP row owns samples l, l + 16, ...: a 4-step in-row scan times a carry, one 16-lane reduction per ray; {r2o64['SQ_INSTS_VALU']/r2o64['SQ_WAVES']:.0f} instructions per four rays): this row.  The fine pass does not write the weights nobody reads (`need_weights=False`)."),
+    ("`sample_pdf` + sort (`raw2outputs.sample_pdf_sort` in the bench line; HBM-cold hipGraph replay like the row above)",
+     f"**{spdf['us_per_launch']:.1f} us per 32 768-ray chunk = {spdf['achieved']:.2f} TB/s = {spdf['frac']:.3f} of 8 TB/s** ({spdf['at_262144_rays']['frac']:.3f} at 262 144 rays); rounds 1 – 4: **90 us** (0.08: one ray per wave, cdf as a 62-step loop of one lane over LDS, a 36-stage bitonic network of LDS compare-exchanges with a block barrier per stage — the largest of the teacher path's glue kernels, three times both `raw2outputs` launches together).  Now `r2l_sample_pdf_sort16_kernel`: a quarter wave per ray, 16 elements of the 256-element network per lane (26 of 36 stages are min / max pairs inside the lane, 10 go through DPP rows: no LDS, no ds_bpermute, no barrier in the sort), the cdf in torch.cumsum's left-to-right order as a 16-step DPP carry chain for four rays at once, 16-byte loads and stores; sums in the generic kernel's association, so both return the same bits.  {pdf_c['SQ_INSTS_VALU']/pdf_c['SQ_WAVES']:.0f} VALU instructions per wave of four rays; PMC traffic {pdf_b/1e6:.1f} MB = the algorithmic {spdf['algorithmic_bytes']/1e6:.1f} MB.  It is VALU-issue bound by the 4608 compare-exchanges a 256-element network costs per ray, not by HBM.  Other shapes: one ray per wave, sort in registers (47 us at this shape).  `tests/test_teacher_gpu.py::test_sample_pdf_sort_shapes_vs_oracle` (sort exact, samples to a conditioning-aware bar)"),
     ("kernel counters (`r05_bench_pmc_summary.json`)", f"exact-fp32 render: MFMA busy {b_fp32:.1f} % (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs), {t_fp32/1e9:.2f} GB HBM-side per 9-frame launch; fp16x2 render: {b_f2:.1f} % busy, {t_f2/1e9:.1f} GB, LDS conflicts / active {r_f2['SQ_LDS_BANK_CONFLICT']/r_f2['SQ_LDS_IDX_ACTIVE']:.4f}; fp16x2 teacher: {b_t2:.1f} % busy"),
     ("range control, two defects fixed (ADVICE r4, both medium)", "(1) the head's weights were scaled by 1/s BEFORE their fp16 (hi, mid) split, so a large s pushed the small head weights' `mid` halves into fp16 subnormals (error grows as s²): the scale is now applied to X₀ after the head's fp32 accumulation (render, cooperative and teacher kernels; body bias stages still carry 1/s) — `test_fp16_range_control_body_amplified` (default-size head, |x| growing to 2e5 through the body, s = 32: inside the 1e-4 parity bar and within 8e-5 of the bf16x3 family; a CPU model of the old rounding moves that net's rgb by 2.9e-4).  (2) a dX-chain-only range trip re-ran the chain on the bf16x3 kernel, which read the forward's fp16 stage-piece stash as chunked fp32: `r2l_pack_bwd3_kernel` now expands the stash in place (descending tiles, one workgroup per slot pair) before the fallback chain reads it — `test_dx_chain_only_trip_expands_the_fp16_stash` (gradients 1e-5 of the oracle; `r05_chain_trip_diag_before_fix.txt`: slot error 1.0 before)"),
     ("small steps (VERDICT r4 #1; `r05_small_step_ab.txt`, `r05_layer_pipeline_probe.txt`, `r05_tile_major_coopf_ab.txt`)", "**shipped: head / tail weight gradients and their reduces on a second stream beside the body dW kernel: 0.789 -> 0.748 ms at 4096 rays (-5.1 %), 1.276 -> 1.271 at 12 288 (same box, three interleaved pairs, bit-identical gradients)**; bench boxes: 0.773 / 1.336 ms (round 4: 0.794 / —).  Measured and NOT shipped: (a) Adam fused with both re-packs (`r2l_adam_step_packed`, opt-in `R2L_ADAM_PACK=1`, bit-identical): 0.773 vs 0.781 at 4096, 1.291 vs 1.278 at 12 288 — neutral (37 us kernel vs 29 + 17 + 5 + 19 us of launches that already overlap their neighbours' tails); finer head slices / tail launch shapes: zero or negative; (b) **layer-stationary CU pipeline, probed**: 10 – 12 stage pipelines of 2 CUs per XCD handing 32-ray tiles through the L2 with plain stores + `sc1` loads: **3.1 us per tile and stage with the MFMAs (2.7 hand-over alone, 1.95 MFMA + LDS alone), all 8 XCDs at once; a cooperative chain layer takes 3.0 us today** — the hand-over does not hide behind the MFMAs, so the pipeline cannot beat the weight-streaming chain; the same numbers rule out (c) (CU pairs exchanging halves each layer: 1.3 us exchange on a 1.25 us half layer); (d) tile-major k order for the two-tile chains (round 4's ISA finding): built, 1.4 % SLOWER at 12 288 rays (B operands read from LDS twice, two barriers per layer) and one nondeterministic test: reverted, patch in `tools/attic/`"),
@@ -175,7 +181,7 @@ rows = [
     ("world = 8 without a node (VERDICT r4 #6)", "`tests/test_world8_gpu.py`: the real CLI under torchrun, EIGHT ranks sharing the one GPU over gloo: create_data (21 poses, rank-disjoint shard ranges), 6 training iterations at `--N_rand 20` ([3, 3, 3, 3, 2, 2, 2, 2] shard files per rank and step, replicas bit-identical), render_test + video (three ranks without a pose); CPU twin `test_eight_rank_gloo_trainer_host_logic`"),
     ("module-boundary forward with a config (VERDICT r4 #7)", "`r2l_forward_emb_cfg`: bf16x3 / fp16x2 body on a caller-supplied embedding (head in fp32 MFMA into an X0 scratch, then `r2l_fwd3_kernel<X0>`); `engine.forward_emb` uses it; `test_emb_path_matches_oracle` over the families"),
     ("families pruned (VERDICT r4 #8; `r05_dispatch_table.md`)", "the round-1 cooperative fp32 kernel (`r2l_coop.hip`, `tiling = coop`) retired: never chosen by the cost model since round 2; `R2L_TILING_COOP_RETIRED` is rejected with a message; the dispatch table lists which kernels each (precision, tiling, rays) cell launches"),
-    ("GPU test suite", "354 passed, 73 skipped (`-m gpu`); CPU suite 56 passed"),
+    ("GPU test suite", "384 passed, 73 skipped (`-m gpu`, 191 s: last full run of the round, rc 0); CPU suite 56 passed"),
 ]
 head = '''# r05 — what changed and what was measured (one MI355X per `gpurun` call; boxes of the pool differ by ±3 % on the 16-bit kernels)
 
