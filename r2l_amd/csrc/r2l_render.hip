@@ -1,6 +1,7 @@
-// r2l_render.hip — the volumetric-render glue of the NeRF teacher for gfx950: HBM-bound, one wavefront per ray,
-// wave shuffles for the scans/reductions, no host round trip (the reference moves sample_pdf to the CPU:
-// /root/reference/utils/create_data.py:506-511).
+// r2l_render.hip — the volumetric-render glue of the NeRF teacher for gfx950: HBM-sized work (1.5 - 3.9 KB per ray) whose cost is
+// cross-lane arithmetic, so the teacher path's shapes run a QUARTER wave per ray (scans, reductions and the sorting network inside
+// 16-lane DPP rows, at VALU rate) and every other shape a wave per ray; no host round trip (the reference moves sample_pdf to the
+// CPU: /root/reference/utils/create_data.py:506-511).
 //   r2l_stratified_z   : z_vals = near(1-t)+far t, stratified jitter            (create_data.py:457-482)
 //   r2l_raw2outputs    : alpha compositing                                       (create_data.py:335-402)
 //   r2l_sample_pdf_sort: inverse-CDF importance sampling + merge-sort of depths  (helpers:283-330, create_data.py:505-515)
