@@ -181,6 +181,7 @@ rows = [
     ("world = 8 without a node (VERDICT r4 #6)", "`tests/test_world8_gpu.py`: the real CLI under torchrun, EIGHT ranks sharing the one GPU over gloo: create_data (21 poses, rank-disjoint shard ranges), 6 training iterations at `--N_rand 20` ([3, 3, 3, 3, 2, 2, 2, 2] shard files per rank and step, replicas bit-identical), render_test + video (three ranks without a pose); CPU twin `test_eight_rank_gloo_trainer_host_logic`"),
     ("module-boundary forward with a config (VERDICT r4 #7)", "`r2l_forward_emb_cfg`: bf16x3 / fp16x2 body on a caller-supplied embedding (head in fp32 MFMA into an X0 scratch, then `r2l_fwd3_kernel<X0>`); `engine.forward_emb` uses it; `test_emb_path_matches_oracle` over the families"),
     ("families pruned (VERDICT r4 #8; `r05_dispatch_table.md`)", "the round-1 cooperative fp32 kernel (`r2l_coop.hip`, `tiling = coop`) retired: never chosen by the cost model since round 2; `R2L_TILING_COOP_RETIRED` is rejected with a message; the dispatch table lists which kernels each (precision, tiling, rays) cell launches"),
+    ("end to end (`r05_e2e.txt`)", "CLI training loop 7.82 ms/iter at 98 304 rays (step alone 7.75); `create_data` 120.1 ms/pose over 12 poses incl. start-up (round 4: 121.3); `--render_test` loop with PSNR + SSIM + 2 PNGs per frame 4.8 – 5.0 ms/frame over 200 frames (4.5 – 4.6 without images)"),
     ("GPU test suite", "384 passed, 73 skipped (`-m gpu`, 191 s: last full run of the round, rc 0); CPU suite 56 passed"),
 ]
 head = '''# r05 — what changed and what was measured (one MI355X per `gpurun` call; boxes of the pool differ by ±3 % on the 16-bit kernels)
@@ -189,7 +190,7 @@ Files: `r05_bench.json` (the bench line of `tools/r05_profile.sh`), `r05_bench_k
 same command), `r05_bench_pmc_summary.json` (separate `--pmc` passes, incl. passes over `tools/r2o_time.py` and `tools/teacher_time.py`),
 `r05_small_step_ab.txt`, `r05_stash_store_ab.txt`, `r05_tile_major_coopf_ab.txt` (same-box A/Bs), `r05_layer_pipeline_probe.txt`
 (`tools/layer_pipeline_probe.hip`), `r05_train_equivalence_seeds.txt`, `r05_chain_trip_diag_before_fix.txt`, `r05_dispatch_table.md`,
-`r05_bench_call1.json` (the first bench line of the round, before the kernel work).  This file and the two tables at the head of DESIGN.md §4
+`r05_bench_call1.json`, `r05_bench_call9.json` (earlier bench lines of the round: before the kernel work / before the quarter-wave glue kernels, on a box 3 % faster on the 16-bit kernels), `r05_e2e.txt` (the three CLI pipelines end to end).  This file and the two tables at the head of DESIGN.md §4
 are generated from the JSONs / CSV by `tools/make_r05_summary.py`.
 
 | item | result |
