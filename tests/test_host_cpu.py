@@ -118,6 +118,11 @@ def test_bad_arguments_are_error_codes_not_device_faults():
     assert lib.r2l_forward_poses_cfg(one, 0, 400, 400, 555., one, one, one, 43, one, None, None) == 0  # K = 0
     assert lib.r2l_forward_poses_cfg(one, 2, 400, 400, 555., None, one, one, 43, one, None, None) == INVALID
     assert lib.r2l_forward_emb(None, one, one, 43, one, None, None, 32, None) == INVALID
+    bf = _lib.make_config(precision="bf16x3")
+    assert lib.r2l_forward_emb_cfg(None, one, one, 43, one, None, None, 32, one, None, ctypes.byref(bf)) == INVALID      # emb (bf16x3 path)
+    assert lib.r2l_forward_emb_cfg(None, one, one, 43, one, None, None, 32, None, None, ctypes.byref(bf)) == INVALID     # ... -> r2l_forward_emb
+    assert lib.r2l_forward_emb_cfg(one, one, one, 5000, one, None, None, 32, one, None, ctypes.byref(bf)) == INVALID     # n_block
+    assert lib.r2l_forward_emb_cfg(None, None, None, 43, None, None, None, 0, None, None, ctypes.byref(bf)) == 0         # N = 0
     assert lib.r2l_pack_forward(None, 43, one, None) == INVALID and lib.r2l_pack_backward(one, 43, None, None) == INVALID
     assert lib.r2l_pack_forward_layout(one, 43, one, 5, None) == INVALID and lib.r2l_pack_backward_layout(one, 5000, one, 2, None) == INVALID
     args = [one] * 12 + [43, 1e-5] + [one] * 6 + [4096, None]
@@ -134,6 +139,9 @@ def test_bad_arguments_are_error_codes_not_device_faults():
     assert lib.r2l_adam_step(None, one, one, one, 10, 1e-3, .9, .999, 1e-8, 1, 1., None) == INVALID
     assert lib.r2l_adam_step(one, one, one, one, 10, 1e-3, .9, .999, 1e-8, 0, 1., None) == INVALID  # step counts from 1
     assert lib.r2l_adam_step(None, None, None, None, 0, 1e-3, .9, .999, 1e-8, 1, 1., None) == 0
+    assert lib.r2l_adam_step_packed(one, one, one, one, 43, 1e-3, .9, .999, 1e-8, 1, 1., None, None, one, None) == INVALID  # wstream_fwd
+    assert lib.r2l_adam_step_packed(one, one, one, one, 43, 1e-3, .9, .999, 1e-8, 0, 1., None, one, one, None) == INVALID   # step
+    assert lib.r2l_adam_step_packed(one, one, one, one, 5000, 1e-3, .9, .999, 1e-8, 1, 1., None, one, one, None) == INVALID
     assert lib.r2l_loss_finish(one, 3, 1., None, None) == INVALID
     assert lib.r2l_pack_teacher(None, one, None) == INVALID
     assert lib.r2l_teacher_mlp(one, one, one, one, one, one, None, 4, 64, None) == INVALID
