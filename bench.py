@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0; its last key "summary" is a digest of every leg.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -661,7 +662,15 @@ def main():
     out["leg_wall_s"] = {k: round(v, 3) for k, v in LEG_WALL.items()}  # rank 0's host wall per leg, warm-up and set-up included
     out["summary"] = summary_of(out)  # LAST key: a compact digest of every leg (records that keep only the tail of this line still hold it)
     if rank == 0:
-        print(json.dumps(out))
+        def finite(o):  # strict JSON has no Infinity / NaN (an unused head-room reads inf): null instead
+            if isinstance(o, float):
+                return o if math.isfinite(o) else None
+            if isinstance(o, dict):
+                return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [finite(v) for v in o]
+            return o
+        print(json.dumps(finite(out), allow_nan=False))
     if distributed:
         dist.destroy_process_group()
 
