@@ -1365,10 +1365,14 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         static hipStream_t side[16] = {nullptr};
         static hipEvent_t ev_fork[16], ev_join[16];
         static int overlap_off = -1;
-        if (overlap_off < 0) overlap_off = r2l_env_on("R2L_NO_DW_OVERLAP") ? 1 : 0;
+        static int64_t overlap_max = R2L_COOPF_MAX_RAYS;
+        if (overlap_off < 0) {
+            overlap_off = r2l_env_on("R2L_NO_DW_OVERLAP") ? 1 : 0;
+            if (const char* e = getenv("R2L_DW_OVERLAP_MAX_RAYS")) overlap_max = atoll(e);  // (tuning knob: tools/r05_run19.sh)
+        }
         int dev = 0;
         if (!overlap_off && (parts & R2L_BWD_BODY) && (parts & R2L_BWD_HEAD) && layer_hi > layer_lo && dw_slab != nullptr &&
-            N <= R2L_COOPF_MAX_RAYS && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+            N <= overlap_max && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
             if (side[dev] == nullptr) {
                 R2L_CHECK(hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking));
                 R2L_CHECK(hipEventCreateWithFlags(&ev_fork[dev], hipEventDisableTiming));
