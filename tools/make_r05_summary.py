@@ -175,6 +175,7 @@ rows = [
     ("kernel counters (`r05_bench_pmc_summary.json`)", f"exact-fp32 render: MFMA busy {b_fp32:.1f} % (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs), {t_fp32/1e9:.2f} GB HBM-side per 9-frame launch; fp16x2 render: {b_f2:.1f} % busy, {t_f2/1e9:.1f} GB, LDS conflicts / active {r_f2['SQ_LDS_BANK_CONFLICT']/r_f2['SQ_LDS_IDX_ACTIVE']:.4f}; fp16x2 teacher: {b_t2:.1f} % busy"),
     ("range control, two defects fixed (ADVICE r4, both medium)", "(1) the head's weights were scaled by 1/s BEFORE their fp16 (hi, mid) split, so a large s pushed the small head weights' `mid` halves into fp16 subnormals (error grows as s²): the scale is now applied to X₀ after the head's fp32 accumulation (render, cooperative and teacher kernels; body bias stages still carry 1/s) — `test_fp16_range_control_body_amplified` (default-size head, |x| growing to 2e5 through the body, s = 32: inside the 1e-4 parity bar and within 8e-5 of the bf16x3 family; a CPU model of the old rounding moves that net's rgb by 2.9e-4).  (2) a dX-chain-only range trip re-ran the chain on the bf16x3 kernel, which read the forward's fp16 stage-piece stash as chunked fp32: `r2l_pack_bwd3_kernel` now expands the stash in place (descending tiles, one workgroup per slot pair) before the fallback chain reads it — `test_dx_chain_only_trip_expands_the_fp16_stash` (gradients 1e-5 of the oracle; `r05_chain_trip_diag_before_fix.txt`: slot error 1.0 before)"),
     ("small steps (VERDICT r4 #1; `r05_small_step_ab.txt`, `r05_layer_pipeline_probe.txt`, `r05_tile_major_coopf_ab.txt`)", "**shipped: head / tail weight gradients and their reduces on a second stream beside the body dW kernel: 0.789 -> 0.748 ms at 4096 rays (-5.1 %), 1.276 -> 1.271 at 12 288 (same box, three interleaved pairs, bit-identical gradients)**; bench boxes: 0.773 / 1.336 ms (round 4: 0.794 / —).  Measured and NOT shipped: (a) Adam fused with both re-packs (`r2l_adam_step_packed`, opt-in `R2L_ADAM_PACK=1`, bit-identical): 0.773 vs 0.781 at 4096, 1.291 vs 1.278 at 12 288 — neutral (37 us kernel vs 29 + 17 + 5 + 19 us of launches that already overlap their neighbours' tails); finer head slices / tail launch shapes: zero or negative; (b) **layer-stationary CU pipeline, probed**: 10 – 12 stage pipelines of 2 CUs per XCD handing 32-ray tiles through the L2 with plain stores + `sc1` loads: **3.1 us per tile and stage with the MFMAs (2.7 hand-over alone, 1.95 MFMA + LDS alone), all 8 XCDs at once; a cooperative chain layer takes 3.0 us today** — the hand-over does not hide behind the MFMAs, so the pipeline cannot beat the weight-streaming chain; the same numbers rule out (c) (CU pairs exchanging halves each layer: 1.3 us exchange on a 1.25 us half layer); (d) tile-major k order for the two-tile chains (round 4's ISA finding): built, 1.4 % SLOWER at 12 288 rays (B operands read from LDS twice, two barriers per layer) and one nondeterministic test: reverted, patch in `tools/attic/`"),
+    ("98 304-ray step: head / tail gradients beside the body's kernel (`r05_large_step_overlap_ab.txt`)", "both kernels take every register of a CU, so the overlap of the small steps does nothing beside a 256-workgroup body kernel; with 192 body workgroups (43 chunk units each) and the overlap: 7.48 vs 7.60 ms (box 1), 7.58 vs 7.63 (box 2): −0.7 … −1.5 %, a narrow, non-monotonic optimum inside the box-to-box spread: measured, knobs kept (`R2L_DW_OVERLAP_MAX_RAYS`, `R2L_DW_WGS`), default unchanged"),
     ("stash stores of the training chains (VERDICT r4 #3; `r05_stash_store_ab.txt`)", "timing build without the stores: forward 2.908 -> 2.675 ms, dX chain 2.841 -> 2.584 ms: **0.49 ms = 6.5 % of the step is the price of the 9 GB of stash**, which the weight-gradient kernels need; cache policy of the stores: plain +0.8 %, `nt` = round 4, **`nt sc1` -0.6 % (7.541 vs 7.588 ms): shipped**.  The ≤ 2.7 ms forward VERDICT asked for equals the no-store build"),
     ("fp16 weight gradients: are they equivalent? (VERDICT r4 #4; `r05_train_equivalence_seeds.txt`)", "12 000 steps of 16 384 rays per run, held-out PSNR mean ± seed std: fp16 trio (default) 25.604 ± 0.182 dB and exact-fp32 MFMA 25.554 ± 0.165 dB over 8 seeds each, bf16x3 trio 25.543 ± 0.220 and fp16 trio with exact dW 25.490 ± 0.150 over 4: default − fp32, paired by seed, +0.050 ± 0.225 dB, standard error 0.079 dB (both signs, no trend) against 0.17 – 0.22 dB between two seeds of ONE family: statistically indistinguishable; the default stays fp16 dW"),
     ("inline-asm MFMA operands for the render kernel (VERDICT r4 #5)", "not built.  The lever (pin the B operands in AGPRs to shed the v_accvgpr copies) was tried through the compiler first: `-mllvm -amdgpu-mfma-vgpr-form` crashes clang (exit 139) on r2l_fwd2.hip; hand-placed asm for 195 MFMAs per layer with the ring schedule would replace the kernel's whole scheduling contract — a 1 – 2 % expectation (3.2 VALU per MFMA is dominated by the operand split, not the copies: `r04_kernel_resources.txt`).  Recorded as a negative decision, DESIGN §7"),
