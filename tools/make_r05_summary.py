@@ -182,6 +182,10 @@ rows = [
     ("world = 8 without a node (VERDICT r4 #6)", "`tests/test_world8_gpu.py`: the real CLI under torchrun, EIGHT ranks sharing the one GPU over gloo: create_data (21 poses, rank-disjoint shard ranges), 6 training iterations at `--N_rand 20` ([3, 3, 3, 3, 2, 2, 2, 2] shard files per rank and step, replicas bit-identical), render_test + video (three ranks without a pose); CPU twin `test_eight_rank_gloo_trainer_host_logic`"),
     ("module-boundary forward with a config (VERDICT r4 #7)", "`r2l_forward_emb_cfg`: bf16x3 / fp16x2 body on a caller-supplied embedding (head in fp32 MFMA into an X0 scratch, then `r2l_fwd3_kernel<X0>`); `engine.forward_emb` uses it; `test_emb_path_matches_oracle` over the families"),
     ("families pruned (VERDICT r4 #8; `r05_dispatch_table.md`)", "the round-1 cooperative fp32 kernel (`r2l_coop.hip`, `tiling = coop`) retired: never chosen by the cost model since round 2; `R2L_TILING_COOP_RETIRED` is rejected with a message; the dispatch table lists which kernels each (precision, tiling, rays) cell launches"),
+    ("three boxes, three bench lines (`r05_bench_call9.json`, `r05_bench.json` = call 13, `r05_bench_call18.json`: the same command; calls 13 and 18 on the final kernels)",
+     "; ".join("%s: %s" % (lab, " / ".join(fmt % (json.load(open(P(f)))["summary"][key][idx]) for f in ("r05_bench_call9.json", "r05_bench.json", "r05_bench_call18.json")))
+               for lab, key, idx, fmt in (("graded render ms per launch", "graded_render_fp32_mfma", 1, "%.1f"), ("graded train ms", "graded_train_fp32_mfma", 1, "%.2f"), ("fast render ms per launch", "fast_render_fp16x2", 1, "%.2f"), ("fast train ms", "fast_train", 1, "%.2f"), ("4096-ray step ms", "fast_train_4096", 1, "%.3f"), ("fast teacher ms per frame", "fast_teacher", 1, "%.1f")))
+     + ": the exact-fp32 render is the same to 0.2 % everywhere (it runs at the nominal clock, 1.1 kW); everything that runs against the power cap moves by 3 – 7 % with the box"),
     ("end to end (`r05_e2e.txt`)", "CLI training loop 7.82 ms/iter at 98 304 rays (step alone 7.75); `create_data` 120.1 ms/pose over 12 poses incl. start-up (round 4: 121.3); `--render_test` loop with PSNR + SSIM + 2 PNGs per frame 4.8 – 5.0 ms/frame over 200 frames (4.5 – 4.6 without images)"),
     ("GPU test suite", "384 passed, 73 skipped (`-m gpu`, 191 s: last full run of the round, rc 0); CPU suite 56 passed"),
 ]
@@ -191,7 +195,7 @@ Files: `r05_bench.json` (the bench line of `tools/r05_profile.sh`), `r05_bench_k
 same command), `r05_bench_pmc_summary.json` (separate `--pmc` passes, incl. passes over `tools/r2o_time.py` and `tools/teacher_time.py`),
 `r05_small_step_ab.txt`, `r05_stash_store_ab.txt`, `r05_tile_major_coopf_ab.txt` (same-box A/Bs), `r05_layer_pipeline_probe.txt`
 (`tools/layer_pipeline_probe.hip`), `r05_train_equivalence_seeds.txt`, `r05_chain_trip_diag_before_fix.txt`, `r05_dispatch_table.md`,
-`r05_bench_call1.json`, `r05_bench_call9.json` (earlier bench lines of the round: before the kernel work / before the quarter-wave glue kernels, on a box 3 % faster on the 16-bit kernels), `r05_e2e.txt` (the three CLI pipelines end to end).  This file and the two tables at the head of DESIGN.md §4
+`r05_bench_call1.json`, `r05_bench_call9.json` (earlier bench lines of the round: before the kernel work / before the quarter-wave glue kernels, on a box 3 % faster on the 16-bit kernels), `r05_bench_call18.json` (the last bench line of the round, a third box; its `raw2outputs.*.traffic` fields are filled from the PMC summary), `r05_e2e.txt` (the three CLI pipelines end to end), `r05_large_step_overlap_ab.txt`.  This file and the two tables at the head of DESIGN.md §4
 are generated from the JSONs / CSV by `tools/make_r05_summary.py`.
 
 | item | result |
