@@ -4,8 +4,9 @@ of 400x400 per launch (the bench workload), three weight sets:
     default      nn.Linear default init (the bench's weights)
     fp16-exact   the same weights rounded to fp16: the `mid` halves of all weights are exactly zero (one of the three fp16 products of
                  every fp32 product multiplies zeros)
-    zero body    body and tail weights zero, head as default: the activations are zero from the first body layer on (the MFMAs of 86 of
-                 88 layers multiply zeros; loads, LDS traffic, operand splits, barriers — everything else — unchanged)
+    zero body    body and tail weights zero, head as default: the weight operand of every MFMA of 86 of the 88 layers is zero (the hidden
+                 activations come out zero, the residual stream stays at the head's output); loads, LDS traffic, operand splits,
+                 barriers — everything else — unchanged
 for the fp16x2 (default), bf16x3 and fp32-MFMA families:  python tools/operand_entropy_render.py [launches=12]"""
 import os
 import sys
