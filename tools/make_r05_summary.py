@@ -179,7 +179,7 @@ rows = [
     ("stash stores of the training chains (VERDICT r4 #3; `r05_stash_store_ab.txt`)", "timing build without the stores: forward 2.908 -> 2.675 ms, dX chain 2.841 -> 2.584 ms: **0.49 ms = 6.5 % of the step is the price of the 9 GB of stash**, which the weight-gradient kernels need; cache policy of the stores: plain +0.8 %, `nt` = round 4, **`nt sc1` -0.6 % (7.541 vs 7.588 ms): shipped**.  The ≤ 2.7 ms forward VERDICT asked for equals the no-store build"),
     ("fp16 weight gradients: are they equivalent? (VERDICT r4 #4; `r05_train_equivalence_seeds.txt`)", "12 000 steps of 16 384 rays per run, held-out PSNR mean ± seed std: fp16 trio (default) 25.604 ± 0.182 dB and exact-fp32 MFMA 25.554 ± 0.165 dB over 8 seeds each, bf16x3 trio 25.543 ± 0.220 and fp16 trio with exact dW 25.490 ± 0.150 over 4: default − fp32, paired by seed, +0.050 ± 0.225 dB, standard error 0.079 dB (both signs, no trend) against 0.17 – 0.22 dB between two seeds of ONE family: statistically indistinguishable; the default stays fp16 dW"),
     ("why the fast-mode render sits at 0.53 – 0.55 (VERDICT r4 weak #7; `r05_operand_entropy.txt`)", "the SAME launch and instruction stream on three data sets: default weights 37.9 ms per 9 frames (0.537 of 833 TF); weights rounded to fp16 (their `mid` halves zero) 36.2 ms; body weights zero (the weight operand of 86 of 88 layers' MFMAs is zero, everything else executes) **28.2 ms = 0.722**: −25.6 % from the data alone; bf16x3 0.613 -> 0.795; the exact-fp32 kernel (not power-capped) 114.7 -> 114.3 ms.  The 16-bit kernels' schedules feed the matrix pipe at 0.72 / 0.80 of its peak; what real data gets is the power envelope (the MFMA-only probe of round 3 loses 29 % between zero and random mantissas); effective clock of those launches (GRBM_GUI_ACTIVE / wall): **1.79 GHz on the bench's weights, 2.39 GHz on zero operands, the same 67 M cycles and 73 – 74 % MFMA busy in both**; the fp32 kernel 2.39 GHz on any data.  Training step (`tools/operand_entropy_train.py`): default trio 7.60 -> 6.28 ms (−17.4 %), bf16x3 16.30 -> 12.49 (−23.4 %), exact fp32 24.89 -> 24.36; teacher frame fp16x2 105.2 -> 90.9 ms (−13.5 %), exact fp32 340.6 -> 336.7"),
-    ("inline-asm MFMA operands for the render kernel (VERDICT r4 #5)", "not built.  The lever (pin the B operands in AGPRs to shed the v_accvgpr copies) was tried through the compiler first: `-mllvm -amdgpu-mfma-vgpr-form` crashes clang (exit 139) on r2l_fwd2.hip; hand-placed asm for 195 MFMAs per layer with the ring schedule would replace the kernel's whole scheduling contract — a 1 – 2 % expectation (3.2 VALU per MFMA is dominated by the operand split, not the copies: `r04_kernel_resources.txt`).  Recorded as a negative decision, DESIGN §7"),
+    ("inline-asm MFMA operands for the render kernel (VERDICT r4 #5)", "not built.  The lever (pin the B operands in AGPRs to shed the v_accvgpr copies) was tried through the compiler first: `-mllvm -amdgpu-mfma-vgpr-form` crashes clang (exit 139) on r2l_fwd2.hip; hand-placed asm for 195 MFMAs per layer with the ring schedule would replace the kernel's whole scheduling contract — a 1 – 2 % expectation (3.2 VALU per MFMA is dominated by the operand split, not the copies: `r04_kernel_resources.txt`).  And the operand-entropy measurement above says what such a lever could buy at best: the launch runs against the power cap — a fixed number of cycles at whatever clock the data's energy allows — so removing VALU instructions from the MFMA shadow returns only their share of the launch's ENERGY, not their share of its cycles.  Recorded as a negative decision, DESIGN §7"),
     ("world = 8 without a node (VERDICT r4 #6)", "`tests/test_world8_gpu.py`: the real CLI under torchrun, EIGHT ranks sharing the one GPU over gloo: create_data (21 poses, rank-disjoint shard ranges), 6 training iterations at `--N_rand 20` ([3, 3, 3, 3, 2, 2, 2, 2] shard files per rank and step, replicas bit-identical), render_test + video (three ranks without a pose); CPU twin `test_eight_rank_gloo_trainer_host_logic`"),
     ("module-boundary forward with a config (VERDICT r4 #7)", "`r2l_forward_emb_cfg`: bf16x3 / fp16x2 body on a caller-supplied embedding (head in fp32 MFMA into an X0 scratch, then `r2l_fwd3_kernel<X0>`); `engine.forward_emb` uses it; `test_emb_path_matches_oracle` over the families"),
     ("families pruned (VERDICT r4 #8; `r05_dispatch_table.md`)", "the round-1 cooperative fp32 kernel (`r2l_coop.hip`, `tiling = coop`) retired: never chosen by the cost model since round 2; `R2L_TILING_COOP_RETIRED` is rejected with a message; the dispatch table lists which kernels each (precision, tiling, rays) cell launches"),
