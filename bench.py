@@ -349,7 +349,8 @@ def summary_of(out):
         return [round(d["value"]), round(d.get("ms_per_step", d.get("ms_per_frame", 0.)), 4), round(r.get("frac", 0.), 4)]
     fm = out.get("fast_mode", {})
     sm = {"graded_render_fp32_mfma": [round(out["value"]), round(out["ms_per_step"], 4), round(out["roofline"]["frac"], 4)],
-          "graded_train_fp32_mfma": row(out.get("train")), "graded_teacher_fp32_mfma": row(out.get("teacher")),
+          "graded_train_fp32_mfma": row(out.get("train")), "graded_train_4096": row(out.get("train_4096")),
+          "graded_train_12288": row(out.get("train_12288")), "graded_teacher_fp32_mfma": row(out.get("teacher")),
           "bf16x3_render": row(out.get("fp32_grade_products")),
           "bf16x3_train": row(out.get("fp32_grade_products", {}).get("train")),
           "fast_render_fp16x2": row(fm), "fast_train": row(fm.get("train")), "fast_train_exact_dw": row(fm.get("train_exact_dw")),
@@ -623,6 +624,9 @@ def main():
         # 12 288 rays = the per-GPU share of the 98 304-ray step at 8 GPUs (strong scaling)
         train_leg(fast, "train_4096", precision="fp16x2", dw_mode="fp16", n_rays=4096)
         train_leg(fast, "train_12288", precision="fp16x2", dw_mode="fp16", n_rays=12288)
+        # the same two step sizes on the reference's arithmetic (exact-fp32 MFMA in every GEMM): graded, top level
+        train_leg(out, "train_4096", precision="fp32_mfma", n_rays=4096)
+        train_leg(out, "train_12288", precision="fp32_mfma", n_rays=12288)
         if distributed and a.segmented_leg:
             # the same steps with the dX chain cut into 3 segments (opt-in, R2LTrainer(chain_segments=3)): each segment's weight
             # gradients and all-reduce beside the next segment — what cutting the chain buys, once a node measures it.  Behind a

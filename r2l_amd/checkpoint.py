@@ -61,8 +61,10 @@ def load_weights_v2(model, ckpt, key):
 
 
 def save_ckpt(path, global_step, model, optimizer_state_dict, best_psnr, best_psnr_step, model_name="R2L",
-              model_fine=None):
-    """Write a reference-layout checkpoint (main.py:1516-1542)."""
+              model_fine=None, r2l_config=None):
+    """Write a reference-layout checkpoint (main.py:1516-1542).  r2l_config: the arithmetic the run trained on
+    ({'precision', 'dw_mode', 'requested'}, driver.apply_arithmetic), stored under a key of its own — the reference's loaders
+    read the keys they know by name (main.py:481-509) and never see it."""
     model = undataparallel(model)
     to_save = {
         "global_step": global_step,
@@ -75,6 +77,8 @@ def save_ckpt(path, global_step, model, optimizer_state_dict, best_psnr, best_ps
         to_save["network_fine_state_dict"] = undataparallel(model_fine).state_dict()
     if model_name in ("nerf_v3.2", "R2L"):
         to_save["network_fn"] = model  # pickled whole, engine state excluded by NeRF_v3_2.__getstate__
+    if r2l_config is not None:
+        to_save["r2l_config"] = dict(r2l_config)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(to_save, path)
     return path

@@ -19,7 +19,7 @@ import torch
 
 from . import data as D
 from .checkpoint import load_weights
-from .driver import init_distributed, sync
+from .driver import apply_arithmetic, init_distributed, sync
 from .logger import Logger
 from .nerf_raybased import NeRF
 from .options import parse_args, validate_accelerated
@@ -97,6 +97,7 @@ def main(argv=None):
         H, W, focal = 400, 400, 555.5555155968841
     near, far = 2., 6.
     coarse, fine = create_teacher(args, device)
+    apply_arithmetic(args, device, logger, teachers=(coarse, fine))  # --r2l_precision: the teacher kernels' arithmetic
     kwargs = teacher_render_kwargs(args, coarse, fine)
 
     datadir_new = args.datadir_kd.split(":")[-1]

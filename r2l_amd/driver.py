@@ -180,6 +180,79 @@ def create_r2l(args, device, logger):
     return model, embedder, history, ckpt
 
 
+def create_nerf_teacher(args, device, logger, near, far):
+    """The `model_name in ['nerf']` branch of create_nerf (main.py:407-453, 481-509, 511-541) for rendering: coarse NeRF (+ the
+    fine one when N_importance > 0) built from --netdepth/--netwidth(/_fine), weights from --pretrained_ckpt through
+    load_weights_v2 ('network_fn_state_dict' / 'network_fine_state_dict'; a checkpoint that carries pickled modules replaces the
+    constructed ones), and render_kwargs_test: perturb = --perturb_test, raw_noise_std = 0, near / far of the blender scenes.
+    Teacher TRAINING is out of scope: no optimizer, parameters frozen."""
+    from .nerf_raybased import NeRF
+    from .render import get_embedder, run_network
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    embeddirs_fn, input_ch_views = (get_embedder(args.multires_views, args.i_embed) if args.use_viewdirs else (None, 0))
+    output_ch = 5 if args.N_importance > 0 else 4
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                          input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+    if args.pretrained_ckpt:
+        ckpt = load_ckpt(args.pretrained_ckpt, map_location=device)
+        if "network_fn" in ckpt:
+            model = ckpt["network_fn"].to(device)
+            if model_fine is not None:
+                assert "network_fine" in ckpt
+                model_fine = ckpt["network_fine"].to(device)
+            logger.info('Use model arch saved in checkpoint "%s"' % args.pretrained_ckpt)
+        load_weights_v2(model, ckpt, "network_fn_state_dict")
+        if model_fine is not None:
+            load_weights_v2(model_fine, ckpt, "network_fine_state_dict")
+        logger.info('Load pretrained ckpt successfully: "%s".' % args.pretrained_ckpt)
+    for net in (model, model_fine):
+        if net is not None:
+            for p in net.parameters():
+                p.requires_grad = False
+    qfn = lambda inputs, viewdirs, fn: run_network(inputs, viewdirs, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                                                   netchunk=args.netchunk)
+    n_params = sum(p.numel() for p in model.parameters())
+    macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
+    macs *= args.N_samples + args.N_samples + args.N_importance  # as main.py:547-549
+    logger.info("Model complexity per pixel: FLOPs %.10fM, Params %.10fM" % (macs / 1e6, n_params / 1e6))
+    # render_kwargs_test (main.py:511-541) + bds_dict (main.py:977-982)
+    return dict(network_query_fn=qfn, perturb=args.perturb_test, N_importance=args.N_importance, network_fine=model_fine,
+                N_samples=args.N_samples, network_fn=model, use_viewdirs=args.use_viewdirs, white_bkgd=args.white_bkgd,
+                raw_noise_std=0., ndc=False, lindisp=args.lindisp, near=near, far=far)
+
+
+def apply_arithmetic(args, device, logger, student=None, teachers=()):
+    """--r2l_precision / --r2l_dw_mode (options.py; include/r2l_hip.h r2l_config) -> the engines of this run, through
+    R2LEngine.set_config / TeacherEngine.set_config — arguments of the *_cfg entry points, not environment switches.  Returns the
+    record {'precision', 'dw_mode', 'requested': {...}} that is logged here and stored in every checkpoint the run writes (key
+    'r2l_config': the reference's loaders never look at it, main.py:481-509).  CPU (config 0, plumbing): torch fp32 ops."""
+    req = {"precision": args.r2l_precision, "dw_mode": args.r2l_dw_mode}
+    if device.type != "cuda":
+        rec = {"precision": "torch fp32 (CPU plumbing)", "dw_mode": "autograd fp32", "requested": req}
+    else:
+        from . import engine as _engine
+        cfg = _lib_config(req)
+        if student is not None:
+            student.engine().set_config(precision=req["precision"], dw_mode=req["dw_mode"])
+        for net in teachers:
+            if net is not None:
+                from .render import teacher_engine
+                teacher_engine(net).set_config(precision=req["precision"])
+        rec = dict(_engine.arithmetic(cfg), requested=req)
+    logger.info("r2l_config: precision %s, dw_mode %s (requested: --r2l_precision %s --r2l_dw_mode %s)" %
+                (rec["precision"], rec["dw_mode"], req["precision"], req["dw_mode"]))
+    return rec
+
+
+def _lib_config(req):
+    from . import _lib
+    return _lib.make_config(precision=req["precision"], dw_mode=req["dw_mode"])
+
+
 POSES_PER_LAUNCH = 9
 
 
@@ -301,11 +374,15 @@ def save_video(rgbs, logger, expid, iter_, tag, rank=0, world=1, device=None):
     return path
 
 
-def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, savedir=None, rank=0, world=1):
+def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, savedir=None, rank=0, world=1, teacher=None):
     """Render poses[rank::world]; returns (rgbs [n,H,W,3], misc with test_loss/test_psnr/test_psnr_v2 over ALL frames)
-    and test_ssim — the R2L branch of main.py:189-398 (LPIPS/FLIP need network weights / packages that are absent: out
-    of scope).  No host sync inside the loop: metrics stay on the device, frames are written by _FrameWriter, per-frame
-    times come from device events and are logged after the loop."""
+    and test_ssim — main.py:189-398 (LPIPS/FLIP need network weights / packages that are absent: out of scope).  No host
+    sync inside the loop: metrics stay on the device, frames are written by _FrameWriter, per-frame times come from device
+    events and are logged after the loop.
+    teacher = None: the R2L branch (main.py:284-324), `model` = the student.
+    teacher = dict(hwf=(H, W, focal), chunk=, render_kwargs=): the `model_name in ['nerf']` branch (main.py:275-282): every
+    frame is render(H, W, focal, chunk, c2w=pose[:3,:4], **render_kwargs) of r2l_amd/render.py (coarse + fine NeRF on the
+    teacher kernels); `model` = render_kwargs['network_fn'], `point_sampler` unused."""
     model.eval()
     mine = list(range(rank, len(poses), world))
     rgbs, sq_err, psnrs, ssims, events = [], [], [], [], []
@@ -327,7 +404,26 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             if gt_imgs is not None:
                 writer.save(gt_imgs[i], os.path.join(savedir, "%03d_gt.png" % i))
 
-    if on_gpu:
+    if teacher is not None:
+        from .render import render
+        H, W, focal = teacher["hwf"]
+        # a whole frame per launch on the GPU (as create_data.main: --chunk is a memory work-around of the op-by-op path)
+        chunk = max(int(teacher["chunk"]), H * W) if on_gpu else int(teacher["chunk"])
+        for i in mine:
+            t0 = time.time()
+            if on_gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            c2w = torch.as_tensor(poses[i], dtype=torch.float32)[:3, :4].to(device)
+            with torch.no_grad():
+                rgb, _disp, _acc, _extras = render(H, W, focal, chunk=chunk, c2w=c2w, **teacher["render_kwargs"])
+            if on_gpu:
+                e1.record()
+                events.append(([i], e0, e1))
+            else:
+                logger.info("[#%d] frame, rendering done, time for this frame: %.4fs" % (i, time.time() - t0))
+            account(i, rgb)
+    elif on_gpu:
         # POSES_PER_LAUNCH frames per launch (engine.forward_poses: no launch gap and no partly filled last round of
         # workgroups per frame; 9 x 1250 workgroups = 43.95 rounds of the 256 CUs at 400x400)
         for g0 in range(0, len(mine), POSES_PER_LAUNCH):
@@ -380,9 +476,12 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
 def main(argv=None):
     args = parse_args(argv)
     validate_accelerated(args)
-    if args.model_name not in ("R2L", "nerf_v3.2"):
-        raise NotImplementedError("main.py accelerates --model_name R2L; the NeRF teacher is used through "
-                                  "utils/create_data.py (its training is out of scope)")
+    is_teacher = args.model_name == "nerf"
+    if is_teacher and (not args.render_only or args.benchmark):
+        # (--benchmark times render_func = the R2L student's forward, main.py:401-404,1124-1133)
+        raise NotImplementedError("--model_name nerf: the accelerated path renders a pretrained teacher (--render_only, with or "
+                                  "without --render_test / --test_pretrained) and uses it in utils/create_data.py; TRAINING "
+                                  "the teacher is out of scope (SURVEY.md §2)")
     rank, world, device = init_distributed()
     np.random.seed(0)
     # every rank must build the same student: torch's default generator is seeded per process otherwise (the reference had
@@ -403,15 +502,27 @@ def main(argv=None):
     if args.focal_scale > 0:
         focal *= args.focal_scale
 
-    model, embedder, history, ckpt = create_r2l(args, device, logger)
-    point_sampler = PointSampler(H, W, focal, args.n_sample_per_ray, near, far, device=device)
+    teacher = None
+    if is_teacher:
+        kwargs_test = create_nerf_teacher(args, device, logger, near, far)
+        model, point_sampler = kwargs_test["network_fn"], None
+        teacher = dict(hwf=(H, W, focal), chunk=args.chunk, render_kwargs=kwargs_test)
+        history = {"start": 0, "best_psnr": 0, "best_psnr_step": 0}
+        r2l_config = apply_arithmetic(args, device, logger, teachers=(model, kwargs_test["network_fine"]))
+    else:
+        model, embedder, history, ckpt = create_r2l(args, device, logger)
+        point_sampler = PointSampler(H, W, focal, args.n_sample_per_ray, near, far, device=device)
+        r2l_config = apply_arithmetic(args, device, logger, student=model)
+        if ckpt is not None and ckpt.get("r2l_config"):
+            was = ckpt["r2l_config"]
+            logger.info("checkpoint was trained with r2l_config: precision %s, dw_mode %s" % (was.get("precision"), was.get("dw_mode")))
     test_poses, test_images = poses[i_test], images[i_test]
     video_poses = D.get_novel_poses(args, n_pose=args.n_pose_video)
     start, best_psnr, best_psnr_step = history["start"], history["best_psnr"], history["best_psnr_step"]
 
     if args.test_pretrained:
         _, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images, rank=rank,
-                              world=world)
+                              world=world, teacher=teacher)
         logger.info("Pretrained test: TestLoss %.4f TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" %
                     (misc["test_loss"].item(), misc["test_psnr"].item(), misc["test_psnr_v2"].item(),
                      misc["test_ssim"].item()))
@@ -423,20 +534,19 @@ def main(argv=None):
         if args.render_test:
             rgbs, misc = render_path(test_poses, model, point_sampler, device, logger, gt_imgs=test_images,
                                      savedir=logger.gen_img_path if rank == 0 or world > 1 else None, rank=rank,
-                                     world=world)
+                                     world=world, teacher=teacher)
             logger.info("[TEST] TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" %
                         (misc["test_psnr"].item(), misc["test_psnr_v2"].item(), misc["test_ssim"].item()))
         else:
             rgbs, misc = render_path(video_poses, model, point_sampler, device, logger, savedir=logger.gen_img_path,
-                                     rank=rank, world=world)
+                                     rank=rank, world=world, teacher=teacher)
         n_rays = rgbs.shape[0] * H * W if rgbs.numel() else 0
         dt = time.time() - t_
         logger.info("Rendered %d frames (%d rays) in %.2fs on rank %d = %.0f rays/s incl. I/O; frames in %s" %
                     (rgbs.shape[0], n_rays, dt, rank, n_rays / max(dt, 1e-9), logger.gen_img_path))
-        video_path = None
-        if not args.render_test:
-            video_path = save_video(rgbs, logger, expid, iter_, args.video_tag, rank, world, device)
-        return {"misc": misc, "rgbs": rgbs, "logger": logger, "video_path": video_path}
+        # (the reference writes the video of whichever frames it rendered — test views too, main.py:1096-1097)
+        video_path = save_video(rgbs, logger, expid, iter_, args.video_tag, rank, world, device)
+        return {"misc": misc, "rgbs": rgbs, "logger": logger, "video_path": video_path, "r2l_config": r2l_config}
 
     if args.benchmark:
         # torch.utils.benchmark.Timer('render_func(model, pose)').timeit(100) in the reference (main.py:1124-1133)
@@ -531,7 +641,7 @@ def main(argv=None):
                 best_psnr, best_psnr_step = misc["test_psnr_v2"].item(), i
                 if rank == 0:
                     save_ckpt(os.path.join(logger.weights_path, "ckpt_best.tar"), i, model,
-                              trainer.optimizer_state_dict(lr), best_psnr, best_psnr_step)
+                              trainer.optimizer_state_dict(lr), best_psnr, best_psnr_step, r2l_config=r2l_config)
             logger.info("[TEST] Iter %d TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f BestPSNRv2 %.4f (Iter %d) "
                         "TrainHistPSNR %.4f LR %.8f Time %.1fs" %
                         (i, misc["test_psnr"].item(), misc["test_psnr_v2"].item(), misc["test_ssim"].item(), best_psnr,
@@ -547,7 +657,7 @@ def main(argv=None):
         if i % args.i_weights == 0 and rank == 0:
             name = "ckpt_%d.tar" % i if args.save_intermediate_models else "ckpt.tar"
             path = save_ckpt(os.path.join(logger.weights_path, name), i, model, trainer.optimizer_state_dict(lr),
-                             best_psnr, best_psnr_step)
+                             best_psnr, best_psnr_step, r2l_config=r2l_config)
             logger.info('Iter %d Save checkpoint: "%s".' % (i, path))
     loader.close()
     if world > 1 and os.environ.get("R2L_CHECK_SYNC"):  # tests: the replicas must have stayed bit-identical
@@ -556,4 +666,4 @@ def main(argv=None):
         logger.info("replicas in sync after %d iterations: %s (skipped steps: %d)" % (args.N_iters, ok, trainer.drain()))
         if not ok:
             raise RuntimeError("data-parallel replicas diverged")
-    return {"trainer": trainer, "logger": logger, "model": model}
+    return {"trainer": trainer, "logger": logger, "model": model, "r2l_config": r2l_config}

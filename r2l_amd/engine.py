@@ -32,6 +32,32 @@ def merged_config(cfg):
                        cfg.reserve_cus or base.reserve_cus, cfg.dw_mode or base.dw_mode)
 
 
+def arithmetic(cfg=None):
+    """{'precision': 'fp16x2'|'bf16x3'|'fp32_mfma', 'dw_mode': 'fp16'|'exact'}: the arithmetic the launches made with `cfg`
+    (an r2l_config, AUTO fields filled from DEFAULT_CONFIG) run on, AUTO resolved the way the library resolves it
+    (csrc/r2l_common.h r2l_use_fwd3 / r2l_use_fwd2 / r2l_use_trio16 / r2l_dw_exact: the R2L_NO_* / R2L_DW_EXACT environment
+    switches an AUTO field falls through to).  What the drivers log and store in the checkpoints they write."""
+    import os
+    cfg = merged_config(cfg if cfg is not None else _lib.Config())
+    on = lambda k: os.environ.get(k, "")[:1] not in ("", "0")  # r2l_env_on
+    names = {v: k for k, v in _lib.PRECISION.items()}
+    if cfg.precision:
+        prec = names[cfg.precision]
+    elif on("R2L_NO_FWD3"):
+        prec = "fp32_mfma"
+    elif on("R2L_NO_FWD2") or on("R2L_NO_BWD2") or on("R2L_NO_DW2"):
+        prec = "bf16x3"  # (training steps; forward-only launches look at R2L_NO_FWD2 alone)
+    else:
+        prec = "fp16x2"
+    if prec != "fp16x2":
+        dw = "exact"  # the fp32-MFMA / bf16x3 weight-gradient GEMMs carry fp32-grade operands
+    elif cfg.dw_mode:
+        dw = {v: k for k, v in _lib.DW_MODE.items()}[cfg.dw_mode]
+    else:
+        dw = "exact" if on("R2L_DW_EXACT") else "fp16"
+    return {"precision": prec, "dw_mode": dw}
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

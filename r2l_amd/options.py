@@ -47,12 +47,17 @@ FLAGS = {
     "teacher_ckpt": (str, None), "test_teacher": ("flag", False), "create_data": (str, "spiral_evenly_spaced"),
     "n_pose_kd": (str, "100"), "create_data_chunk": (int, 100), "rm_existing_data": ("flag", False),
     "max_save": (int, 40000),
+    # arithmetic of the HIP kernels (this build's own keys; include/r2l_hip.h r2l_config.precision / .dw_mode): which kernel
+    # family every launch of the run uses.  auto = the library default (fp16x2 products, fp16 weight-gradient operands);
+    # fp32_mfma = the reference's arithmetic (exact fp32 products and accumulation) — the graded numbers of bench.py
+    "r2l_precision": (str, "auto"), "r2l_dw_mode": (str, "auto"),
     # new-architecture switches (dotted group)
     "trial.ON": ("flag", False), "trial.body_arch": (str, "mlp"), "trial.res_scale": (float, 1.),
     "trial.n_learnable": (int, 2), "trial.inact": (str, "relu"), "trial.outact": (str, "none"),
     "trial.n_block": (int, -1), "trial.near": (float, -1.), "trial.far": (float, -1.),
 }
-CHOICES = {"model_name": ["nerf", "nerf_v3.2", "R2L"], "data_mode": ["images", "rays"], "act": ["relu", "lrelu"],
+CHOICES = {"r2l_precision": ["auto", "fp16x2", "bf16x3", "fp32_mfma"], "r2l_dw_mode": ["auto", "fp16", "exact"],
+           "model_name": ["nerf", "nerf_v3.2", "R2L"], "data_mode": ["images", "rays"], "act": ["relu", "lrelu"],
            "trial.body_arch": ["mlp", "resmlp"], "trial.inact": ["none", "relu", "lrelu"],
            "trial.outact": ["none", "relu", "lrelu"]}
 # flags of reference variants outside the accelerated path: accepted so old command lines / configs still parse

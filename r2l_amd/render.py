@@ -82,6 +82,11 @@ class TeacherEngine:
         self._ver = None
         self.cfg = _lib.Config()  # r2l_config of this teacher's calls (only .precision matters); all zero = AUTO
 
+    def set_config(self, precision="auto"):
+        """Kernel family of this teacher's point-network launches: 'auto|fp16x2|bf16x3|fp32_mfma' (r2l_config.precision)."""
+        self.cfg = _lib.make_config(precision=precision)
+        return self.cfg
+
     def _aliased(self):
         if self.flat is None:
             return False

@@ -53,8 +53,9 @@ def test_render_only_cpu_plumbing(tmp_path, monkeypatch):
     rgbs, misc = out["rgbs"], out["misc"]
     assert rgbs.shape == (2, 6, 6, 3)  # half_res of the 12x12 test views
     assert np.isfinite(misc["test_psnr"].item()) and np.isfinite(misc["test_psnr_v2"].item())
-    pngs = sorted(os.listdir(out["logger"].gen_img_path))
+    pngs = sorted(f for f in os.listdir(out["logger"].gen_img_path) if f.endswith(".png"))
     assert pngs == ["000.png", "000_gt.png", "001.png", "001_gt.png"]
+    assert out["video_path"].endswith(".avi")  # the reference writes the video of the test frames too (main.py:1096-1097)
     # the frame equals the oracle's evaluation of the same weights on the same pose
     from r2l_amd import data
     imgs, poses, _, hwf, i_split = data.load_blender_data(scene, True, 1)
@@ -71,6 +72,53 @@ def test_render_only_cpu_plumbing(tmp_path, monkeypatch):
     frames, fps = read_mjpeg_avi(out["video_path"])
     assert frames.shape == (5, 6, 6, 3) and fps == 30
     assert np.abs(frames.astype(np.int32) - to8b(out["rgbs"]).astype(np.int32)).mean() < 12  # (JPEG of 6x6 noise-like frames)
+
+
+def oracle_teacher_frame(csd, fsd, pose, H, W, focal, white_bkgd=True):
+    """[H,W,3] of the seeded teacher pair through the oracle's render_rays (perturb 0, det u), rays as render() packs them
+    (main.py:141-175): [o, d, near = 2, far = 6, d / |d|]."""
+    o, d = O.rays_from_pose(O.pixel_dirs(H, W, focal), torch.as_tensor(np.asarray(pose), dtype=torch.float32)[:3, :4])
+    ones = torch.ones_like(d[:, :1])
+    rb = torch.cat([o, d, 2. * ones, 6. * ones, d / torch.norm(d, dim=-1, keepdim=True)], -1)
+    with torch.no_grad():
+        return O.render_rays(rb, csd, fsd, 64, 128, perturb=0., white_bkgd=white_bkgd)["rgb_map"].view(H, W, 3)
+
+
+def test_teacher_render_only_cpu_plumbing(tmp_path, monkeypatch):
+    """README step 2's teacher test command, `main.py --model_name nerf --config configs/lego.txt --pretrained_ckpt <tar>
+    --render_only --render_test --testskip 1` (/root/reference/README.md:72; main.py:275-282, 407-453, 1063-1099), on CPU:
+    every frame equals the oracle's render_rays of the same weights, metrics are the reference's, TRAINING stays rejected."""
+    from r2l_amd import data, driver
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene)
+    csd, fsd = O.make_teacher_state_dicts(5, 2, alpha_bias=0.5)
+    ck = str(tmp_path / "teacher.tar")
+    torch.save({"global_step": 200000, "network_fn_state_dict": csd, "network_fine_state_dict": fsd}, ck)
+    common = ["--model_name", "nerf", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene,
+              "--pretrained_ckpt", ck, "--testskip", "1", "--experiment_name", "Test__NeRF__cpu"]
+    out = driver.main(common + ["--render_only", "--render_test"])
+    rgbs, misc = out["rgbs"], out["misc"]
+    assert rgbs.shape == (2, 6, 6, 3)
+    imgs, poses, _, hwf, i_split = data.load_blender_data(scene, True, 1)
+    imgs = torch.as_tensor(imgs)
+    gts = imgs[..., :3] * imgs[..., -1:] + (1. - imgs[..., -1:])
+    psnrs = []
+    for k, i in enumerate(i_split[2]):
+        ref = oracle_teacher_frame(csd, fsd, poses[i], 6, 6, float(hwf[2]))
+        assert (rgbs[k] - ref).abs().max().item() < 1e-5
+        psnrs.append(O.mse2psnr(O.img2mse(ref, gts[i])).item())
+    assert abs(misc["test_psnr_v2"].item() - np.mean(psnrs)) < 1e-3
+    pngs = sorted(f for f in os.listdir(out["logger"].gen_img_path) if f.endswith(".png"))
+    assert pngs == ["000.png", "000_gt.png", "001.png", "001_gt.png"]
+    assert out["video_path"].endswith(".avi")  # the reference writes the video of the test frames too (main.py:1096-1097)
+    # novel-pose video of the teacher
+    out = driver.main(common + ["--render_only", "--n_pose_video", "3", "--experiment_name", "Video__NeRF__cpu"])
+    assert out["rgbs"].shape == (3, 6, 6, 3) and out["video_path"].endswith("_pose3.avi")
+    with pytest.raises(NotImplementedError, match="TRAINING"):
+        driver.main(common)
 
 
 def test_mjpeg_avi_round_trip(tmp_path):

@@ -133,10 +133,113 @@ def test_cli_render_two_ranks(tmp_path):
     r = subprocess.run(run + ["--experiment_name", "two_video"], env=env, cwd=str(tmp_path), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
-    avis = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith(".avi"))
+    # (the --render_test runs write a video of the test frames as well, main.py:1096-1097: not the ones compared here)
+    avis = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith(".avi") and "_video_" in dp)
     assert len(avis) == 2  # one from the single process, one from rank 0 of the pair
     a, b = (open(f, "rb").read() for f in avis)
     assert a == b and len(a) > 1000  # the same five frames in the same order
+
+
+def test_cli_teacher_render_test_vs_oracle(tmp_path):
+    """README step 2's teacher test command (`main.py --model_name nerf --config configs/lego.txt --pretrained_ckpt <tar>
+    --render_only --render_test --testskip 1`, /root/reference/README.md:72; main.py:275-282 `model_name in ['nerf']` branch of
+    render_path, 107-186 render, 407-453 create_nerf) on the teacher kernels: every test frame against the oracle's render_rays
+    of the same seeded pair (rgb < 1e-4, north_star's bar), PSNR / SSIM against the oracle's metrics of the oracle's frames,
+    for each arithmetic the CLI can select; plus the novel-pose video of the teacher."""
+    from r2l_amd import data, driver
+    from tests.test_driver_cpu import oracle_teacher_frame
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=64)  # half_res -> 32 x 32 frames, 2 test views
+    csd, fsd = O.make_teacher_state_dicts(5, 2, alpha_bias=0.5)
+    ck = str(tmp_path / "NeRF__lego_SERVER000-20260101-000000" / "weights" / "200000.tar")
+    os.makedirs(os.path.dirname(ck))
+    torch.save({"global_step": 200000, "network_fn_state_dict": csd, "network_fine_state_dict": fsd}, ck)
+    common = ["--model_name", "nerf", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene,
+              "--pretrained_ckpt", ck, "--testskip", "1", "--render_only"]
+    imgs, poses, _, hwf, i_split = data.load_blender_data(scene, True, 1)
+    imgs = torch.as_tensor(imgs)
+    gts = imgs[..., :3] * imgs[..., -1:] + (1. - imgs[..., -1:])
+    refs = [oracle_teacher_frame(csd, fsd, poses[i], 32, 32, float(hwf[2])) for i in i_split[2]]
+    want_psnr = np.mean([O.mse2psnr(O.img2mse(r, gts[i])).item() for r, i in zip(refs, i_split[2])])
+    want_ssim = np.mean([O.ssim(r, gts[i]).item() for r, i in zip(refs, i_split[2])])
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        for prec in ("auto", "fp32_mfma", "bf16x3"):
+            out = driver.main(common + ["--render_test", "--experiment_name", "Test__NeRF__" + prec, "--r2l_precision", prec])
+            rgbs, misc = out["rgbs"].cpu(), out["misc"]
+            assert rgbs.shape == (2, 32, 32, 3)
+            for k in range(2):
+                assert (rgbs[k] - refs[k]).abs().max().item() < 1e-4, (prec, k)
+            assert abs(misc["test_psnr_v2"].item() - want_psnr) < 1e-3 and abs(misc["test_ssim"].item() - want_ssim) < 1e-4
+            pngs = sorted(f for f in os.listdir(out["logger"].gen_img_path) if f.endswith(".png"))
+            assert pngs == ["000.png", "000_gt.png", "001.png", "001_gt.png"]
+            assert "_SERVER000-20260101-000000_iter200000_" in os.path.basename(out["video_path"])
+        out = driver.main(common + ["--n_pose_video", "3", "--experiment_name", "Video__NeRF"])
+        assert out["rgbs"].shape == (3, 32, 32, 3) and out["video_path"].endswith("_pose3.avi")
+        with pytest.raises(NotImplementedError, match="TRAINING"):
+            driver.main([a for a in common if a != "--render_only"])
+    finally:
+        os.chdir(cwd)
+
+
+def test_cli_arithmetic_is_a_recorded_option(tmp_path):
+    """--r2l_precision / --r2l_dw_mode (r2l_amd/options.py -> engine.set_config): `main.py ... --r2l_precision
+    fp32_mfma --render_only --render_test` gives the frames of engine.set_config(precision='fp32_mfma') bit for bit (and not the
+    default family's); a training run logs the effective r2l_config and stores it in the checkpoint it writes."""
+    from r2l_amd import data, driver
+    from r2l_amd.checkpoint import load_ckpt, save_ckpt
+    from r2l_amd.nerf_raybased import PointSampler
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene, size=128)
+    sd = O.make_state_dict(n_block=2, seed=1)
+    ckpt = str(tmp_path / "ckpt.tar")
+    save_ckpt(ckpt, 7, build_model(sd, 2).cpu(), {"state": {}, "param_groups": []}, 0., 0)
+    common = ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene,
+              "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "6", "--use_residual", "--trial.ON",
+              "--trial.body_arch", "resmlp", "--testskip", "1"]
+    render = common + ["--pretrained_ckpt", ckpt, "--render_only", "--render_test"]
+    _, poses, _, hwf, i_split = data.load_blender_data(scene, True, 1)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        frames = {}
+        for prec in ("fp32_mfma", "bf16x3", "auto"):
+            out = driver.main(render + ["--r2l_precision", prec, "--experiment_name", "arith_" + prec])
+            assert out["r2l_config"]["precision"] == ("fp16x2" if prec == "auto" else prec)
+            frames[prec] = out["rgbs"]
+            net = build_model(sd, 2)
+            net.engine().set_config(precision=prec)
+            ps = PointSampler(64, 64, float(hwf[2]), 16, 2., 6., device="cuda")
+            c2ws = torch.stack([torch.as_tensor(poses[i], dtype=torch.float32)[:3, :4] for i in i_split[2]], 0)
+            with torch.no_grad():
+                want = net.render_poses(c2ws, ps).view(len(i_split[2]), 64, 64, 3)
+            assert torch.equal(out["rgbs"], want), prec
+            log = open(os.path.join(out["logger"].log_path, "log.txt")).read()
+            assert "r2l_config: precision %s" % out["r2l_config"]["precision"] in log
+        assert not torch.equal(frames["fp32_mfma"], frames["auto"])  # (different arithmetic: the option is not a no-op)
+        # training: the record goes into the checkpoint
+        rng = np.random.RandomState(0)
+        kd = str(tmp_path / "kd")
+        os.makedirs(kd)
+        for k in range(4):
+            rows = np.concatenate([rng.randn(4096, 3) * 0.3 + [0, 0, 4], rng.randn(4096, 3), rng.rand(4096, 3)], 1).astype(np.float32)
+            np.save(os.path.join(kd, "data_%d.npy" % k), rows)
+        out = driver.main(common + ["--datadir_kd", kd, "--data_mode", "rays", "--N_rand", "1", "--N_iters", "3", "--i_weights", "3",
+                                    "--i_print", "1", "--i_testset", "100", "--r2l_precision", "fp16x2", "--r2l_dw_mode", "exact",
+                                    "--experiment_name", "arith_train"])
+        ck = load_ckpt(os.path.join(out["logger"].weights_path, "ckpt.tar"))
+        assert ck["r2l_config"] == {"precision": "fp16x2", "dw_mode": "exact", "requested": {"precision": "fp16x2", "dw_mode": "exact"}}
+        assert out["trainer"].eng.effective_config().dw_mode == 2
+        # resuming / rendering from it says what trained it
+        out = driver.main(common + ["--pretrained_ckpt", os.path.join(out["logger"].weights_path, "ckpt.tar"), "--render_only",
+                                    "--render_test", "--experiment_name", "arith_back"])
+        assert "checkpoint was trained with r2l_config: precision fp16x2, dw_mode exact" in open(
+            os.path.join(out["logger"].log_path, "log.txt")).read()
+    finally:
+        os.chdir(cwd)
 
 
 def test_create_data_two_ranks_then_continue(tmp_path):

@@ -226,6 +226,38 @@ def test_options_readme_command(tmp_path):
     assert b.use_viewdirs and b.N_importance == 128 and not hasattr(b, "trial")
 
 
+def test_arithmetic_options_parse_and_resolve(tmp_path, monkeypatch):
+    """--r2l_precision / --r2l_dw_mode (this build's own keys, also as config-file lines): parsed next to the reference's flags,
+    and engine.arithmetic() resolves AUTO the way the library does (csrc/r2l_common.h r2l_use_fwd3 / r2l_use_fwd2 / r2l_dw_exact)."""
+    from r2l_amd import _lib, engine
+    from r2l_amd.options import parse_args
+    a = parse_args(["--model_name", "R2L"])
+    assert (a.r2l_precision, a.r2l_dw_mode) == ("auto", "auto")
+    cfg = tmp_path / "c.txt"
+    cfg.write_text("r2l_precision = bf16x3\nr2l_dw_mode = exact\n")
+    a = parse_args(["--config", str(cfg)])
+    assert (a.r2l_precision, a.r2l_dw_mode) == ("bf16x3", "exact")
+    a = parse_args(["--config", str(cfg), "--r2l_precision", "fp32_mfma"])  # the command line wins
+    assert a.r2l_precision == "fp32_mfma"
+    with pytest.raises(SystemExit):
+        parse_args(["--r2l_precision", "fp8"])
+    for k in ("R2L_NO_FWD3", "R2L_NO_FWD2", "R2L_NO_BWD2", "R2L_NO_DW2", "R2L_DW_EXACT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(engine, "DEFAULT_CONFIG", {})
+    assert engine.arithmetic() == {"precision": "fp16x2", "dw_mode": "fp16"}
+    assert engine.arithmetic(_lib.make_config(dw_mode="exact")) == {"precision": "fp16x2", "dw_mode": "exact"}
+    assert engine.arithmetic(_lib.make_config(precision="fp32_mfma")) == {"precision": "fp32_mfma", "dw_mode": "exact"}
+    assert engine.arithmetic(_lib.make_config(precision="bf16x3", dw_mode="fp16")) == {"precision": "bf16x3", "dw_mode": "exact"}
+    monkeypatch.setenv("R2L_NO_FWD3", "1")
+    assert engine.arithmetic()["precision"] == "fp32_mfma"
+    assert engine.arithmetic(_lib.make_config(precision="fp16x2"))["precision"] == "fp16x2"  # an explicit field beats the environment
+    monkeypatch.setenv("R2L_NO_FWD3", "0")
+    monkeypatch.setenv("R2L_DW_EXACT", "1")
+    assert engine.arithmetic() == {"precision": "fp16x2", "dw_mode": "exact"}
+    monkeypatch.setattr(engine, "DEFAULT_CONFIG", {"precision": "bf16x3"})
+    assert engine.arithmetic()["precision"] == "bf16x3"
+
+
 def test_unpickle_reference_checkpoint(golden_dir):
     """ckpt_w32d6.tar was written by the REFERENCE's save_ckpt (pickled reference NeRF_v3_2): it must load into our
     classes without running __init__, and the restored module must compute the reference's rgb."""
@@ -539,14 +571,16 @@ def test_checkpoint_written_here_loads_in_the_reference(tmp_path):
     opt = torch.optim.Adam(m.parameters(), lr=5e-4)
     m(x).sum().backward()
     opt.step()
-    save_ckpt(str(tmp_path / "ckpt.tar"), 7, m, opt.state_dict(), 1.0, 3)
+    # (with the arithmetic record the drivers store, driver.apply_arithmetic: a key the reference's loaders never read)
+    save_ckpt(str(tmp_path / "ckpt.tar"), 7, m, opt.state_dict(), 1.0, 3,
+              r2l_config={"precision": "fp32_mfma", "dw_mode": "exact", "requested": {"precision": "fp32_mfma", "dw_mode": "auto"}})
     torch.save({"x": x, "y": m(x).detach()}, str(tmp_path / "io.pt"))
     code = ("import sys; sys.path.insert(0, '/root/reference')\n"
             "import torch, model.nerf_raybased as rm\n"
             "assert rm.__file__.startswith('/root/reference')\n"
             "ck = torch.load(%r, weights_only=False, map_location='cpu')\n"
             "m = ck['network_fn']\n"
-            "assert type(m) is rm.NeRF_v3_2 and ck['global_step'] == 7\n"
+            "assert type(m) is rm.NeRF_v3_2 and ck['global_step'] == 7 and ck['r2l_config']['precision'] == 'fp32_mfma'\n"
             "m.load_state_dict(ck['network_fn_state_dict'])\n"
             "io = torch.load(%r)\n"
             "assert torch.equal(m(io['x']), io['y'])\n"

@@ -109,7 +109,39 @@ def test_cli_render_eight_ranks(scene_and_teacher):
                                                                   one_test["misc"]["test_ssim"].item())
     assert want in out, (want, [l for l in out.splitlines() if "[TEST]" in l])
     _torchrun(29657, "main.py", common + ["--experiment_name", "eight_video"], root)
-    avis = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs if f.endswith(".avi"))
+    avis = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs if f.endswith(".avi") and "_video" in dp)
     assert len(avis) == 2, avis  # one from the single process, one from rank 0 of the eight
     a, b = (open(f, "rb").read() for f in avis)
     assert a == b and len(a) > 1000  # the same five frames in the same order
+
+
+def test_cli_teacher_render_eight_ranks(scene_and_teacher):
+    """The teacher through `main.py --model_name nerf --render_only` (main.py:275-282) over 8 ranks sharing this GPU: the test
+    frames (2 views: six ranks hold none) and the 9-pose video come out byte for byte as from one process."""
+    from r2l_amd import driver
+    root, scene = scene_and_teacher
+    common = ["--model_name", "nerf", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene, "--pretrained_ckpt",
+              str(root / "teacher.tar"), "--testskip", "1", "--render_only", "--n_pose_video", "9"]
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        one_test = driver.main(common + ["--render_test", "--experiment_name", "t1_test"])
+        driver.main(common + ["--experiment_name", "t1_vid"])
+    finally:
+        os.chdir(cwd)
+    out = _torchrun(29659, "main.py", common + ["--render_test", "--experiment_name", "t8_test"], root)
+    want = "[TEST] TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" % (one_test["misc"]["test_psnr"].item(),
+                                                                  one_test["misc"]["test_psnr_v2"].item(),
+                                                                  one_test["misc"]["test_ssim"].item())
+    assert want in out, (want, [l for l in out.splitlines() if "[TEST]" in l])
+    _torchrun(29661, "main.py", common + ["--experiment_name", "t8_vid"], root)
+
+    def files(tag, ext):
+        hits = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(root) for f in fs if f.endswith(ext) and os.sep + tag + "_" in dp)
+        return {os.path.basename(f).split("_SERVER")[0] if ext == ".avi" else os.path.basename(f): open(f, "rb").read() for f in hits}
+    for tag1, tag8, ext, n in (("t1_test", "t8_test", ".png", 4), ("t1_vid", "t8_vid", ".png", 9), ("t1_vid", "t8_vid", ".avi", 1),
+                               ("t1_test", "t8_test", ".avi", 1)):
+        a, b = files(tag1, ext), files(tag8, ext)
+        assert len(a) == n and a.keys() == b.keys(), (tag1, ext, sorted(a), sorted(b))
+        for k in a:
+            assert a[k] == b[k] and len(a[k]) > 100, (tag1, ext, k)
