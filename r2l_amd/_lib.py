@@ -23,12 +23,15 @@ class Config(ctypes.Structure):
 
 
 PRECISION = {"auto": 0, "fp16x2": 1, "bf16x3": 2, "fp32_mfma": 3}
-TILING = {"auto": 0, "main": 1, "coop": 2, "coop16": 3, "coopf": 4}
+TILING = {"auto": 0, "main": 1, "coop16": 3, "coopf": 4}  # (2 = "coop", the 32-ray fp32-MFMA cooperative family: retired in round 5)
 DW_MODE = {"auto": 0, "fp16": 1, "exact": 2}
 _cfgp = ctypes.POINTER(Config)
 
 
 def make_config(precision="auto", tiling="auto", coop_tiles=0, reserve_cus=0, dw_mode="auto"):
+    if tiling == "coop":
+        raise ValueError("tiling 'coop' (the 32-ray fp32-MFMA cooperative kernels) was retired in round 5: every *_cfg call would "
+                         "fail with it; 'coop16' serves those launches")
     return Config(PRECISION[precision], TILING[tiling], int(coop_tiles), int(reserve_cus), DW_MODE[dw_mode])
 
 

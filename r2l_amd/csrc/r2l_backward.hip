@@ -1232,7 +1232,6 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
                                  grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, parts, layer_lo, layer_hi,
                                  nullptr);
 }
-static thread_local hipEvent_t g_r2l_join_ev = nullptr;  // (the join event of the call in flight: r2l_backward_part_cfg)
 extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                                      const float* emb, const float* rgb, const float* target, const float* drgb,
                                      const float* save_x, const float* save_t,
@@ -1361,30 +1360,46 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
     // stream nothing changes (capturable: the side stream joins the capture and leaves it at the join).  R2L_NO_DW_OVERLAP=1: off.
     hipStream_t hstream = stream;
     bool overlap = false;
-    {
-        static hipStream_t side[16] = {nullptr};
-        static hipEvent_t ev_fork[16], ev_join[16];
-        static int overlap_off = -1;
-        static int64_t overlap_max = R2L_COOPF_MAX_RAYS;
-        if (overlap_off < 0) {
-            overlap_off = r2l_env_on("R2L_NO_DW_OVERLAP") ? 1 : 0;
-            if (const char* e = getenv("R2L_DW_OVERLAP_MAX_RAYS")) overlap_max = atoll(e);  // (tuning knob: tools/r05_run19.sh)
+    // The side stream and its fork / join events belong to the calling THREAD (and device): two host threads driving the same
+    // device never record or wait on each other's events; calls of one thread are issued in order, so a later
+    // call's re-record cannot be seen by an earlier call's already enqueued wait.
+    struct R2LJoin {  // always joins once forked — on the error returns below too (an unjoined fork would invalidate a capture
+        hipStream_t from = nullptr, to = nullptr;  // in progress and let the caller's later work race with head / tail kernels)
+        hipEvent_t ev = nullptr;
+        int join() {
+            if (from == nullptr) return 0;
+            const hipStream_t f = from;
+            from = nullptr;
+            R2L_CHECK(hipEventRecord(ev, f));
+            R2L_CHECK(hipStreamWaitEvent(to, ev, 0));
+            return 0;
         }
+        ~R2LJoin() { (void)join(); }
+    } joiner;
+    {
+        static thread_local hipStream_t side[16] = {nullptr};
+        static thread_local hipEvent_t ev_fork[16], ev_join[16];
+        static const bool overlap_off = r2l_env_on("R2L_NO_DW_OVERLAP");
+        static const int64_t overlap_max = [] {
+            const char* e = getenv("R2L_DW_OVERLAP_MAX_RAYS");  // (tuning knob: tools/run_ab.sh)
+            return e ? (int64_t)atoll(e) : (int64_t)R2L_COOPF_MAX_RAYS;
+        }();
         int dev = 0;
         if (!overlap_off && (parts & R2L_BWD_BODY) && (parts & R2L_BWD_HEAD) && layer_hi > layer_lo && dw_slab != nullptr &&
             N <= overlap_max && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
             if (side[dev] == nullptr) {
-                R2L_CHECK(hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking));
+                hipStream_t st = nullptr;
+                R2L_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
                 R2L_CHECK(hipEventCreateWithFlags(&ev_fork[dev], hipEventDisableTiming));
                 R2L_CHECK(hipEventCreateWithFlags(&ev_join[dev], hipEventDisableTiming));
+                side[dev] = st;  // (last: a failed creation above leaves the slot empty and the next call retries)
             }
             R2L_CHECK(hipEventRecord(ev_fork[dev], stream));
             R2L_CHECK(hipStreamWaitEvent(side[dev], ev_fork[dev], 0));
             hstream = side[dev];
             overlap = true;
+            joiner.from = hstream; joiner.to = stream; joiner.ev = ev_join[dev];
         }
-        // (the join at the end of this function needs the same objects)
-        if (overlap) { g_r2l_join_ev = ev_join[dev]; }
     }
     // 2. body weight gradients
     if ((parts & R2L_BWD_BODY) && layer_hi > layer_lo) {
@@ -1442,6 +1457,7 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         R2LDwHeadArgs a{};
         a.rays_o = rays_o; a.rays_d = rays_d; a.t_rand = t_rand; a.ztab = ztab; a.emb = emb; a.gh = gx; a.grads = grads; a.N = N;
         int64_t slices = n_cu / 4;
+        if (slices > DW_HEAD_SLAB_MAX / (R2L_W * 1024)) slices = DW_HEAD_SLAB_MAX / (R2L_W * 1024);  // (what the slab region holds)
         // small launches: >= 256 rays per slice (each slice costs a 1 MB partial).  (Round 5 tried 128 and 64 rays per slice for the
         // 4096-ray step — 32 / 64 slices instead of 16: 0.789 / 0.823 ms per step against 0.789, same box: what the wider grid gains
         // the 1 MB-per-slice reduce gives back; profiles/r05_small_step_ab.txt)
@@ -1457,7 +1473,8 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         const int64_t slab_floats = slices * (int64_t)(R2L_W * 1024);
         const int64_t gt_floats = (int64_t)n_block * R2L_PAD_ROWS(N) * R2L_W;
         if (slices > 1 && dw_slab != nullptr && slab_floats <= DW_HEAD_SLAB_MAX) a.slab = dw_slab + DW_BODY_SLAB;
-        else a.slab = (slices > 1 && slab_floats <= gt_floats) ? gt : nullptr;
+        // (never `gt` beside the body kernels of an overlapped call: they are still reading it on the other stream)
+        else a.slab = (slices > 1 && slab_floats <= gt_floats && !overlap) ? gt : nullptr;
         const dim3 hg((unsigned)(slices * 4)), hb(256);
         if (trio16 && emb == nullptr) {
             // default trio: the same GEMM on the fp16 matrix pipe (r2l_dw_head16.hip); the fp32 kernel behind it runs only when
@@ -1486,7 +1503,8 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
     // 4. tail gradients
     if (parts & R2L_BWD_TAIL) {
         int64_t wgs = 2 * n_cu;
-        int64_t per = (N + wgs - 1) / wgs;
+        if (wgs > DW_TAIL_SLAB / (4 * R2L_W)) wgs = DW_TAIL_SLAB / (4 * R2L_W);  // (what the slab region holds: no switch of paths,
+        int64_t per = (N + wgs - 1) / wgs;                                      //  i.e. of summation order, on a larger device)
         if (per < 1) per = 1;
         wgs = (N + per - 1) / per;
         // partials in the tail's region of dw_slab; summed in workgroup order
@@ -1501,9 +1519,5 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
             R2L_CHECK(hipGetLastError());
         }
     }
-    if (overlap) {  // join: the caller's stream continues when head + tail are done as well
-        R2L_CHECK(hipEventRecord(g_r2l_join_ev, hstream));
-        R2L_CHECK(hipStreamWaitEvent(stream, g_r2l_join_ev, 0));
-    }
-    return 0;
+    return joiner.join();  // the caller's stream continues when head + tail are done as well
 }

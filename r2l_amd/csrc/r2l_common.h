@@ -14,6 +14,7 @@
 // device (r2l_pack.hip) into the exact per-lane A-operand order, as ONE contiguous stream in
 // consumption order, so every wave streams them with fully coalesced 1 KiB (16 B per lane) buffer loads.
 #pragma once
+#include <stdio.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -395,6 +396,15 @@ __host__ __device__ static inline int64_t r2l_fwd2_stream_floats(int n_block) { 
 enum { F2S_FLAG = 0, F2S_AMAX = 1, F2S_SCALE = 2, F2S_INV = 3, F2S_MAGIC = 4, F2S_TRIPS = 5, F2S_PEAK = 6, F2S_RESCALES = 7,
        F2S_DONE = 8, F2S_GO = 9, F2S_REFINE = 10 };
 #define F2_MAGIC 0x52324c34u
+// The activation scale a fp16x2 stream is packed for / its inverse, as the chain kernels read them: (1, 1) while the status area
+// has not been committed (a zero-filled stream whose stages were written without r2l_fwd2_commit: INV would read 0 and X_0
+// vanish silently) — the same rule as the packers (r2l_f2.h f2_status_scale, r2l_train.hip)
+__device__ __forceinline__ float f2_act_scale(const unsigned* st) {
+    return st[F2S_MAGIC] == F2_MAGIC ? __builtin_bit_cast(float, st[F2S_SCALE]) : 1.0f;
+}
+__device__ __forceinline__ float f2_act_inv(const unsigned* st) {
+    return st[F2S_MAGIC] == F2_MAGIC ? __builtin_bit_cast(float, st[F2S_INV]) : 1.0f;
+}
 __host__ __device__ static inline int64_t r2l_bwd3_stages(int n_block) { return 34 * (int64_t)n_block; }
 __host__ __device__ static inline int64_t r2l_bwd3_stream_floats(int n_block) {
     return (r2l_bwd3_stages(n_block) + R2L_F3_PAD_STAGES) * (24576 / 4);
@@ -464,7 +474,7 @@ static inline const char* r2l_cfg_check(const r2l_config* c) {
     if (c->precision < 0 || c->precision > R2L_PRECISION_FP32_MFMA) return "r2l_config.precision: not an R2L_PRECISION_* value";
     if (c->tiling < 0 || c->tiling > R2L_TILING_COOPF) return "r2l_config.tiling: not an R2L_TILING_* value";
     if (c->tiling == R2L_TILING_COOP_RETIRED) return "r2l_config.tiling: 2 (the 32-ray fp32-MFMA cooperative kernels) was retired in round 5 — R2L_TILING_COOP16 serves those launches";
-    if (c->coop_tiles < 0 || c->coop_tiles > 2) return "r2l_config.coop_tiles: 0 (auto), 1 or 2";
+    if (c->coop_tiles < 0 || c->coop_tiles > 3) return "r2l_config.coop_tiles: 0 (auto), 1, 2 or 3 (mixed)";
     if (c->reserve_cus < -1) return "r2l_config.reserve_cus: -1 (none), 0 (auto) or a CU count";
     if (c->dw_mode < 0 || c->dw_mode > R2L_DW_EXACT) return "r2l_config.dw_mode: not an R2L_DW_* value";
     if (c->reserved[0] || c->reserved[1] || c->reserved[2]) return "r2l_config.reserved: must be 0";
@@ -559,7 +569,16 @@ static inline int r2l_forced_tiling() {
     if (!e || !e[0]) return R2L_TILING_AUTO;
     if (e[0] == 'm') return R2L_TILING_WAVE_PER_TILE;
     if (e[0] == 'c' && e[1] && e[2] && e[3] && e[4] == 'f') return R2L_TILING_COOPF;
-    if (e[0] == 'c') return R2L_TILING_COOP16;  // (coop16; "coop" named the retired 32-ray family: its launches are coop16's now)
+    if (e[0] == 'c') {  // coop16; "coop" named the retired 32-ray family: its launches are coop16's now — said once, not silently
+        if (e[1] && e[2] && e[3] && !e[4]) {
+            static bool warned = false;
+            if (!warned) {
+                warned = true;
+                fprintf(stderr, "libr2l_hip: R2L_FORCE_VARIANT=coop names the kernel family retired in round 5; taking coop16\n");
+            }
+        }
+        return R2L_TILING_COOP16;
+    }
     return R2L_TILING_WAVE_PER_TILE;  // (anything else used to mean "not the cooperative fp16 kernels")
 }
 static inline bool r2l_use_coopf(int64_t N, int n_block) {

@@ -246,21 +246,37 @@ __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bop
     if (MASK) *mword = mw;
 }
 
-// ray tiles per workgroup: 1 while that keeps the launch within one workgroup per CU, else 2 (R2L_COOPF_TILES=1|2 overrides)
-static inline bool r2l_coopf_two_tiles(int64_t tiles) {
-    if (g_r2l_cfg.coop_tiles == 1) return false;
-    if (g_r2l_cfg.coop_tiles == 2) return true;
-    if (const char* e = getenv("R2L_COOPF_TILES")) {
-        if (e[0] == '1') return false;
-        if (e[0] == '2') return true;
-    }
+// ray tiles per workgroup: 1 while that keeps the launch within one workgroup per CU; 2 from two tiles per CU on; in between
+// (n_cu < tiles < 2 n_cu) the MIXED grid (3): tiles - n_cu two-tile workgroups and 2 n_cu - tiles one-tile ones = one workgroup
+// on every CU, where ceil(tiles / 2) two-tile workgroups leave CUs idle for the whole chain (r2l_coopf_fwd.hip).
+// r2l_config.coop_tiles = 1 | 2 | 3, else R2L_COOPF_TILES=1|2|3, pins the policy (3 outside its band: 1 below, 2 above).
+static inline int r2l_coopf_n_cu() {
     static int n_cu = 0;  // one device type per process
     if (n_cu == 0) {
         int dev = 0, v = 0;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    return tiles > n_cu;
+    return n_cu;
 }
+static inline int r2l_coopf_policy(int64_t tiles) {
+    int want = g_r2l_cfg.coop_tiles;
+    if (want == 0) {
+        if (const char* e = getenv("R2L_COOPF_TILES")) {
+            if (e[0] >= '1' && e[0] <= '3') want = e[0] - '0';
+        }
+    }
+    if (want == 1 || want == 2) return want;
+    const int n_cu = r2l_coopf_n_cu();
+    if (tiles <= n_cu) return 1;
+    if (tiles >= 2 * (int64_t)n_cu) return 2;
+#ifdef FC_NO_MIXED_AUTO  // A/B builds: AUTO keeps the round-5 policy (two tiles from n_cu + 1 tiles on)
+    if (want == 0) return 2;
+#endif
+    return 3;
+}
+static inline bool r2l_coopf_two_tiles(int64_t tiles) { return r2l_coopf_policy(tiles) == 2; }
+// two-tile workgroups of a MIXED launch (its grid has tiles - this many workgroups), or 0: not a mixed launch
+static inline int r2l_coopf_mixed_two(int64_t tiles) { return r2l_coopf_policy(tiles) == 3 ? (int)(tiles - r2l_coopf_n_cu()) : 0; }
 
 // launchers (called from r2l_fwd2_forward / r2l_bwd2_backward when the launch is small: r2l_use_coopf)
 int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* c2w_host12,

@@ -37,6 +37,7 @@ struct CfBwdArgs {
     // idle: g then crosses the launch boundary as fp32 fragments in the tile's row-major area of gx slot 0 (which only the
     // last launch finally fills), every other value takes the path it takes in one launch: results are bit-identical.
     int b_start, b_end;
+    int n_two;  // mixed launch: workgroups 0 .. n_two - 1 take two ray tiles, the others one
 };
 
 // masked u: bit tt*16 + c of the forward's mask word of this wave
@@ -45,10 +46,10 @@ struct CfMask {
     __device__ __forceinline__ float operator()(float v, int tt, int c) const { return ((w >> (tt * 16 + c)) & 1u) ? v : 0.f; }
 };
 
-template <int NT, bool MID = false>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
-    // B-operand images: [g | masked u][ray tile][16 stages x (hi, mid) x 1 KiB]
-    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
+// The dX chain of one workgroup on the NT ray tiles tile0 .. tile0 + NT - 1; bop_lds = LDS byte address of the B-operand images
+// [g | masked u][ray tile][16 stages x (hi, mid) x 1 KiB] (the kernel's allocation: the mixed launch below runs both bodies)
+template <int NT, bool MID>
+__device__ __forceinline__ void cf_bwd_body(const CfBwdArgs& a, const int64_t tile0, const unsigned bop_lds) {
     if (__builtin_nontemporal_load(a.fmt) != 0u) {  // the forward's stash is the bf16x3 trio's: so is this step's backward
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
         return;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     int64_t tile[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
-        tile[rt] = (int64_t)blockIdx.x * NT + rt;
+        tile[rt] = tile0 + rt;
         if (tile[rt] > n_tiles - 1) tile[rt] = n_tiles - 1;
     }
     const int64_t Np = R2L_PAD_ROWS(a.N);
@@ -166,7 +167,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     f16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
-    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
     constexpr unsigned KIND = NT * FC_BOP_BYTES;
     const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;
     const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;
@@ -275,6 +275,24 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(con
     }
 }
 
+template <int NT, bool MID = false>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_bwd_kernel(const CfBwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
+    cf_bwd_body<NT, MID>(a, (int64_t)blockIdx.x * NT, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0]);
+}
+
+// MIXED launch (r2l_coopf_fwd.hip r2l_coopf_fwd_mixed_kernel: same tile -> workgroup map, so a tile's stash is read by the
+// role that wrote it — not that it matters: every tile takes the same path in either role)
+template <bool MID>
+__global__ __launch_bounds__(256, 1) void r2l_coopf_bwd_mixed_kernel(const CfBwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][2][FC_BOP_BYTES];
+    // (128 KiB: at most one workgroup per CU — the one-tile body must not share a SIMD with a second wave, r2l_coopf.h)
+    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    if (b < a.n_two) cf_bwd_body<2, MID>(a, (int64_t)2 * b, bop_lds);
+    else cf_bwd_body<1, MID>(a, (int64_t)a.n_two + b, bop_lds);
+}
+
 int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb, const float* save_x, const float* save_t,
                        const float* wstream_bwd2, const float* params, int n_block, float grad_scale, float* dpre, float* gx,
                        float* gt, float* sqerr_partial, int64_t N, hipStream_t stream, float gscale, unsigned* status,
@@ -292,7 +310,12 @@ int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb,
     a.mid_units = r2l_dw_exact() ? R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) / 16 : 0;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
     static int solo_ok[2] = {0, 0};
-    if (a.mid_units != 0) {  // exact weight gradients: the mid halves of g / masked u are stashed too
+    if (const int n_two = r2l_coopf_mixed_two(tiles); n_two > 0) {  // between one and two tiles per CU: one workgroup on every CU
+        a.n_two = n_two;
+        const dim3 grid((unsigned)(tiles - n_two));
+        if (a.mid_units != 0) hipLaunchKernelGGL((r2l_coopf_bwd_mixed_kernel<true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((r2l_coopf_bwd_mixed_kernel<false>), grid, dim3(256), 0, stream, a);
+    } else if (a.mid_units != 0) {  // exact weight gradients: the mid halves of g / masked u are stashed too
         if (r2l_coopf_two_tiles(tiles))
             hipLaunchKernelGGL((r2l_coopf_bwd_kernel<2, true>), dim3((unsigned)((tiles + 1) / 2)), dim3(256), 0, stream, a);
         else {

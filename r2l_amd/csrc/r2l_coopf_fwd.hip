@@ -29,15 +29,16 @@ struct CfFwdArgs {
     float* save_t;
     int64_t N;
     int64_t mid_units;  // != 0: mid quads stashed this many 16-byte units behind the hi pieces (exact weight gradients)
+    int n_two;          // mixed launch: workgroups 0 .. n_two - 1 take two ray tiles, the others one
 };
 
-template <bool POSE, bool SAVE, int NT, bool MID = false>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
-    // B-operand images: [x | relu(t)][ray tile][16 stages x (hi, mid) x 1 KiB]
-    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
-    __shared__ float pts[NT * 32][49];  // the tiles' 16 x 3 point coordinates per ray (row stride 49: conflict-free column reads)
-    __shared__ float red[4][NT * 32][3];
-
+// The chain of one workgroup on the NT ray tiles tile0 .. tile0 + NT - 1.  LDS comes from the kernel (the mixed launch below
+// runs the NT = 1 and the NT = 2 body from ONE kernel's allocation): bop_lds = LDS byte address of the B-operand images
+// [x | relu(t)][ray tile][16 stages x (hi, mid) x 1 KiB], pts = the tiles' 16 x 3 point coordinates per ray (row stride 49:
+// conflict-free column reads), red = [4 waves][NT * 32 rays][3] partial tail sums.
+template <bool POSE, bool SAVE, int NT, bool MID>
+__device__ __forceinline__ void cf_fwd_body(const CfFwdArgs& a, const int64_t tile0, const unsigned bop_lds, float (*pts)[49],
+                                            float (*red)[3]) {
     if (__builtin_nontemporal_load(a.status) != 0u) return;  // these weights left fp16's range before: the bf16x3 kernel behind
 #ifdef FC_SKEW  // diagnostic builds: the second workgroup of every CU starts FC_SKEW x ~4 us late (which neighbour phase arms the fault?)
     if (blockIdx.x >= 256)
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
     int64_t tile[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
-        tile[rt] = (int64_t)blockIdx.x * NT + rt;
+        tile[rt] = tile0 + rt;
         if (tile[rt] > n_tiles - 1) tile[rt] = n_tiles - 1;
     }
     const int64_t Np = R2L_PAD_ROWS(a.N);
@@ -112,7 +113,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (_Float16)((h == 0 && k < 2) ? 1.0f : 0.0f);
 
-    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
     constexpr unsigned KIND = NT * FC_BOP_BYTES;                                        // x images -> relu(t) images
     const unsigned bop_rd = bop_lds + (unsigned)lane * 16u;                            // + kind*KIND + rt*32768 + kb*2048 (+1024)
     const unsigned bop_wr = bop_lds + (unsigned)lane * 16u + (unsigned)wave * 8192u;    // stage 4w of x image 0
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         if (c < 3) fc_barrier();
     }
     // the head ran on unscaled weights (r2l_f2.h range control): the chain continues on X_0 / act_s (exact: a power of two)
-    const float act_inv = __builtin_bit_cast(float, a.status[F2S_INV]);
+    // (uniform words, kept in SGPRs: as VGPR values hipcc pairs them with a neighbour and broadcasts with the packed-multiply
+    // op_sel form the ISA audit refuses, r2l_amd/build.py)
+    const float act_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f2_act_inv(a.status))));
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         mwp[rt] = SAVE ? reinterpret_cast<unsigned*>(a.save_t + R2L_MASK_OFFSET(Np) + tile[rt] * 256 + lane * 4) + wave : nullptr;
     }
     // the activation scale this stream was packed for (r2l_f2.h range control): what the chain holds is x / act_s
-    const float act_s = __builtin_bit_cast(float, a.status[F2S_SCALE]);
+    const float act_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f2_act_scale(a.status))));
     if (SAVE && blockIdx.x == 0 && threadIdx.x == 0) {  // stash format word: fp16 stage pieces (a fallback launch overwrites it),
         reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;  // and the scale of the stashed x, relu(t)
         reinterpret_cast<float*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np) + 1] = act_s;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
         for (int c = 0; c < 3; ++c) p3[c] += __shfl_xor(p3[c], 32);
         if (h == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) red[wave][rt * 32 + j][c] = p3[c];
+            for (int c = 0; c < 3; ++c) red[wave * (NT * 32) + rt * 32 + j][c] = p3[c];
         }
     }
     __syncthreads();
@@ -348,11 +350,38 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(con
             const int rj = rt * 32 + j;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = ((red[0][rj][c] + red[1][rj][c]) + (red[2][rj][c] + red[3][rj][c])) * act_s + a.params[cf_off_tail_b(a.n_block) + c];
+                const float v = ((red[rj][c] + red[NT * 32 + rj][c]) + (red[2 * NT * 32 + rj][c] + red[3 * NT * 32 + rj][c])) * act_s +
+                                a.params[cf_off_tail_b(a.n_block) + c];
                 a.rgb[ray * 3 + c] = 1.0f / (1.0f + expf(-v));
             }
         }
     }
+}
+
+template <bool POSE, bool SAVE, int NT, bool MID = false>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void r2l_coopf_fwd_kernel(const CfFwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][NT][FC_BOP_BYTES];
+    __shared__ float pts[NT * 32][49];
+    __shared__ float red[4 * NT * 32][3];
+    cf_fwd_body<POSE, SAVE, NT, MID>(a, (int64_t)blockIdx.x * NT,
+                                     (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0], pts, red);
+}
+
+// MIXED launch (tile counts between one and two per CU, n_cu < tiles <= 2 n_cu: the per-GPU share of the README's 98 304-ray
+// step at 8 GPUs is 12 288 rays = 384 tiles): ONE grid of n_cu workgroups, the first a.n_two of them with two ray tiles
+// (tiles 2b, 2b + 1), the others with one (tile 2 n_two + (b - n_two)) — instead of ceil(tiles / 2) two-tile workgroups that
+// leave n_cu - tiles / 2 CUs idle for the whole chain.  Each tile takes exactly the path it takes in the NT = 1 / NT = 2 kernels
+// (same streams, stash, summation order): results are bit-identical to both.  The NT = 2 allocation (143 KiB) keeps it to one
+// workgroup per CU (r2l_coopf.h: the one-tile body must not share a SIMD with a second wave).
+template <bool SAVE, bool MID>
+__global__ __launch_bounds__(256, 1) void r2l_coopf_fwd_mixed_kernel(const CfFwdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char bop[2][2][FC_BOP_BYTES];
+    __shared__ float pts[2 * 32][49];
+    __shared__ float red[4 * 2 * 32][3];
+    const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    if (b < a.n_two) cf_fwd_body<false, SAVE, 2, MID>(a, (int64_t)2 * b, bop_lds, pts, red);
+    else cf_fwd_body<false, SAVE, 1, MID>(a, (int64_t)a.n_two + b, bop_lds, pts, red);  // 2 n_two + (b - n_two)
 }
 
 int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* c2w_host12,
@@ -366,7 +395,17 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
     if (c2w_host12) for (int i = 0; i < 12; ++i) a.c2w[i] = c2w_host12[i];
     a.mid_units = (save_x != nullptr && r2l_dw_exact()) ? R2L_H16_MID_BYTES(R2L_PAD_ROWS(N)) / 16 : 0;
     const int64_t tiles = (N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS;
-    // up to one workgroup per CU: one ray tile each; beyond, two tiles per workgroup share every weight load
+    // up to one workgroup per CU: one ray tile each; beyond, two tiles per workgroup share every weight load; between one and
+    // two tiles per CU: the mixed grid (explicit rays only: the single-pose render launches are far above this band)
+    if (const int n_two = r2l_coopf_mixed_two(tiles); n_two > 0 && !c2w_host12) {
+        a.n_two = n_two;
+        const dim3 grid((unsigned)(tiles - n_two)), block(256);
+        if (save_x && a.mid_units != 0) hipLaunchKernelGGL((r2l_coopf_fwd_mixed_kernel<true, true>), grid, block, 0, stream, a);
+        else if (save_x) hipLaunchKernelGGL((r2l_coopf_fwd_mixed_kernel<true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((r2l_coopf_fwd_mixed_kernel<false, false>), grid, block, 0, stream, a);
+        R2L_CHECK(hipGetLastError());
+        return 0;
+    }
     const bool two = r2l_coopf_two_tiles(tiles);
     const dim3 grid((unsigned)(two ? (tiles + 1) / 2 : tiles)), block(256);
     static int solo_ok[4] = {0, 0, 0, 0};  // one-tile kernels: at most one workgroup per CU, verified before the first launch
@@ -404,6 +443,6 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
 extern "C" int r2l_coop_tiles_for_cfg(int64_t N, int n_block, const r2l_config* cfg) {
     R2L_CFG_QUERY(cfg);
     if (!r2l_use_coopf(N, n_block)) return 0;
-    return r2l_coopf_two_tiles((N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS) ? 2 : 1;
+    return r2l_coopf_policy((N + R2L_TILE_RAYS - 1) / R2L_TILE_RAYS);
 }
 extern "C" int r2l_coop_tiles_for(int64_t N, int n_block) { return r2l_coop_tiles_for_cfg(N, n_block, nullptr); }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     f2_stage<false, false, true>(x, P, F3None{}, F3None{});
     // the head ran on unscaled weights (r2l_f2.h range control): the chain continues on X_0 / act_s — one fp32 multiply by a
     // power of two per value (1.0 for every net below the guard: bit-identical to the unscaled chain)
-    const float act_inv = __builtin_bit_cast(float, a.status[F2S_INV]);
+    const float act_inv = f2_act_inv(a.status);
 #pragma unroll
     for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd2_kernel(const F2Args a) {
     const F3Dma no_dma{false, u32x4{0u, 0u, 0u, 0u}, 0u, 0u, 0u};
     constexpr bool mid = SAVE && MID;
     // the activation scale this stream was packed for (r2l_f2.h range control): what the chain holds is x / act_s
-    const float act_s = __builtin_bit_cast(float, a.status[F2S_SCALE]);
+    const float act_s = f2_act_scale(a.status);
     if (SAVE && blockIdx.x == 0 && threadIdx.x == 0) {  // stash format word: fp16 stage pieces (a fallback launch overwrites it),
         reinterpret_cast<unsigned*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np)] = 0u;  // and the scale of the stashed x, relu(t)
         reinterpret_cast<float*>(a.save_x)[R2L_STASH_FMT_WORD(a.n_block, Np) + 1] = act_s;

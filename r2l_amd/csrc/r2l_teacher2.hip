@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
         }
     }
     const float* P0 = a.params;
-    const float act_s = __builtin_bit_cast(float, a.status[F2S_SCALE]);  // the activation scale the stream is packed for
+    const float act_s = f2_act_scale(a.status);  // the activation scale the stream is packed for
 
     F2Pipe P;
     {
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void r2l_teacher2_kernel(const T2Args a) {
     f2_stage<false, false, false>(x, P, Xyz4{p, h, 24}, Xyz4{p, h, 28});
     f2_stage<false, false, true>(x, P, F3None{}, F3None{});
     {   // layer 0 ran on unscaled weights: the chain continues on x / act_s (a power of two, 1.0 for every teacher in range)
-        const float act_inv = __builtin_bit_cast(float, a.status[F2S_INV]);
+        const float act_inv = f2_act_inv(a.status);
 #pragma unroll
         for (int T = 0; T < R2L_NT; ++T)
 #pragma unroll

@@ -119,7 +119,7 @@ class R2LEngine:
         self.cfg = _lib.Config()
 
     def set_config(self, **kw):
-        """precision='auto|fp16x2|bf16x3|fp32_mfma', tiling='auto|main|coop|coop16|coopf', coop_tiles=0|1|2,
+        """precision='auto|fp16x2|bf16x3|fp32_mfma', tiling='auto|main|coop16|coopf', coop_tiles=0|1|2|3 (mixed),
         reserve_cus=n, dw_mode='auto|fp16|exact'.  Weight streams are layout-specific: they re-pack on the next call."""
         cur = dict(precision=self.cfg.precision, tiling=self.cfg.tiling, coop_tiles=self.cfg.coop_tiles,
                    reserve_cus=self.cfg.reserve_cus, dw_mode=self.cfg.dw_mode)

@@ -58,6 +58,8 @@ def test_explicit_config_dispatch(monkeypatch):
     assert lib.r2l_coop_tiles_for_cfg(98304, 43, ref(_lib.make_config(tiling="coopf"))) == 2
     assert lib.r2l_coop_tiles_for_cfg(4096, 43, ref(_lib.make_config(coop_tiles=2))) == 2
     assert lib.r2l_coop_tiles_for_cfg(12288, 43, ref(_lib.make_config(coop_tiles=1))) == 1
+    assert lib.r2l_coop_tiles_for_cfg(12288, 43, ref(_lib.make_config(coop_tiles=2))) == 2
+    assert lib.r2l_coop_tiles_for_cfg(12288, 43, ref(_lib.make_config(coop_tiles=3))) == 3
     # explicit fields beat the environment; AUTO fields follow it; nothing sticks after the call
     monkeypatch.setenv("R2L_NO_FWD2", "1")
     monkeypatch.setenv("R2L_FORCE_VARIANT", "coop16")
@@ -67,8 +69,12 @@ def test_explicit_config_dispatch(monkeypatch):
     assert lib.r2l_variant_for_cfg(98304, ref(f16)) == 2  # tiling AUTO: the environment's coop16
     assert lib.r2l_forward_layout_for(98304, 1) == 16 and lib.r2l_variant_for(98304) == 2
     # the 32-ray fp32-MFMA cooperative family (tiling value 2) was retired in round 5: the value stays reserved and is refused
-    assert lib.r2l_variant_for_cfg(4096, ref(_lib.make_config(tiling="coop"))) == -1
+    retired = _lib.make_config()
+    retired.tiling = 2
+    assert lib.r2l_variant_for_cfg(4096, ref(retired)) == -1
     assert b"retired" in lib.r2l_last_error()
+    with pytest.raises(ValueError, match="retired"):  # ... and the Python binding no longer offers the name
+        _lib.make_config(tiling="coop")
 
 
 def test_invalid_config_is_rejected():
@@ -78,7 +84,7 @@ def test_invalid_config_is_rejected():
     from r2l_amd import _lib
     lib = _lib.load()
     bad = []
-    for field, value in (("precision", 4), ("precision", -1), ("tiling", 5), ("coop_tiles", 3), ("reserve_cus", -2),
+    for field, value in (("precision", 4), ("precision", -1), ("tiling", 5), ("coop_tiles", 4), ("reserve_cus", -2),
                          ("dw_mode", 3)):
         c = _lib.make_config()
         setattr(c, field, value)
@@ -166,10 +172,13 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     assert lib.r2l_forward_layout_for(4096, 1) == 2 and lib.r2l_backward_layout_for(4096) == 2
     assert lib.r2l_forward_layout_for(98304, 1) == 2 and lib.r2l_forward_layout_for(160000, 0) == 2
     assert lib.r2l_backward_layout_for(98304) == 2
-    # ... cooperative: one tile per workgroup up to one tile per CU, two above, up to 16 384 rays; and again (two tiles) where
-    # the one-wave-per-tile kernels would run a half-empty second round
-    assert [lib.r2l_coop_tiles_for(n, 43) for n in (32, 4096, 8192, 8193, 16384, 16385, 32768, 32769, 49152, 49153, 98304,
-                                                     160000)] == [1, 1, 1, 2, 2, 0, 0, 2, 2, 0, 0, 0]
+    # ... cooperative: one tile per workgroup up to one tile per CU, two from two tiles per CU on, the MIXED grid (3: two-tile and
+    # one-tile workgroups, one on every CU) in between, up to 16 384 rays; and again (two tiles) where the one-wave-per-tile
+    # kernels would run a half-empty second round
+    assert [lib.r2l_coop_tiles_for(n, 43) for n in (32, 4096, 8192, 8193, 12288, 16352, 16353, 16384, 16385, 32768, 32769, 49152,
+                                                     49153, 98304, 160000)] == [1, 1, 1, 3, 3, 3, 2, 2, 0, 0, 2, 2, 0, 0, 0]
+    monkeypatch.setenv("R2L_COOPF_TILES", "3")  # mixed pinned: outside its band one tile below, two above
+    assert [lib.r2l_coop_tiles_for(n, 43) for n in (4096, 12288, 16384)] == [1, 3, 2]
     monkeypatch.setenv("R2L_COOPF_TILES", "2")
     assert lib.r2l_coop_tiles_for(4096, 43) == 2 and lib.r2l_coop_tiles_for(98304, 43) == 0
     monkeypatch.delenv("R2L_COOPF_TILES")

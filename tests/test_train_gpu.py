@@ -681,6 +681,51 @@ def test_coopf_one_tile_beside_other_kernels(chain_variant, monkeypatch):
                 assert torch.equal(x, y), kind
 
 
+@pytest.mark.parametrize("n,dw_mode,segments", [(12288 - 5, "fp16", 1), (8192 + 32, "fp16", 1), (16384 - 64, "exact", 1),
+                                                 (12288, "fp16", 3)])
+def test_mixed_cooperative_launch_is_bit_identical(chain_variant, monkeypatch, n, dw_mode, segments):
+    """Tile counts between one and two per CU (256 < tiles < 512; 12 288 rays = the per-GPU share of the README's step at 8
+    GPUs, /root/reference/main.py:1371-1406) run as ONE grid of tiles - 256 two-tile and 512 - tiles one-tile cooperative
+    workgroups (r2l_config.coop_tiles = 3, AUTO's choice in that band; csrc/r2l_coopf_fwd.hip r2l_coopf_fwd_mixed_kernel).
+    Every tile takes the path it takes in the one-tile and in the two-tile kernels: rgb, loss and the whole flat gradient are
+    bit-identical to both forced forms — also with the mid halves stashed (exact dW) and with the dX chain cut into segments."""
+    if chain_variant != "coopf":
+        pytest.skip("one comparison")
+    from model.nerf_raybased import PointSampler
+    from r2l_amd import _lib
+    from r2l_amd.train_step import R2LTrainer
+    from tests.conftest import use_family
+    use_family(monkeypatch)
+    for k in ("R2L_COOPF_TILES", "R2L_FORCE_VARIANT"):
+        monkeypatch.delenv(k, raising=False)
+    nb = 43 if segments == 1 and dw_mode == "fp16" and n == 12288 - 5 else 6
+    sd = O.make_state_dict(n_block=nb, seed=3)
+    ps = PointSampler(400, 400, 555.5555155968841, 16, 2., 6.)
+    g = torch.Generator().manual_seed(n)
+    o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    tgt = torch.rand(n, 3, generator=g).cuda(); tr = torch.rand(n, 16, generator=g).cuda()
+
+    def run(tiles):
+        m = build_model(sd, nb)
+        t = R2LTrainer(m, ps, dw_mode=dw_mode, chain_segments=segments)
+        t.calibrate = False
+        t.eng.set_config(precision="fp16x2", tiling="coopf", coop_tiles=tiles)
+        if segments > 1:
+            t.force_staged = True
+        assert _lib.load().r2l_coop_tiles_for_cfg(n, nb, t.eng._cfg()) == (tiles or 3)
+        rgb = t.forward_backward(o, d, tgt, perturb=1.0, t_rand=tr)
+        with torch.no_grad():
+            plain = m.forward_rays(o, d, ps, perturb=1.0, t_rand=tr)
+        return t.loss_out.clone(), rgb.clone(), t.grads.clone(), plain.clone()
+
+    mixed, auto, one, two = run(3), run(0), run(1), run(2)
+    assert torch.isfinite(mixed[2]).all() and mixed[2].abs().max().item() > 0
+    for other, name in ((auto, "auto"), (one, "one tile"), (two, "two tiles")):
+        for x, y, what in zip(mixed, other, ("loss", "rgb", "grads", "forward-only rgb")):
+            assert torch.equal(x, y), (name, what)
+
+
 def test_mid_size_step_on_cooperative_chains(chain_variant, monkeypatch):
     """Launches between one and one and a half rounds of the one-wave-per-tile kernels (32 769 .. 49 152 rays) take the
     two-tile cooperative chains by default (csrc/r2l_common.h r2l_use_coopf): same step within rounding, ragged size."""

@@ -26,13 +26,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     res = {}
-    for v in ("main", "coop", "coop16"):
+    for v in ("main", "coopf", "coop16"):  # ("coop", the 32-ray fp32-MFMA cooperative family, was retired in round 5)
         env = dict(os.environ, R2L_FORCE_VARIANT=v)
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         res[v] = json.loads(r.stdout.strip().splitlines()[-1])
-    print("%8s | %10s %10s %10s | %10s %10s %10s" % ("rays", "fwd main", "fwd coop", "fwd c16", "step main", "step coop",
+    print("%8s | %10s %10s %10s | %10s %10s %10s" % ("rays", "fwd main", "fwd coopf", "fwd c16", "step main", "step coopf",
                                                        "step c16"))
     for n in res["main"]:
         print("%8s | %8.3f ms %8.3f ms %8.3f ms | %8.3f ms %8.3f ms %8.3f ms" % (
-            n, res["main"][n][0], res["coop"][n][0], res["coop16"][n][0], res["main"][n][1], res["coop"][n][1],
+            n, res["main"][n][0], res["coopf"][n][0], res["coop16"][n][0], res["main"][n][1], res["coopf"][n][1],
             res["coop16"][n][1]))
