@@ -244,6 +244,7 @@ def teacher_leg(device, world, rank, distributed, frames=2, precision="fp16x2"):
     peak = PEAK_BF16_MFMA / 3. if fwd2 else (PEAK_BF16_MFMA / 6. if fwd3 else PEAK_FP32_MFMA)
     return {"value": H * W * frames * world / dt, "unit": "rays/s", "ms_per_frame": dt / frames * 1e3,
             "precision": precision, "range": teacher_engine(nets[1]).range_info() if fwd2 else None,
+            "parallelism": "poses sharded across %d rank(s), no collective" % world,
             "workload": "NeRF teacher render 400x400, 64+128 samples/ray, perturb=1, chunk 32768 (create_data rand)",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "peak_fp32_mfma": PEAK_FP32_MFMA, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA,

@@ -76,6 +76,8 @@ struct BwdAHook {
         asm volatile("" : "+v"(tvo));
         pend[G & 1] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo + (unsigned)(32 * (G >> 2) + 8 * (G & 3)) * 4u, 0, 0));
+#elif defined(R2L_TIMING_NO_MASK_LOAD)  // timing builds only: what reading save_t for its signs costs (results are wrong)
+        pend[G & 1] = f32x4{1.f, 1.f, 1.f, 1.f};
 #else
         pend[G & 1] = *reinterpret_cast<const f32x4*>(trow + 32 * (G >> 2) + 8 * (G & 3));
 #endif

@@ -173,7 +173,26 @@ struct NoHook {
 // stores retire through the same in-order vmcnt queue as the weight prefetches — but only for stores that cover whole
 // cache lines: the 32- / 64-byte fragment pieces of the chain kernels rely on L2 to merge partial lines (same-box A/B
 // with nt on those: 98 304-ray step 25.2 -> 34 ms).  Whole-row stores (r2l_coop16.hip): 462 -> 446 us with nt.
+#ifdef R2L_STASH_ST_AUX  // A/B builds (tools/mkvar.sh ... -DR2L_STASH_ST_AUX=1|2|3|4): cache policy of the fragment-piece stores
+#if R2L_STASH_ST_AUX == 1
+#define R2L_STASH_ST_POLICY "sc1"
+#elif R2L_STASH_ST_AUX == 2
+#define R2L_STASH_ST_POLICY "nt"
+#elif R2L_STASH_ST_AUX == 3
+#define R2L_STASH_ST_POLICY "sc1 nt"
+#else
+#define R2L_STASH_ST_POLICY "sc0 sc1"
+#endif
+__device__ __forceinline__ void r2l_stash_store(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off " R2L_STASH_ST_POLICY : : "v"(p), "v"(v) : "memory");
+}
+#elif defined(R2L_TIMING_NO_STASH_STORE)  // timing builds only: what the ride-along stores cost (results are wrong)
+__device__ __forceinline__ void r2l_stash_store(float* p, const f32x4& v) {
+    if (__builtin_expect(v[0] == 1.2345e-33f, 0)) *reinterpret_cast<f32x4*>(p) = v;
+}
+#else
 __device__ __forceinline__ void r2l_stash_store(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+#endif
 __device__ __forceinline__ void r2l_stash_store_nt(float* p, const f32x4& v) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }

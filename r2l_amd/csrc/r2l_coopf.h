@@ -278,6 +278,23 @@ static inline bool r2l_coopf_two_tiles(int64_t tiles) { return r2l_coopf_policy(
 // two-tile workgroups of a MIXED launch (its grid has tiles - this many workgroups), or 0: not a mixed launch
 static inline int r2l_coopf_mixed_two(int64_t tiles) { return r2l_coopf_policy(tiles) == 3 ? (int)(tiles - r2l_coopf_n_cu()) : 0; }
 
+// Position of this workgroup in the role order of a MIXED launch.  The two roles run at different paces (one tile: ~3.1 us per
+// layer, two tiles: ~4.5 us), and the workgroups of one XCD share the weight stream through that XCD's 4 MiB L2 only while they
+// stay within a few blocks (0.57 MB each) of each other: with the roles interleaved over the XCDs (position = blockIdx) the
+// one-tile workgroups run ahead and every XCD fetches the stream twice — measured SLOWER than the plain two-tile launch
+// (profiles/r06_mixed_coopf_ab.txt).  xcd_major: position = (blockIdx % 8) * (grid / 8) + blockIdx / 8 — workgroups are dealt to
+// the 8 XCDs round-robin, so the two-tile roles fill whole XCDs and the one-tile roles the others (at most one XCD holds both).
+__device__ __forceinline__ int fc_mixed_index(int xcd_major) {
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int g = (int)gridDim.x;
+    if (!xcd_major || (g & 7) != 0) return b;
+    return (b & 7) * (g >> 3) + (b >> 3);
+}
+static inline int r2l_coopf_mixed_xcd_major() {
+    const char* e = getenv("R2L_MIXED_MAP");  // A/B knob: 0 = roles by blockIdx, 1 (default) = XCD-major
+    return (e && e[0] == '0') ? 0 : 1;
+}
+
 // launchers (called from r2l_fwd2_forward / r2l_bwd2_backward when the launch is small: r2l_use_coopf)
 int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab, const float* c2w_host12,
                       int H, int W, float focal, const float* wstream2, const float* params, int n_block, float* rgb,

@@ -37,7 +37,8 @@ struct CfBwdArgs {
     // idle: g then crosses the launch boundary as fp32 fragments in the tile's row-major area of gx slot 0 (which only the
     // last launch finally fills), every other value takes the path it takes in one launch: results are bit-identical.
     int b_start, b_end;
-    int n_two;  // mixed launch: workgroups 0 .. n_two - 1 take two ray tiles, the others one
+    int n_two;  // mixed launch: workgroups 0 .. n_two - 1 (in fc_mixed_index order) take two ray tiles, the others one
+    int xcd_major;
 };
 
 // masked u: bit tt*16 + c of the forward's mask word of this wave
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void r2l_coopf_bwd_mixed_kernel(const CfBwd
     __shared__ __attribute__((aligned(1024))) unsigned char bop[2][2][FC_BOP_BYTES];
     // (128 KiB: at most one workgroup per CU — the one-tile body must not share a SIMD with a second wave, r2l_coopf.h)
     const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
-    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int b = fc_mixed_index(a.xcd_major);
     if (b < a.n_two) cf_bwd_body<2, MID>(a, (int64_t)2 * b, bop_lds);
     else cf_bwd_body<1, MID>(a, (int64_t)a.n_two + b, bop_lds);
 }
@@ -312,6 +313,7 @@ int r2l_coopf_backward(const float* rgb, const float* target, const float* drgb,
     static int solo_ok[2] = {0, 0};
     if (const int n_two = r2l_coopf_mixed_two(tiles); n_two > 0) {  // between one and two tiles per CU: one workgroup on every CU
         a.n_two = n_two;
+        a.xcd_major = r2l_coopf_mixed_xcd_major();
         const dim3 grid((unsigned)(tiles - n_two));
         if (a.mid_units != 0) hipLaunchKernelGGL((r2l_coopf_bwd_mixed_kernel<true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((r2l_coopf_bwd_mixed_kernel<false>), grid, dim3(256), 0, stream, a);

@@ -29,7 +29,8 @@ struct CfFwdArgs {
     float* save_t;
     int64_t N;
     int64_t mid_units;  // != 0: mid quads stashed this many 16-byte units behind the hi pieces (exact weight gradients)
-    int n_two;          // mixed launch: workgroups 0 .. n_two - 1 take two ray tiles, the others one
+    int n_two;          // mixed launch: workgroups 0 .. n_two - 1 (in fc_mixed_index order) take two ray tiles, the others one
+    int xcd_major;
 };
 
 // The chain of one workgroup on the NT ray tiles tile0 .. tile0 + NT - 1.  LDS comes from the kernel (the mixed launch below
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void r2l_coopf_fwd_mixed_kernel(const CfFwd
     __shared__ float pts[2 * 32][49];
     __shared__ float red[4 * 2 * 32][3];
     const unsigned bop_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&bop[0][0][0];
-    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int b = fc_mixed_index(a.xcd_major);
     if (b < a.n_two) cf_fwd_body<false, SAVE, 2, MID>(a, (int64_t)2 * b, bop_lds, pts, red);
     else cf_fwd_body<false, SAVE, 1, MID>(a, (int64_t)a.n_two + b, bop_lds, pts, red);  // 2 n_two + (b - n_two)
 }
@@ -399,6 +400,7 @@ int r2l_coopf_forward(const float* rays_o, const float* rays_d, const float* t_r
     // two tiles per CU: the mixed grid (explicit rays only: the single-pose render launches are far above this band)
     if (const int n_two = r2l_coopf_mixed_two(tiles); n_two > 0 && !c2w_host12) {
         a.n_two = n_two;
+        a.xcd_major = r2l_coopf_mixed_xcd_major();
         const dim3 grid((unsigned)(tiles - n_two)), block(256);
         if (save_x && a.mid_units != 0) hipLaunchKernelGGL((r2l_coopf_fwd_mixed_kernel<true, true>), grid, block, 0, stream, a);
         else if (save_x) hipLaunchKernelGGL((r2l_coopf_fwd_mixed_kernel<true, false>), grid, block, 0, stream, a);

@@ -70,6 +70,7 @@ class R2LTrainer:
         self.segments_disabled = False
         self.skipped_steps = 0
         self._side = None
+        self._head_side = None  # staged backward of small steps: the head gradient beside the body buckets (_launch_head_beside)
         self._status_dev = None
         self._status_host = None  # pinned ring of validity words, one slot per segmented step still in flight
         self._status_pending = collections.deque()  # (event behind the copy, ring slot), oldest first
@@ -212,9 +213,17 @@ class R2LTrainer:
             # staged backward (include/r2l_hip.h r2l_backward_part): dX chain + tail, then the body buckets from the last
             # blocks to the first, the head last; every finished range of the flat gradient goes to the collective at once
             self._launch_backward(args, _lib.BWD_CHAIN | _lib.BWD_TAIL, 0, 0, "r2l_backward_part(chain, tail)")
+            # small steps: the head's weight gradient BESIDE the body buckets, on a second stream (round 6: what the one-call
+            # form does inside the library since round 5 — the head kernels are VALU-bound on 64 workgroups and would run
+            # alone on a mostly idle chip behind the last bucket; they share only the chain's outputs with the body kernels and
+            # write their own regions of the flat gradient and of dw_slab, r2l_dw.h).  Same kernels, same arguments: bit-identical.
+            head_done = self._launch_head_beside(args, n)
             for lo, hi, flat_lo, flat_hi in bucket_plan(eng.n_block, self.n_buckets):
                 if flat_lo == 0:
-                    self._launch_backward(args, _lib.BWD_HEAD, 0, 0, "r2l_backward_part(head)")
+                    if head_done is None:
+                        self._launch_backward(args, _lib.BWD_HEAD, 0, 0, "r2l_backward_part(head)")
+                    else:
+                        torch.cuda.current_stream().wait_event(head_done)
                 elif hi > lo:  # (a net without body blocks has one empty body bucket: only its tail range to exchange)
                     self._launch_backward(args, _lib.BWD_BODY, lo, hi, "r2l_backward_part(%d, %d)" % (lo, hi))
                 self.reducer.submit(self.grads[flat_lo:flat_hi])
@@ -222,6 +231,28 @@ class R2LTrainer:
             self._launch_backward(args, _lib.BWD_ALL, 0, 2 * eng.n_block, "r2l_backward")
         self._launch_loss_finish(n)
         return rgb
+
+    HEAD_BESIDE_MAX_RAYS = 16384  # (as the library's own overlap of the one-call form: R2L_DW_OVERLAP_MAX_RAYS, csrc/r2l_backward.hip)
+
+    def _launch_head_beside(self, args, n):
+        """Staged backward, small steps: launch the head weight gradient on the side stream behind the dX chain (already enqueued on
+        the current stream) and return the event that marks it done — or None: the caller launches it in line (large steps, where
+        the body kernels fill the chip; R2L_NO_DW_OVERLAP=1; a stand-in engine without a device, tests/test_driver_cpu.py)."""
+        dev = getattr(self.eng, "device", None)
+        if (n > self.HEAD_BESIDE_MAX_RAYS or os.environ.get("R2L_NO_DW_OVERLAP", "")[:1] not in ("", "0") or self.dw_slab is None
+                or not isinstance(dev, torch.device) or dev.type != "cuda"):
+            return None
+        if self._head_side is None:
+            self._head_side = torch.cuda.Stream(device=dev)
+        main, side = torch.cuda.current_stream(), self._head_side
+        fork = torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            self._launch_backward(args[:-1] + (ctypes.c_void_p(side.cuda_stream),), _lib.BWD_HEAD, 0, 0, "r2l_backward_part(head)")
+            done = torch.cuda.Event()
+            done.record(side)
+        return done
 
     # ---- range control ------------------------------------------------------------------------------------------------------
     def _calibrate(self, rays_o, rays_d, perturb, t_rand):
@@ -463,9 +494,16 @@ def bench(net, ps, a, world, rank, distributed, device, timed, flop_per_ray, pea
         if nt:
             # cooperative chains (r2l_coopf: one or two 32-ray tiles per workgroup), each workgroup streaming the 25 MB of
             # packed weights per chain from L2 — measured ~45 B/clk per CU, which is what bounds the small launches
-            wgs = ((n + 31) // 32 + nt - 1) // nt
-            path += "; chains: cooperative kernels (%d tile(s) per workgroup), L2 weight stream: %d workgroups x 25.1 MB per " \
-                    "chain" % (nt, wgs)
+            tiles = (n + 31) // 32
+            if nt == 3:  # mixed grid (csrc/r2l_coopf.h r2l_coopf_policy): one workgroup per CU
+                n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+                wgs = n_cu
+                path += "; chains: cooperative kernels, MIXED grid (%d two-tile + %d one-tile workgroups = one per CU), L2 weight " \
+                        "stream: %d workgroups x 25.1 MB per chain" % (tiles - n_cu, 2 * n_cu - tiles, wgs)
+            else:
+                wgs = (tiles + nt - 1) // nt
+                path += "; chains: cooperative kernels (%d tile(s) per workgroup), L2 weight stream: %d workgroups x 25.1 MB per " \
+                        "chain" % (nt, wgs)
             extra["weight_stream_bytes_per_step"] = 2 * wgs * 25.1e6
         extra["range"] = tr.range_info()
     if distributed:

@@ -398,6 +398,42 @@ def test_load_blender_synthetic(tmp_path):
     np.testing.assert_allclose(imgs.numpy(), full.numpy().reshape(6, 4, 2, 4, 2, 4).mean(axis=(2, 4)), atol=1e-7)
 
 
+def test_half_res_hand_computed_4x4_fixture(tmp_path):
+    """--half_res (dataset/load_blender.py:100-112: cv2.resize(img, (H/2, W/2), interpolation=cv2.INTER_AREA) on the float image):
+    for an exact factor of 2 INTER_AREA is the mean of each 2x2 block.  cv2 is on neither box, so the resize is pinned here by a
+    HAND-COMPUTED 4x4 fixture instead of by cv2's output: every expected value below was worked out on paper
+    from the 8-bit pixels, (a + b + c + d) / (4 * 255); float32 rounding of either summation order stays within one ulp of it."""
+    import json
+    from PIL import Image
+    from r2l_amd import data
+    # channel R: blocks with exactly representable means; G: mixed values; B: a ramp; A: opaque / half / transparent
+    R = np.array([[0, 255, 255, 255], [255, 0, 255, 255], [0, 0, 51, 51], [0, 0, 204, 204]], np.uint8)
+    G = np.array([[10, 20, 1, 2], [30, 40, 3, 4], [100, 150, 7, 7], [200, 250, 7, 8]], np.uint8)
+    B = np.arange(16, dtype=np.uint8).reshape(4, 4) * 16
+    A = np.array([[255, 255, 0, 0], [255, 255, 0, 0], [255, 0, 128, 128], [0, 255, 128, 128]], np.uint8)
+    want = np.zeros((2, 2, 4))
+    want[..., 0] = [[510 / 1020, 1020 / 1020], [0 / 1020, 510 / 1020]]      # (0+255+255+0), (255*4) | 0, (51+51+204+204)
+    want[..., 1] = [[100 / 1020, 10 / 1020], [700 / 1020, 29 / 1020]]        # 10+20+30+40, 1+2+3+4 | 100+150+200+250, 7+7+7+8
+    want[..., 2] = [[160 / 1020, 288 / 1020], [672 / 1020, 800 / 1020]]      # 0+16+64+80, 32+48+96+112 | 128+144+192+208, 160+176+224+240
+    want[..., 3] = [[1020 / 1020, 0 / 1020], [510 / 1020, 512 / 1020]]
+    img = np.stack([R, G, B, A], -1)
+    for split in ("train", "val", "test"):
+        os.makedirs(tmp_path / split)
+        Image.fromarray(img).save(tmp_path / split / "r_0.png")
+        with open(tmp_path / ("transforms_%s.json" % split), "w") as f:
+            json.dump({"camera_angle_x": 0.6911112070083618,
+                       "frames": [{"file_path": "./%s/r_0" % split, "transform_matrix": data.pose_spherical(0., -30., 4.).tolist()}]}, f)
+    imgs, _, _, hwf, _ = data.load_blender_data(str(tmp_path), half_res=True, testskip=1)
+    assert imgs.shape == (3, 2, 2, 4) and imgs.dtype == torch.float32 and hwf[:2] == [2, 2]
+    got = imgs[0].numpy().astype(np.float64)
+    assert np.abs(got - want).max() <= 2.0 ** -24, np.abs(got - want).max()  # one ulp of a float32 in [0.5, 1)
+    assert got[0, 1, 0] == 1.0 and got[1, 0, 0] == 0.0 and got[0, 1, 3] == 0.0 and got[0, 0, 3] == 1.0  # the exact cases
+    # and the white-background composite the drivers apply to it (main.py:933-937): rgb * a + (1 - a)
+    comp = imgs[..., :3] * imgs[..., -1:] + (1. - imgs[..., -1:])
+    assert torch.equal(comp[0, 0, 1], torch.ones(3))  # transparent block -> white
+    assert abs(comp[0, 1, 1, 1].item() - ((29 / 1020) * (512 / 1020) + 1 - 512 / 1020)) < 1e-6
+
+
 def test_convert_images_to_ray_shards(tmp_path):
     """README step 4 data: every pixel of the train views becomes one [o,d,rgb] row; shards feed BlenderDataset_v2."""
     from tests.test_driver_cpu import make_scene

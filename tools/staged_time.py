@@ -10,10 +10,12 @@ import bench  # noqa: E402
 
 
 def main():
+    label = sys.argv[1] if len(sys.argv) > 1 else ""
+    sizes = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (98304, 12288, 4096)
     dev = torch.device("cuda", 0)
     net, ps, _ = bench.make_model(dev)
     from r2l_amd.train_step import R2LTrainer, lr_schedule
-    for n in (98304, 12288, 4096):
+    for n in sizes:
         g = torch.Generator().manual_seed(1)
         o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(dev)
         d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
@@ -25,7 +27,7 @@ def main():
             # the dX chain itself cut into segments, weight gradients of a finished segment on a second stream beside the next
             cases += [("chain in %d segments, dW beside it" % k, False, 4, None, k) for k in (2, 3, 4, 6)]
             cases += [("chain in 4 segments, 8 CUs reserved", False, 4, "8", 4)]
-        for label, staged, buckets, reserve, segments in cases:
+        for case, staged, buckets, reserve, segments in cases:
             tr.force_staged, tr.n_buckets, tr.chain_segments = staged, buckets, segments
             if reserve:
                 os.environ["R2L_RESERVE_CUS"] = reserve
@@ -41,7 +43,7 @@ def main():
                 tr.step(o, d, tgt, lr_schedule(i + 4, 5e-4, 500, "0.0001,200"), perturb=1.0)
             e1.record()
             torch.cuda.synchronize()
-            print("%6d rays  %-36s %.3f ms/step" % (n, label, e0.elapsed_time(e1) / k))
+            print("%-28s %6d rays  %-36s %.3f ms/step" % (label, n, case, e0.elapsed_time(e1) / k))
         os.environ.pop("R2L_RESERVE_CUS", None)
 
 

@@ -1,5 +1,6 @@
 """ms per default-trio training step at 98 304 rays (README: N_rand 20 x 4096 + 20 % hard rays) for same-box A/Bs of library
-variants (R2L_LIB_PATH) and environment switches:  python tools/train_step_time.py [label] [steps=60] [rays=98304]"""
+variants (R2L_LIB_PATH) and environment switches:  python tools/train_step_time.py [label] [steps=60] [rays=98304] [precision=auto]
+(precision fp32_mfma: the graded exact-fp32 family)"""
 import os
 import sys
 import time
@@ -20,6 +21,8 @@ o = (torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0., 0., 4.])).to(dev)
 d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
 tgt = torch.rand(n, 3, generator=g).to(dev)
 tr = R2LTrainer(net, ps)
+if len(sys.argv) > 4:
+    tr.eng.set_config(precision=sys.argv[4])
 for i in range(8):
     tr.step(o, d, tgt, lr_schedule(i + 1, 5e-4, 500, "0.0001,200"), perturb=1.0)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
