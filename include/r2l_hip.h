@@ -41,8 +41,8 @@ enum { R2L_DW_AUTO = 0,
 typedef struct r2l_config {
     int precision;    /* R2L_PRECISION_*                                                                                  */
     int tiling;       /* R2L_TILING_*                                                                                     */
-    int coop_tiles;   /* 0 auto, 1 or 2: 32-ray tiles per workgroup of the fp16x2 cooperative kernels; 3: mixed grid (two-
-                         tile and one-tile workgroups, one per CU) for tile counts between one and two per CU              */
+    int coop_tiles;   /* 0 auto, 1 or 2: 32-ray tiles per workgroup of the fp16x2 cooperative kernels; 3 (opt-in, never auto):
+                         mixed grid (two-tile and one-tile workgroups, one per CU) for tile counts between one and two per CU */
     int reserve_cus;  /* 0 auto (R2L_RESERVE_CUS or none), n > 0: CUs the persistent weight-gradient kernels leave free
                          for collectives running beside them, -1: none                                                    */
     int dw_mode;      /* R2L_DW_*                                                                                         */
@@ -74,8 +74,8 @@ int r2l_pack_backward(const float* params, int n_block, float* wstream_bwd, void
  * (main | coopf | coop16). */
 int r2l_variant_for(int64_t N);
 /* Within the fp16 trio (layout 2): 0 = the one-wave-per-tile chains serve a launch of N rays, 1 / 2 = the cooperative chains
- * with that many 32-ray tiles per workgroup, 3 = their MIXED grid (tile counts between one and two per CU: tiles - n_cu
- * two-tile workgroups + 2 n_cu - tiles one-tile ones, one workgroup on every CU) (<= 16 384 rays, and 32 769 .. 49 152 rays:
+ * with that many 32-ray tiles per workgroup, 3 = their MIXED grid (only when pinned; tile counts between one and two per CU:
+ * tiles - n_cu two-tile workgroups + 2 n_cu - tiles one-tile ones, one workgroup on every CU) (<= 16 384 rays, and 32 769 .. 49 152 rays:
  * csrc/r2l_common.h r2l_use_coopf; R2L_FORCE_VARIANT=main|coopf and R2L_COOPF_TILES=1|2|3 pin it).  1 / 2 / 3 give
  * bit-identical results (every tile takes the same path); 0 agrees with them within rounding. */
 int r2l_coop_tiles_for(int64_t N, int n_block);

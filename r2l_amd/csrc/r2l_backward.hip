@@ -39,54 +39,10 @@ struct MaskAct {
     }
 };
 
-// GEMM-A hook of the backward chain (u = W2^T g): (1) g = dL/dx_{b+1} is the B operand, its store to gx[b+1] rides
-// along; (2) the ReLU mask of the block's hidden activation is prefetched one 16-byte piece per group from the forward
-// stash and folded into 128 bits per lane, so no load latency is exposed between the two GEMMs.
-struct BwdAHook {
-    static constexpr int RD = 1, WR = 1;
-    StoreHook st;
-#if R2L_HOOK_BUFFER
-    __amdgpu_buffer_rsrc_t trs;  // descriptor of this block's save_t slot
-    unsigned tvo;                // ray*1024 + 16*h
-#else
-    const float* trow;  // save_t row of this lane (+4h)
-#endif
-    unsigned (&mb)[4];
-    f32x4 pend[2];  // mask pieces in flight: consumed two groups after their load was issued
-    __device__ __forceinline__ BwdAHook(float* gbase, const float* tbase, int64_t ray, int h,
-                                        const f32x16 (&g)[R2L_NT], unsigned (&m)[4])
-#if R2L_HOOK_BUFFER
-        : st(gbase, ray, h, g),
-          trs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, 0xffffffff, 0x00020000)),
-          tvo((unsigned)(ray * (R2L_W * 4) + 16 * h)), mb(m) {}
-#else
-        : st(gbase, ray, h, g), trow(tbase + ray * R2L_W + 4 * h), mb(m) {}
-#endif
-    __device__ __forceinline__ void fold(int G) {
-        const f32x4 p = pend[G & 1];
-        const int sh = ((G >> 2) & 1) * 16 + (G & 3) * 4;
-        unsigned bits = (p[0] > 0.f ? 1u : 0u) | (p[1] > 0.f ? 2u : 0u) | (p[2] > 0.f ? 4u : 0u) |
-                        (p[3] > 0.f ? 8u : 0u);
-        mb[G >> 3] |= bits << sh;
-    }
-    __device__ __forceinline__ void at(int G) {
-        st.at(G);
-        if (G > 1) fold(G - 2);
-#if R2L_HOOK_BUFFER
-        asm volatile("" : "+v"(tvo));
-        pend[G & 1] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo + (unsigned)(32 * (G >> 2) + 8 * (G & 3)) * 4u, 0, 0));
-#elif defined(R2L_TIMING_NO_MASK_LOAD)  // timing builds only: what reading save_t for its signs costs (results are wrong)
-        pend[G & 1] = f32x4{1.f, 1.f, 1.f, 1.f};
-#else
-        pend[G & 1] = *reinterpret_cast<const f32x4*>(trow + 32 * (G >> 2) + 8 * (G & 3));
-#endif
-    }
-    __device__ __forceinline__ void finish() {
-        fold(R2L_LAYER_GROUPS - 2);
-        fold(R2L_LAYER_GROUPS - 1);
-    }
-};
+// GEMM A of the backward chain (u = W2^T g): g = dL/dx_{b+1} is the B operand, its store to gx[b+1] rides along (StoreHook).
+// The ReLU mask of the block's hidden activation comes from the forward's mask words (r2l_common.h r2l_mask32_offset): one
+// 16-byte load per lane, issued in front of the GEMM and first used behind it.  (Rounds 1 - 5 prefetched relu(t) itself, one
+// 16-byte piece per group, and folded its signs: 32 loads per lane and block, all of save_t read a second time.)
 
 __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs a) {
     __shared__ float stash[4][R2L_NT * 16][64];  // dy of each wave's tile (outer residual branch), re-added at the head
@@ -156,14 +112,14 @@ __global__ __launch_bounds__(256, 1) void r2l_bwd_chain_kernel(const R2LBwdArgs 
         for (int c = 0; c < 16; ++c) stash[wave][T * 16 + c][lane] = g[T][c];
 #pragma unroll 1
     for (int b = a.n_block - 1; b >= 0; --b) {
-        // u = W2^T g (accumulators initialised by the first group, C = 0); g (= dL/dx_{b+1}) is stored to gx[b+1] and
-        // the ReLU mask bits of the block's hidden activation are prefetched along the way
-        unsigned mb[4] = {0u, 0u, 0u, 0u};
+        // u = W2^T g (accumulators initialised by the first group, C = 0); g (= dL/dx_{b+1}) is stored to gx[b+1] along the way;
+        // the ReLU mask words of the block's hidden activation are requested in front of it
+        const u32x4 mw = *reinterpret_cast<const u32x4*>(a.save_t + r2l_mask32_offset(a.n_block, Np, b) + tile * 256 + lane * 4);
         {
-            BwdAHook hk(a.gx + (int64_t)(b + 1) * Np * R2L_W, a.save_t + (int64_t)b * Np * R2L_W, ray, h, g, mb);
+            StoreHook hk(a.gx + (int64_t)(b + 1) * Np * R2L_W, ray, h, g);
             gemm256a<IdentityAct, 0, true>(u, g, ws, hk, IdentityAct());
-            hk.finish();
         }
+        const unsigned mb[4] = {mw[0], mw[1], mw[2], mw[3]};
         // g += W1^T (u . mask): the mask relu'(hidden) = (t_b > 0) is applied lazily to the B operands of each group and
         // to the pieces of u (= dL/d hidden pre-activation) stored to gt[b] along the way
         {

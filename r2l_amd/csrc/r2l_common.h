@@ -257,6 +257,32 @@ struct StoreHookT {
 };
 typedef StoreHookT<false> StoreHook;
 
+// ReLU mask words of the fp32 one-wave-per-tile training chains (round 6).  The forward (r2l_fwd_kernel<*, SAVE>) leaves, per
+// block and 32-ray tile, 64 lanes x 4 words = 1 KiB: bit (T & 1) * 16 + c of word T >> 1 of lane (j, h) = [t > 0] for the lane's
+// fragment register (T, c) — the layout of the trios' mask words — behind the n_block dense [Np][256] slots of save_t (a slot
+// is R2L_TRIO_SLOT(Np) = Np * 264 floats for every caller, include/r2l_hip.h: the row-major family used Np * 256 of them).
+// The dX chain (r2l_bwd_chain_kernel) reads ONE 16-byte piece per lane and block instead of all of relu(t) for its signs
+// (32 loads per lane and block, 4.3 GB per 98 304-ray step: 8.42 -> 7.83 ms measured with the loads stubbed out,
+// profiles/r06_graded_step_ab.txt).
+__host__ __device__ static inline int64_t r2l_mask32_offset(int n_block, int64_t Np, int b) {
+    return (int64_t)n_block * Np * R2L_W + (int64_t)b * Np * 8;  // floats from save_t; + tile * 256 + lane * 4
+}
+// StoreHookT<true> (relu(t) rides along GEMM 2 of a block) that also folds the signs of the pieces it stores into mb[4]
+struct StoreMaskHook {
+    static constexpr int RD = 0, WR = 1;
+    StoreHookT<true> st;
+    unsigned (&mb)[4];
+    __device__ __forceinline__ StoreMaskHook(float* base, int64_t ray, int h, const f32x16 (&s)[R2L_NT], unsigned (&m)[4])
+        : st(base, ray, h, s), mb(m) {}
+    __device__ __forceinline__ void at(int G) {
+        st.at(G);
+        const int T = G >> 2, q = (G & 3) * 4;
+        const unsigned bits = (st.src[T][q + 0] > 0.f ? 1u : 0u) | (st.src[T][q + 1] > 0.f ? 2u : 0u) |
+                              (st.src[T][q + 2] > 0.f ? 4u : 0u) | (st.src[T][q + 3] > 0.f ? 8u : 0u);
+        mb[G >> 3] |= bits << (((G >> 2) & 1) * 16 + q);
+    }
+};
+
 // Consume one bias group of the forward stream: acc (+)= bias x [1,0]^T  — 8 MFMAs, one per tile.
 template <bool ZERO_INIT, int SLOT = 0, int D>
 __device__ __forceinline__ void mfma_bias_group(f32x16 (&acc)[R2L_NT], WRingT<D>& ws, float one_h0) {

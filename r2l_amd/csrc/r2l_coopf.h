@@ -246,10 +246,15 @@ __device__ __forceinline__ void fc_produce(const f32x16 (&frag)[2], unsigned bop
     if (MASK) *mword = mw;
 }
 
-// ray tiles per workgroup: 1 while that keeps the launch within one workgroup per CU; 2 from two tiles per CU on; in between
-// (n_cu < tiles < 2 n_cu) the MIXED grid (3): tiles - n_cu two-tile workgroups and 2 n_cu - tiles one-tile ones = one workgroup
-// on every CU, where ceil(tiles / 2) two-tile workgroups leave CUs idle for the whole chain (r2l_coopf_fwd.hip).
-// r2l_config.coop_tiles = 1 | 2 | 3, else R2L_COOPF_TILES=1|2|3, pins the policy (3 outside its band: 1 below, 2 above).
+// ray tiles per workgroup: 1 while that keeps the launch within one workgroup per CU, else 2.  A third policy, 3 = the MIXED
+// grid for n_cu < tiles < 2 n_cu (tiles - n_cu two-tile workgroups and 2 n_cu - tiles one-tile ones = one workgroup on every CU,
+// where ceil(tiles / 2) two-tile workgroups leave CUs idle; r2l_coopf_fwd.hip), is OPT-IN: r2l_config.coop_tiles = 3, else
+// R2L_COOPF_TILES=3 (outside its band: 1 below, 2 above).  Built and measured in round 6 as VERDICT r5 #2 asked: bit-identical
+// to both plain forms, and SLOWER than the two-tile launch at 12 288 rays (forward 461 vs 438 us, dX chain 412 vs 375 us with
+// the roles dealt evenly over the XCDs; 497 / 443 us with the two-tile roles filling whole XCDs) — these chains are bound by the
+// weight stream each XCD's L2 serves its CUs (~1.2 - 1.6 TB/s per XCD at 24 - 32 streaming workgroups), so putting the idle
+// CUs to work on one more stream each slows every workgroup down by more than the shorter two-tile queue gains
+// (profiles/r06_mixed_coopf_ab.txt).  AUTO therefore keeps the round-5 policy.
 static inline int r2l_coopf_n_cu() {
     static int n_cu = 0;  // one device type per process
     if (n_cu == 0) {
@@ -269,7 +274,7 @@ static inline int r2l_coopf_policy(int64_t tiles) {
     const int n_cu = r2l_coopf_n_cu();
     if (tiles <= n_cu) return 1;
     if (tiles >= 2 * (int64_t)n_cu) return 2;
-#ifdef FC_NO_MIXED_AUTO  // A/B builds: AUTO keeps the round-5 policy (two tiles from n_cu + 1 tiles on)
+#ifndef FC_MIXED_AUTO  // (A/B builds with -DFC_MIXED_AUTO: AUTO takes the mixed grid in its band)
     if (want == 0) return 2;
 #endif
     return 3;
@@ -281,9 +286,10 @@ static inline int r2l_coopf_mixed_two(int64_t tiles) { return r2l_coopf_policy(t
 // Position of this workgroup in the role order of a MIXED launch.  The two roles run at different paces (one tile: ~3.1 us per
 // layer, two tiles: ~4.5 us), and the workgroups of one XCD share the weight stream through that XCD's 4 MiB L2 only while they
 // stay within a few blocks (0.57 MB each) of each other: with the roles interleaved over the XCDs (position = blockIdx) the
-// one-tile workgroups run ahead and every XCD fetches the stream twice — measured SLOWER than the plain two-tile launch
-// (profiles/r06_mixed_coopf_ab.txt).  xcd_major: position = (blockIdx % 8) * (grid / 8) + blockIdx / 8 — workgroups are dealt to
-// the 8 XCDs round-robin, so the two-tile roles fill whole XCDs and the one-tile roles the others (at most one XCD holds both).
+// one-tile workgroups run ahead.  xcd_major (A/B knob R2L_MIXED_MAP=1): position = (blockIdx % 8) * (grid / 8) + blockIdx / 8 —
+// workgroups are dealt to the 8 XCDs round-robin, so the two-tile roles fill whole XCDs and the one-tile roles the others (at
+// most one XCD holds both).  Measured: WORSE (forward 497 vs 461 us at 12 288 rays) — 32 two-tile streams on one L2 are slower
+// than 16 + 16; both are slower than the plain two-tile launch (438 us): profiles/r06_mixed_coopf_ab.txt.  Default: by blockIdx.
 __device__ __forceinline__ int fc_mixed_index(int xcd_major) {
     const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
     const int g = (int)gridDim.x;
@@ -291,8 +297,8 @@ __device__ __forceinline__ int fc_mixed_index(int xcd_major) {
     return (b & 7) * (g >> 3) + (b >> 3);
 }
 static inline int r2l_coopf_mixed_xcd_major() {
-    const char* e = getenv("R2L_MIXED_MAP");  // A/B knob: 0 = roles by blockIdx, 1 (default) = XCD-major
-    return (e && e[0] == '0') ? 0 : 1;
+    const char* e = getenv("R2L_MIXED_MAP");  // A/B knob: 0 (default) = roles by blockIdx, 1 = XCD-major
+    return (e && e[0] == '1') ? 1 : 0;
 }
 
 // launchers (called from r2l_fwd2_forward / r2l_bwd2_backward when the launch is small: r2l_use_coopf)

@@ -198,8 +198,13 @@ __global__ __launch_bounds__(256, 1) void r2l_fwd_kernel(const R2LFwdArgs a) {
         // x += W2 relu(t) + b2
         mfma_bias_group<false, 0>(x, ws, one_h0);  // block-local group 33 -> slot 0
         if constexpr (SAVE) {
-            StoreHookT<true> st(a.save_t + (int64_t)b * Np * R2L_W, ray, h, t);
+            // relu(t) rides along as this GEMM's B operand; its signs are folded into 128 bits per lane on the way and leave as
+            // ONE 16-byte store per lane (1 KiB per tile): the dX chain reads those instead of relu(t) (r2l_common.h)
+            unsigned mb[4] = {0u, 0u, 0u, 0u};
+            StoreMaskHook st(a.save_t + (int64_t)b * Np * R2L_W, ray, h, t, mb);
             gemm256x<true, 1>(x, t, ws, st);
+            *reinterpret_cast<u32x4*>(a.save_t + r2l_mask32_offset(a.n_block, Np, b) + (ray >> 5) * 256 + lane * 4) =
+                u32x4{mb[0], mb[1], mb[2], mb[3]};
         } else {
             NoHook nh;
             gemm256x<true, 1>(x, t, ws, nh);

@@ -232,7 +232,7 @@ class R2LTrainer:
         self._launch_loss_finish(n)
         return rgb
 
-    HEAD_BESIDE_MAX_RAYS = 16384  # (as the library's own overlap of the one-call form: R2L_DW_OVERLAP_MAX_RAYS, csrc/r2l_backward.hip)
+    HEAD_BESIDE_MAX_RAYS = 8192  # one tile per cooperative workgroup = idle CUs beside the body kernels (measured: 4096 rays 0.950 vs 0.967 ms, 12 288 rays 1.565 vs 1.550: profiles/r06_staged_backward.txt)
 
     def _launch_head_beside(self, args, n):
         """Staged backward, small steps: launch the head weight gradient on the side stream behind the dX chain (already enqueued on

@@ -172,13 +172,13 @@ def test_dispatch_and_buffer_size_helpers(monkeypatch):
     assert lib.r2l_forward_layout_for(4096, 1) == 2 and lib.r2l_backward_layout_for(4096) == 2
     assert lib.r2l_forward_layout_for(98304, 1) == 2 and lib.r2l_forward_layout_for(160000, 0) == 2
     assert lib.r2l_backward_layout_for(98304) == 2
-    # ... cooperative: one tile per workgroup up to one tile per CU, two from two tiles per CU on, the MIXED grid (3: two-tile and
-    # one-tile workgroups, one on every CU) in between, up to 16 384 rays; and again (two tiles) where the one-wave-per-tile
-    # kernels would run a half-empty second round
+    # ... cooperative: one tile per workgroup up to one tile per CU, two above, up to 16 384 rays; and again (two tiles) where
+    # the one-wave-per-tile kernels would run a half-empty second round.  (The MIXED grid, 3, is opt-in: measured slower in
+    # round 6, profiles/r06_mixed_coopf_ab.txt)
     assert [lib.r2l_coop_tiles_for(n, 43) for n in (32, 4096, 8192, 8193, 12288, 16352, 16353, 16384, 16385, 32768, 32769, 49152,
-                                                     49153, 98304, 160000)] == [1, 1, 1, 3, 3, 3, 2, 2, 0, 0, 2, 2, 0, 0, 0]
+                                                     49153, 98304, 160000)] == [1, 1, 1, 2, 2, 2, 2, 2, 0, 0, 2, 2, 0, 0, 0]
     monkeypatch.setenv("R2L_COOPF_TILES", "3")  # mixed pinned: outside its band one tile below, two above
-    assert [lib.r2l_coop_tiles_for(n, 43) for n in (4096, 12288, 16384)] == [1, 3, 2]
+    assert [lib.r2l_coop_tiles_for(n, 43) for n in (4096, 8193, 12288, 16352, 16353, 16384)] == [1, 3, 3, 3, 2, 2]
     monkeypatch.setenv("R2L_COOPF_TILES", "2")
     assert lib.r2l_coop_tiles_for(4096, 43) == 2 and lib.r2l_coop_tiles_for(98304, 43) == 0
     monkeypatch.delenv("R2L_COOPF_TILES")

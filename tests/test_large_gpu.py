@@ -127,7 +127,7 @@ def test_dispatch_thresholds_forward_and_gradient(n, monkeypatch):
     m = build_model(sd, nb)
     tr = R2LTrainer(m, ps)
     tiles = tr.lib.r2l_coop_tiles_for_cfg(n, nb, tr.eng._cfg())
-    assert tiles == {8192: 1, 8193: 3, 16384: 2, 16385: 0, 32768: 0, 32769: 2, 49152: 2, 49153: 0}[n]
+    assert tiles == {8192: 1, 8193: 2, 16384: 2, 16385: 0, 32768: 0, 32769: 2, 49152: 2, 49153: 0}[n]
     rgb = tr.forward_backward(o, d, tgt, perturb=1., t_rand=u)
     auto = tr.grads.clone()
     pick = torch.cat([torch.arange(128), torch.arange(n - 128, n)])

@@ -686,7 +686,8 @@ def test_coopf_one_tile_beside_other_kernels(chain_variant, monkeypatch):
 def test_mixed_cooperative_launch_is_bit_identical(chain_variant, monkeypatch, n, dw_mode, segments):
     """Tile counts between one and two per CU (256 < tiles < 512; 12 288 rays = the per-GPU share of the README's step at 8
     GPUs, /root/reference/main.py:1371-1406) run as ONE grid of tiles - 256 two-tile and 512 - tiles one-tile cooperative
-    workgroups (r2l_config.coop_tiles = 3, AUTO's choice in that band; csrc/r2l_coopf_fwd.hip r2l_coopf_fwd_mixed_kernel).
+    workgroups (r2l_config.coop_tiles = 3 — opt-in: measured slower than the two-tile launch, profiles/r06_mixed_coopf_ab.txt;
+    csrc/r2l_coopf_fwd.hip r2l_coopf_fwd_mixed_kernel).
     Every tile takes the path it takes in the one-tile and in the two-tile kernels: rgb, loss and the whole flat gradient are
     bit-identical to both forced forms — also with the mid halves stashed (exact dW) and with the dX chain cut into segments."""
     if chain_variant != "coopf":
@@ -713,7 +714,7 @@ def test_mixed_cooperative_launch_is_bit_identical(chain_variant, monkeypatch, n
         t.eng.set_config(precision="fp16x2", tiling="coopf", coop_tiles=tiles)
         if segments > 1:
             t.force_staged = True
-        assert _lib.load().r2l_coop_tiles_for_cfg(n, nb, t.eng._cfg()) == (tiles or 3)
+        assert _lib.load().r2l_coop_tiles_for_cfg(n, nb, t.eng._cfg()) == (tiles or 2)
         rgb = t.forward_backward(o, d, tgt, perturb=1.0, t_rand=tr)
         with torch.no_grad():
             plain = m.forward_rays(o, d, ps, perturb=1.0, t_rand=tr)
