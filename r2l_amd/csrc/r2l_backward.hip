@@ -31,11 +31,12 @@ struct R2LBwdArgs {
     int64_t N;
 };
 
-// relu'(t) as 128 bits per lane: bit (T&1)*16 + c of word T>>1 belongs to fragment register (T, c)
+// relu'(t) as 128 bits per lane: bit R2L_MASK32_BIT(T, c) of word T >> 1 belongs to fragment register (T, c) (r2l_common.h: the
+// forward's mask words)
 struct MaskAct {
     unsigned mb[4];
     __device__ __forceinline__ float operator()(float v, int T, int c) const {
-        return ((mb[T >> 1] >> ((T & 1) * 16 + c)) & 1u) ? v : 0.f;
+        return ((mb[T >> 1] >> R2L_MASK32_BIT(T, c)) & 1u) ? v : 0.f;
     }
 };
 

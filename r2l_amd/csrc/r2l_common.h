@@ -258,16 +258,19 @@ struct StoreHookT {
 typedef StoreHookT<false> StoreHook;
 
 // ReLU mask words of the fp32 one-wave-per-tile training chains (round 6).  The forward (r2l_fwd_kernel<*, SAVE>) leaves, per
-// block and 32-ray tile, 64 lanes x 4 words = 1 KiB: bit (T & 1) * 16 + c of word T >> 1 of lane (j, h) = [t > 0] for the lane's
-// fragment register (T, c) — the layout of the trios' mask words — behind the n_block dense [Np][256] slots of save_t (a slot
-// is R2L_TRIO_SLOT(Np) = Np * 264 floats for every caller, include/r2l_hip.h: the row-major family used Np * 256 of them).
-// The dX chain (r2l_bwd_chain_kernel) reads ONE 16-byte piece per lane and block instead of all of relu(t) for its signs
-// (32 loads per lane and block, 4.3 GB per 98 304-ray step: 8.42 -> 7.83 ms measured with the loads stubbed out,
+// block and 32-ray tile, 64 lanes x 4 words = 1 KiB behind the n_block dense [Np][256] slots of save_t (a slot is
+// R2L_TRIO_SLOT(Np) = Np * 264 floats for every caller, include/r2l_hip.h: the row-major family used Np * 256 of them): bit
+// 31 - ((T & 1) * 16 + c) of word T >> 1 of lane (j, h) = [t > 0] for the lane's fragment register (T, c).  The dX chain
+// (r2l_bwd_chain_kernel) reads ONE 16-byte piece per lane and block instead of all of relu(t) for its signs (rounds 1 - 5:
+// 32 loads per lane and block, 4.3 GB per 98 304-ray step; same-box A/B 8.21 -> 7.56 ms for the chain,
 // profiles/r06_graded_step_ab.txt).
 __host__ __device__ static inline int64_t r2l_mask32_offset(int n_block, int64_t Np, int b) {
     return (int64_t)n_block * Np * R2L_W + (int64_t)b * Np * 8;  // floats from save_t; + tile * 256 + lane * 4
 }
-// StoreHookT<true> (relu(t) rides along GEMM 2 of a block) that also folds the signs of the pieces it stores into mb[4]
+#define R2L_MASK32_BIT(T, c) (31 - (((T) & 1) * 16 + (c)))
+// StoreHookT<true> (relu(t) rides along GEMM 2 of a block) that also folds the signs of the pieces it stores into mb[4]: two
+// VALU instructions per value — the sign bit of 0 - t is [t > 0] exactly (+-0 -> +0, t < 0 -> positive), shifted in from the
+// right with v_alignbit_b32 ({w, y} >> 31 = (w << 1) | y[31]), so the value folded i-th into a word ends at bit 31 - i.
 struct StoreMaskHook {
     static constexpr int RD = 0, WR = 1;
     StoreHookT<true> st;
@@ -277,9 +280,11 @@ struct StoreMaskHook {
     __device__ __forceinline__ void at(int G) {
         st.at(G);
         const int T = G >> 2, q = (G & 3) * 4;
-        const unsigned bits = (st.src[T][q + 0] > 0.f ? 1u : 0u) | (st.src[T][q + 1] > 0.f ? 2u : 0u) |
-                              (st.src[T][q + 2] > 0.f ? 4u : 0u) | (st.src[T][q + 3] > 0.f ? 8u : 0u);
-        mb[G >> 3] |= bits << (((G >> 2) & 1) * 16 + q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float y = 0.f - st.src[T][q + j];
+            mb[G >> 3] = __builtin_amdgcn_alignbit(mb[G >> 3], __builtin_bit_cast(unsigned, y), 31);
+        }
     }
 };
 

@@ -95,7 +95,13 @@ def test_cli_render_eight_ranks(scene_and_teacher):
     save_ckpt(ckpt, 7, build_model(sd, 43).cpu(), {"state": {}, "param_groups": []}, 0., 0)
     common = ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene,
               "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "88", "--use_residual", "--trial.ON",
-              "--trial.body_arch", "resmlp", "--testskip", "1", "--pretrained_ckpt", ckpt, "--render_only", "--n_pose_video", "5"]
+              "--trial.body_arch", "resmlp", "--testskip", "1", "--pretrained_ckpt", ckpt, "--render_only", "--n_pose_video", "5",
+              # byte equality across rank counts needs ONE kernel family at every launch size: the single process renders the 5
+              # video frames in one 20 480-ray launch, a rank of the eight renders one 4096-ray frame.  The exact-fp32 family serves
+              # both with the 16-ray cooperative kernels (profiles/r05_dispatch_table.md); the default fp16x2 family would take
+              # the one-wave-per-tile kernel for the former and the cooperative one for the latter — equal within rounding
+              # (~2e-6 in rgb), not in every byte of a PNG
+              "--r2l_precision", "fp32_mfma"]
     cwd = os.getcwd()
     os.chdir(root)
     try:
