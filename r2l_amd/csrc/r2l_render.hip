@@ -481,9 +481,12 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* _
 // sample_pdf + sort-merge for the reference's configuration (S = 64 coarse depths, NI = 128 new ones): a QUARTER wave per ray.
 // The one-ray-per-wave kernel above is VALU-issue bound (~900 instructions per ray: 47 us per 32 768-ray chunk, 0.2 of the HBM
 // roofline its 2.3 KB per ray would allow).  With 16 lanes per ray and 16 elements of the 256-element network per lane,
-//   * 26 of the 36 network stages are min / max pairs between a lane's own registers (2 instructions per compare-exchange instead
-//     of 4 + a cross-lane move for each of the two partners), the other 10 reach their partner inside the 16-lane DPP row
-//     (quad_perm, row_half_mirror, row_mirror): no ds_bpermute at all, a compare + select per element;
+//   * the sort (round 6): the 128 samples are sorted alone — 28 stages on the lane's 8 consecutive samples, 18 of them min / max pairs
+//     between the lane's own registers, the other 10 reaching their partner inside the 16-lane DPP row (quad_perm, row_half_mirror,
+//     row_mirror: no ds_bpermute, a compare + select per element) — and then MERGED with the 64 coarse depths, which arrive
+//     ascending: the last phase of the 256-element network only (8 stages on 16 values per lane).  2816 compare-exchanges per ray
+//     instead of the 4608 of round 5's full network, which stays in the kernel for waves whose coarse depths do not ascend (checked);
+//     waves whose samples already ascend (perturb = 0: the inverse cdf is monotone in the linspace u) skip the sample sort too;
 //   * the left-to-right cdf runs for four rays at once: 16 steps of (carry from the previous lane by row_shr:1, four dependent
 //     adds) — the same association as torch.cumsum, element for element;
 //   * sums over a ray (pdf normalisation, z_std) follow wave_sum's butterfly association (k ^ 32, 16, ... 1 over the 64 positions),
@@ -506,6 +509,26 @@ __device__ __forceinline__ float r2o_row_sum64(float a0, float a1, float a2, flo
     const float b0 = a0 + a2, b1 = a1 + a3;                  // k ^ 2
     return b0 + b1;                                          // k ^ 1
 }
+// the same sum for the layout of the round-6 kernel: position k = 8 l' + q in register a[q] of lane l' = l16 & 7 (the two half rows
+// hold the same 64 values); same association, every lane gets the total
+__device__ __forceinline__ float r2o_row_sum64_8(float (&a)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += X4(a[q]);  // k ^ 32
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += X2(a[q]);  // k ^ 16
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += X1(a[q]);  // k ^ 8
+    const float b0 = a[0] + a[4], b1 = a[1] + a[5], b2 = a[2] + a[6], b3 = a[3] + a[7];  // k ^ 4
+    const float c0 = b0 + b2, c1 = b1 + b3;                                                // k ^ 2
+    return c0 + c1;                                                                        // k ^ 1
+}
+template <int MASK>
+__device__ __forceinline__ void r2o_inlane8(float (&v)[8]) {  // compare-exchange r <-> r ^ MASK among a lane's 8, smaller first
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if ((r ^ MASK) > r) r2o_ce(v[r], v[r ^ MASK]);
+}
+__device__ __forceinline__ void r2o_tail8(float (&v)[8]) { r2o_inlane8<4>(v); r2o_inlane8<2>(v); r2o_inlane8<1>(v); }
 template <int MASK>
 __device__ __forceinline__ void r2o_inlane(float (&v)[16]) {  // compare-exchange r <-> r ^ MASK inside the lane, smaller first
 #pragma unroll
@@ -513,12 +536,21 @@ __device__ __forceinline__ void r2o_inlane(float (&v)[16]) {  // compare-exchang
         if ((r ^ MASK) > r) r2o_ce(v[r], v[r ^ MASK]);
 }
 __device__ __forceinline__ void r2o_tail16(float (&v)[16]) { r2o_inlane<8>(v); r2o_inlane<4>(v); r2o_inlane<2>(v); r2o_inlane<1>(v); }
-// `take`: this lane holds the LARGER index of the pair (it keeps the larger value)
-#define R2O_TAKE(v_, p_, upper_) { const float pp = (p_); const bool c = (pp < (v_)) != (upper_); (v_) = c ? pp : (v_); }
+// `take`: the lanes of the wave-uniform 64-bit mask upper_ hold the LARGER index of the pair (they keep the larger value).  The
+// predicate is kept in SGPRs end to end — v_cmp -> vcc, s_xor_b64 with the lane mask, v_cndmask on the result —: as a per-lane
+// bool, hipcc turns the `!= upper` into compare + select + compare on the VALU once the value crosses a branch (round 6: the
+// sort / merge paths sit behind wave-uniform branches), five VALU instructions per element instead of two + the DPP move.
+#define R2O_TAKE(v_, p_, upper_) { const float pp = (p_);                                                   \
+    const unsigned long long c = __builtin_amdgcn_ballot_w64(pp < (v_)) ^ (upper_);                          \
+    (v_) = __builtin_amdgcn_inverse_ballot_w64(c) ? pp : (v_); }
 #define R2O_MIRROR16(F, UPPER) { float q[16];                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) q[r] = F(v[15 - r]);                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) R2O_TAKE(v[r], q[r], UPPER) }
 #define R2O_XOR16(F, UPPER) { _Pragma("unroll") for (int r = 0; r < 16; ++r) R2O_TAKE(v[r], F(v[r]), UPPER) }
+#define R2O_MIRROR8(F, UPPER) { float q[8];                                                   \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) q[r] = F(sm[7 - r]);                        \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) R2O_TAKE(sm[r], q[r], UPPER) }
+#define R2O_XOR8(F, UPPER) { _Pragma("unroll") for (int r = 0; r < 8; ++r) R2O_TAKE(sm[r], F(sm[r]), UPPER) }
 
 __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float* __restrict__ z, const float* __restrict__ wts,
                                                                     const float* __restrict__ u, int64_t u_stride,
@@ -536,8 +568,12 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
     // ---- loads: four coarse depths, four weights and eight u's per lane ----
     const f32x4 z4 = *reinterpret_cast<const f32x4*>(z + ray * S + 4 * l16);
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wts + ray * S + 4 * l16);
-    const f32x4 ua = *reinterpret_cast<const f32x4*>(u + ray * u_stride + 4 * l16);
-    const f32x4 ub = *reinterpret_cast<const f32x4*>(u + ray * u_stride + 64 + 4 * l16);
+    // (samples 8 l16 .. 8 l16 + 7: the lane's eight are consecutive in u order — the order the sort below starts from)
+    const f32x4 ua = *reinterpret_cast<const f32x4*>(u + ray * u_stride + 8 * l16);
+    const f32x4 ub = *reinterpret_cast<const f32x4*>(u + ray * u_stride + 8 * l16 + 4);
+    // the lane's eight coarse depths for the merge (lanes 0 - 7; the others hold the +inf padding)
+    f32x4 za = *reinterpret_cast<const f32x4*>(z + ray * S + 8 * (l16 & 7));
+    f32x4 zb = *reinterpret_cast<const f32x4*>(z + ray * S + 8 * (l16 & 7) + 4);
     // ---- bins (position k = 4 l16 + j: .5 (z[k+1] + z[k]); k = 63 is never read) ----
     const float zn = r2l_dpp<0x101, 0xf>(0.f, z4[0]);  // row_shl:1: the next lane's first depth
     *reinterpret_cast<f32x4*>(bins + 4 * l16) = f32x4{.5f * (z4[1] + z4[0]), .5f * (z4[2] + z4[1]), .5f * (z4[3] + z4[2]), .5f * (zn + z4[3])};
@@ -569,7 +605,7 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
             if (4 * l16 + j < NW) cdf[4 * l16 + j + 1] = cc[j];
     }
     __syncthreads();
-    // ---- inverse CDF: sample i = 4 l16 + 64 m + j ----
+    // ---- inverse CDF: sample i = 8 l16 + q ----
     float samp[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -589,23 +625,75 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
         samp[q] = b0 + t * (b1 - b0);
     }
     if (live) {
-        *reinterpret_cast<f32x4*>(z_samples + ray * NI + 4 * l16) = f32x4{samp[0], samp[1], samp[2], samp[3]};
-        *reinterpret_cast<f32x4*>(z_samples + ray * NI + 64 + 4 * l16) = f32x4{samp[4], samp[5], samp[6], samp[7]};
+        *reinterpret_cast<f32x4*>(z_samples + ray * NI + 8 * l16) = f32x4{samp[0], samp[1], samp[2], samp[3]};
+        *reinterpret_cast<f32x4*>(z_samples + ray * NI + 8 * l16 + 4) = f32x4{samp[4], samp[5], samp[6], samp[7]};
     }
-    // ---- z_std = std(z_samples, unbiased=False), in the generic kernel's association (position k sums its samples k, k + 64) ----
-    const float mean = r2o_row_sum64(samp[0] + samp[4], samp[1] + samp[5], samp[2] + samp[6], samp[3] + samp[7]) / (float)NI;
-    float sq[4];
+    // ---- z_std = std(z_samples, unbiased=False), in the generic kernel's association: position k = 0 .. 63 sums its samples k and
+    //      k + 64 — lane l16 < 8 holds sample k = 8 l16 + q, lane l16 + 8 its partner (row_ror:8; the sum commutes, so both half
+    //      rows end up with the same 64 values) — then the butterfly over the positions ----
+    float t8[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float d0 = (samp[j] - mean) * (samp[j] - mean), d1 = (samp[4 + j] - mean) * (samp[4 + j] - mean);
-        sq[j] = d0 + d1;
+    for (int q = 0; q < 8; ++q) t8[q] = samp[q] + X8(samp[q]);
+    const float mean = r2o_row_sum64_8(t8) / (float)NI;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float e = (samp[q] - mean) * (samp[q] - mean);
+        t8[q] = e + X8(e);
     }
-    const float sqs = r2o_row_sum64(sq[0], sq[1], sq[2], sq[3]);
+    const float sqs = r2o_row_sum64_8(t8);
     if (live && l16 == 0 && z_std != nullptr) z_std[ray] = sqrtf(sqs / (float)NI);
-    // ---- sort [z (64), samples (128), +inf (64)]: element 16 l16 + r of the 256-element network in register v[r] ----
+    // ---- z_all = sort([z (64), samples (128)]).  Round 6: SORT the 128 samples (28 stages on 8 values per lane), then MERGE them
+    //      with the 64 coarse depths, which arrive ascending (one bitonic merge phase of the 256-element network: 8 stages on 16
+    //      values per lane) — 2816 compare-exchanges instead of the 4608 of sorting all 256 from scratch.  Both shortcuts are
+    //      CHECKED, per wave: a wave whose rays' coarse depths are not ascending (never, for the z the render stack produces:
+    //      stratified depths are monotone) takes the full network below; a wave whose samples already ascend (perturb = 0: u is
+    //      a linspace and the inverse cdf is monotone) skips their sort.  The result is the sorted multiset either way: same bits
+    //      as torch.sort.
+    // lanes whose l16 has bit b set, as wave-uniform masks (l16 = lane & 15: the same four rows in every wave)
+    const unsigned long long u0 = 0xAAAAAAAAAAAAAAAAull, u1 = 0xCCCCCCCCCCCCCCCCull, u2 = 0xF0F0F0F0F0F0F0F0ull, u3 = 0xFF00FF00FF00FF00ull;
+    if (l16 >= 8) { za = f32x4{INFINITY, INFINITY, INFINITY, INFINITY}; zb = za; }
+    const float z_next = r2l_dpp<0x101, 0xf>(INFINITY, za[0]);  // row_shl:1: the next lane's first (lane 15: none -> +inf)
+    const bool z_asc = za[0] <= za[1] && za[1] <= za[2] && za[2] <= za[3] && za[3] <= zb[0] && zb[0] <= zb[1] && zb[1] <= zb[2] &&
+                       zb[2] <= zb[3] && zb[3] <= z_next;
+    if (__builtin_amdgcn_ballot_w64(z_asc) == ~0ull) {
+        float sm[8] = {samp[0], samp[1], samp[2], samp[3], samp[4], samp[5], samp[6], samp[7]};
+        const float s_next = r2l_dpp<0x101, 0xf>(INFINITY, sm[0]);
+        const bool s_asc = sm[0] <= sm[1] && sm[1] <= sm[2] && sm[2] <= sm[3] && sm[3] <= sm[4] && sm[4] <= sm[5] && sm[5] <= sm[6] &&
+                           sm[6] <= sm[7] && sm[7] <= s_next;
+        if (__builtin_amdgcn_ballot_w64(s_asc) != ~0ull) {  // sort the samples: element 8 l16 + r of a 128-element network in sm[r]
+            r2o_inlane8<1>(sm);                                                                        // k = 2
+            r2o_inlane8<3>(sm); r2o_inlane8<1>(sm);                                                    // k = 4
+            r2o_inlane8<7>(sm); r2o_inlane8<2>(sm); r2o_inlane8<1>(sm);                                // k = 8
+            R2O_MIRROR8(X1, u0) r2o_tail8(sm);                                                         // k = 16
+            R2O_MIRROR8(X3, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);                                        // k = 32
+            R2O_MIRROR8(X7, u2) R2O_XOR8(X2, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);                       // k = 64
+            R2O_MIRROR8(X15, u3) R2O_XOR8(X4, u2) R2O_XOR8(X2, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);     // k = 128
+        }
+        // merge: position P = 128 half + 8 l16 + r; half 0 = the sorted samples, half 1 = [z ascending, +inf x 64]
+        float v[16] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], sm[6], sm[7], za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+        {   // P <-> P ^ 255: the other half, lane ^ 15, register 7 - r; the lower half keeps the smaller
+            float qa[8], qb[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { qa[r] = X15(v[15 - r]); qb[r] = X15(v[7 - r]); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { v[r] = r2o_min(v[r], qa[r]); v[8 + r] = r2o_max(v[8 + r], qb[r]); }
+        }
+        R2O_XOR16(X8, u3) R2O_XOR16(X4, u2) R2O_XOR16(X2, u1) R2O_XOR16(X1, u0)      // P ^ 64, 32, 16, 8: lane ^ 8, 4, 2, 1
+        r2o_inlane<4>(v); r2o_inlane<2>(v); r2o_inlane<1>(v);                        // P ^ 4, 2, 1: inside each half of the lane
+        if (live) {  // lane l16: z_all[8 l16 .. + 7] and, of the upper half, z_all[128 + 8 l16 .. + 7] (l16 < 8: 192 depths)
+            float* out = z_all + ray * (S + NI) + 8 * l16;
+            *reinterpret_cast<f32x4*>(out) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(out + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            if (l16 < 8) {
+                *reinterpret_cast<f32x4*>(out + 128) = f32x4{v[8], v[9], v[10], v[11]};
+                *reinterpret_cast<f32x4*>(out + 132) = f32x4{v[12], v[13], v[14], v[15]};
+            }
+        }
+        return;
+    }
+    // ---- full network (coarse depths not ascending): [z (64), samples (128), +inf (64)], element 16 l16 + r in register v[r] ----
     float v[16] = {z4[0], z4[1], z4[2], z4[3], samp[0], samp[1], samp[2], samp[3], samp[4], samp[5], samp[6], samp[7],
                    INFINITY, INFINITY, INFINITY, INFINITY};
-    const bool u0 = (l16 & 1) != 0, u1 = (l16 & 2) != 0, u2 = (l16 & 4) != 0, u3 = (l16 & 8) != 0;
     r2o_inlane<1>(v);                                                                     // k = 2
     r2o_inlane<3>(v); r2o_inlane<1>(v);                                                   // k = 4
     r2o_inlane<7>(v); r2o_inlane<2>(v); r2o_inlane<1>(v);                                 // k = 8
@@ -630,6 +718,8 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
 #undef R2O_TAKE
 #undef R2O_MIRROR16
 #undef R2O_XOR16
+#undef R2O_MIRROR8
+#undef R2O_XOR8
 
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI

@@ -128,6 +128,57 @@ def test_sample_pdf_sort_golden(golden_dir):
         np.testing.assert_allclose(z_std.cpu().numpy(), torch.std(zs.cpu(), dim=-1, unbiased=False).numpy(), rtol=1e-4)
 
 
+def test_sample_pdf_sort_three_paths_agree_bit_for_bit():
+    """r2l_sample_pdf_sort16_kernel (round 6; reference: helpers:283-330 sample_pdf + the sort of create_data.py:513-517) sorts the
+    128 samples and MERGES them with the 64 coarse depths instead of sorting all 256 values — legitimate only while the coarse
+    depths ascend, which the kernel checks per wave (four rays).  All its paths must give torch.sort's bits:
+      (a) random u, ascending z           -> sort of the samples + merge;
+      (b) det u (a linspace), ascending z -> the samples already ascend: their sort is skipped, merge only;
+      (c) rays whose z is NOT ascending (never produced by the render stack; the C ABI accepts any z) -> the full 256-element
+          network, for that wave, while its neighbours stay on the merge;
+    and z_samples / z_std carry the same bits as the generic one-ray-per-wave kernel (same summation association)."""
+    import ctypes
+    from r2l_amd import _lib
+    from r2l_amd.render import sample_pdf_sort
+    lib = _lib.load()
+    R, S, NI = 203, 64, 128
+    g = torch.Generator().manual_seed(77)
+    z = torch.sort(torch.rand(R, S, generator=g) * 4 + 2, -1)[0]
+    z[5, 10:20] = z[5, 10]           # ties
+    w = torch.rand(R, S, generator=g) ** 3
+    u = torch.rand(R, NI, generator=g)
+    u[7] = torch.sort(u[7])[0]       # one ray of a random wave with ascending samples: its wave still sorts
+    u[9, 3] = u[9, 4]                # equal uniforms
+    bad = z.clone()
+    for r in (0, 41, 42, 43, 130, 202):  # non-ascending coarse depths: a single swap, a reversed row, a late inversion
+        bad[r] = z[r].flip(0) if r == 41 else z[r]
+    bad[0, [3, 4]] = bad[0, [4, 3]]
+    bad[42, [62, 63]] = bad[42, [63, 62]]
+    bad[43, [7, 8]] = bad[43, [8, 7]]      # (an inversion across the boundary of two lanes' eight depths)
+    bad[130, [31, 32]] = bad[130, [32, 31]]
+    bad[202, [0, 63]] = bad[202, [63, 0]]
+    assert (bad[:, 1:] < bad[:, :-1]).any(1).sum().item() == 6
+
+    def generic(zz, uu):  # the one-ray-per-wave kernel: reached through an odd u stride (the 16-lane kernel needs 16-byte rows)
+        upad = torch.zeros(R, NI + 1)
+        upad[:, :NI] = uu
+        ud, zd_in, wd = upad.cuda(), zz.cuda().contiguous(), w.cuda().contiguous()  # (kept alive until the results are read back)
+        zs, za, zd = (torch.empty(R, NI, device="cuda"), torch.empty(R, S + NI, device="cuda"), torch.empty(R, device="cuda"))
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(lib.r2l_sample_pdf_sort(p(zd_in), p(wd), p(ud), NI + 1, p(zs), p(za), p(zd), R, S, NI,
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "r2l_sample_pdf_sort")
+        return zs.cpu(), za.cpu(), zd.cpu()
+
+    for zz, uu, det in ((z, u, False), (z, torch.linspace(0., 1., NI).expand(R, NI).contiguous(), True), (bad, u, False)):
+        zs, z_all, z_std = sample_pdf_sort(zz.cuda(), w.cuda(), NI, det=det, u=uu if not det else torch.linspace(0., 1., NI))
+        zs, z_all, z_std = zs.cpu(), z_all.cpu(), z_std.cpu()
+        assert torch.equal(z_all, torch.sort(torch.cat([zz, zs], -1), -1)[0])
+        gs, ga, gd = generic(zz, uu)
+        assert torch.equal(zs, gs) and torch.equal(z_all, ga) and torch.equal(z_std, gd)
+        if det:
+            assert (zs[:, 1:] >= zs[:, :-1]).all()  # the monotone inverse cdf: what lets the kernel skip the sort
+
+
 @pytest.mark.parametrize("S,NI,R", [(64, 128, 37), (64, 128, 4099), (64, 64, 9), (33, 77, 21), (16, 192, 5), (5, 3, 7)])
 def test_sample_pdf_sort_shapes_vs_oracle(S, NI, R):
     """(64, 128): the quarter-wave-per-ray kernel (r2l_sample_pdf_sort16_kernel; 16 rays per workgroup: R = 37 / 4099 leave tail

@@ -156,15 +156,18 @@ def test_cli_teacher_render_eight_ranks(scene_and_teacher):
 def test_bench_eight_ranks_walk(tmp_path):
     """`bench.py --gpus 8` as the driver launches it, with the eight ranks sharing this GPU over gloo (R2L_BENCH_SHARED_GPU_TEST=1):
     every leg an 8-GPU node would time produces a well-formed record — frames sharded over 8 ranks, weak-scaling train legs with
-    the bucketed all-reduce (timeline of 4 buckets), the strong-scaling leg at 98 304 / 8 = 12 288 rays per rank on the two-tile
-    cooperative chains, the 4096-ray legs, the pose-sharded teacher leg — so that the first contact with a real node has nothing at
+    the bucketed all-reduce (timeline of 4 buckets + the head), the strong-scaling leg, the 12 288-ray leg (= 98 304 / 8, the per-rank
+    share of the README step) on the two-tile cooperative chains, the 4096-ray legs, the pose-sharded teacher leg — so that the first contact with a real node has nothing at
     N = 8 that is new code (VERDICT r5 #4; reference mechanism: main.py:472-479, utils/create_data.py:297-299).  Not a measurement."""
     import json
     env = _env()
     env.pop("R2L_DIST_BACKEND", None)
     env["R2L_BENCH_SHARED_GPU_TEST"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(WORLD), "--master-addr", "127.0.0.1",
-           "--master-port", "29663", os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "2", "--warmup", "1"]
+           "--master-port", "29663", os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "2", "--warmup", "1",
+           # (eight ranks share ONE GPU's memory here: the default 98 304-ray legs hold 36 GB of stash per rank — 288 GB, the whole
+           # HBM, and the walk then spends minutes in allocator retries; a third of the rays walks the same code)
+           "--train-rays", "32768"]
     r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -181,14 +184,15 @@ def test_bench_eight_ranks_walk(tmp_path):
         rf = leg["roofline"]
         assert rf["grad_allreduce_alone_ms"] > 0 and rf["grad_allreduce_bytes"] == 5917187 * 4 and rf["allreduce_buckets"] == 4
         tl = rf["bucket_timeline_ms"]
-        assert len(tl) == 4 and sum(b["floats"] for b in tl) == 5917187 and all(b["submit"] >= 0 for b in tl), tl
+        # (4 body / tail buckets + the head's range, in submission order: together the whole flat gradient, each float once)
+        assert len(tl) == 5 and sum(b["floats"] for b in tl) == 5917187 and all(b["submit"] >= 0 for b in tl), tl
         assert rf["bucket_timeline_step_ms"] > 0
 
-    for leg, n in ((out["train"], 98304), (out["train_4096"], 4096), (out["train_12288"], 12288), (fast["train"], 98304),
-                   (fast["train_strong"], 12288), (fast["train_4096"], 4096), (fast["train_12288"], 12288)):
+    for leg, n in ((out["train"], 32768), (out["train_4096"], 4096), (out["train_12288"], 12288), (fast["train"], 32768),
+                   (fast["train_strong"], 4096), (fast["train_4096"], 4096), (fast["train_12288"], 12288)):
         well_formed(leg, n)
-    assert fast["train_strong"]["scaling"] == "strong" and fast["train_strong"]["global_rays_per_step"] == 98304
-    assert "2 tile(s) per workgroup" in fast["train_strong"]["roofline"]["matrix_path"]
+    assert fast["train_strong"]["scaling"] == "strong" and fast["train_strong"]["global_rays_per_step"] == 32768
+    assert "2 tile(s) per workgroup" in fast["train_12288"]["roofline"]["matrix_path"]  # the per-GPU share of the README step at 8 GPUs
     for t in (out["teacher"], fast["teacher"]):
         assert t["value"] > 0 and t["precision"] in ("fp32_mfma", "fp16x2") and t["parallelism"].startswith("poses sharded across 8")
     assert list(out)[-1] == "summary" and out["summary"]["fast_train_strong"][0] > 0 and out["summary"]["graded_train_4096"][0] > 0
