@@ -311,16 +311,23 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
         return {"bytes_per_ray": bpr, "weights_emitted": need_w, "us_per_launch": us, "timing": method, "input_sets_cycled": n_sets,
                 "achieved": tbs, "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3}
 
-    def measure_pdf(rays, n_sets, k, S=64, NI=128):
+    def measure_pdf(rays, n_sets, k, S=64, NI=128, det=False):
         zs = [(torch.sort(torch.rand(rays, S, generator=g), -1)[0] * 4. + 2.).to(device) for _ in range(n_sets)]
         ws = [(torch.rand(rays, S, generator=g) ** 4).to(device) for _ in range(n_sets)]
-        us_ = [torch.rand(rays, NI, generator=g).to(device) for _ in range(n_sets)]
-        us, method = graph_us(lambda i: sample_pdf_sort(zs[i % n_sets], ws[i % n_sets], NI, u=us_[i % n_sets]), k, warmup)
-        bpr = 4 * (S + S + NI) + 4 * (NI + S + NI) + 4
+        if det:  # perturb = 0 (the test-set / video renders of the teacher): ONE linspace for every ray, 512 B instead of 512 B per ray
+            lin = torch.linspace(0., 1., NI).to(device)
+            us, method = graph_us(lambda i: sample_pdf_sort(zs[i % n_sets], ws[i % n_sets], NI, det=True, u=lin), k, warmup)
+        else:
+            us_ = [torch.rand(rays, NI, generator=g).to(device) for _ in range(n_sets)]
+            us, method = graph_us(lambda i: sample_pdf_sort(zs[i % n_sets], ws[i % n_sets], NI, u=us_[i % n_sets]), k, warmup)
+        bpr = 4 * (S + S + (0 if det else NI)) + 4 * (NI + S + NI) + 4
         tbs = rays * bpr / (us * 1e-6) / 1e12
         return {"bytes_per_ray": bpr, "us_per_launch": us, "timing": method, "input_sets_cycled": n_sets, "achieved": tbs,
                 "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3, "kernel": "r2l_sample_pdf_sort16_kernel",
-                "bound_note": "2308 B per ray would make it HBM-bound; the 256-element sorting network per ray (4608 compare-exchanges) makes it VALU-issue bound"}
+                "bound_note": "2308 B per ray would make it HBM-bound; round 6: the 128 samples are sorted and merged with the ascending "
+                              "coarse depths (2816 compare-exchanges per ray instead of 4608; 1342 VALU instructions per wave of four rays "
+                              "instead of 1581) — the launch is one round of resident waves whose load, compute and store phases do "
+                              "not overlap (profiles/r06_sample_pdf_sort.txt)"}
 
     for S, need_w in ((64, True), (192, False)):
         r = measure(S, need_w, n_rays, 8 if S <= 64 else 4, max(20, steps))
@@ -338,6 +345,9 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
     r["traffic"], r["traffic_source"] = pmc_traffic("r2l_sample_pdf_sort16_kernel", grid_threads=(n_rays + 15) // 16 * 256)
     r["algorithmic_bytes"] = n_rays * r["bytes_per_ray"]
     out["sample_pdf_sort"] = r
+    rd = measure_pdf(n_rays, 8, max(20, steps), det=True)  # perturb = 0: the samples come out ascending, their sort is skipped
+    rd["note"] = "det u (perturb = 0: main.py --model_name nerf --render_test): merge only"
+    out["sample_pdf_sort_det"] = rd
     return out
 
 
@@ -364,7 +374,8 @@ def summary_of(out):
     if r2o:
         sm["raw2outputs_frac_of_8TBs"] = {k: round(v["frac"], 4) for k, v in r2o.items() if isinstance(v, dict)}
         sm["raw2outputs_TBs"] = {k: round(v["achieved"], 3) for k, v in r2o.items() if isinstance(v, dict)}
-        sm["raw2outputs_TBs_at_262144_rays"] = {k: round(v["at_262144_rays"]["achieved"], 3) for k, v in r2o.items() if isinstance(v, dict)}
+        sm["raw2outputs_TBs_at_262144_rays"] = {k: round(v["at_262144_rays"]["achieved"], 3) for k, v in r2o.items()
+                                                if isinstance(v, dict) and "at_262144_rays" in v}
     cb = out.get("cpu_baseline")
     if cb:
         sm["cpu_baseline_rays_per_s"] = {"forward": round(cb["value"]), "train": round(cb["train"]["value"]), "cores": cb["cores"]}

@@ -500,6 +500,12 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort_kernel(const float* _
 #define X4(x) r2o_perm<0x1B>(r2o_perm<0x141>(x))  /* (lane ^ 3) ^ 7                 */
 #define X8(x) r2o_perm<0x128>(x)                  /* row_ror:8            lane ^ 8  */
 #define X15(x) r2o_perm<0x140>(x)                 /* row_mirror           lane ^ 15 */
+#define DPP_X1 "quad_perm:[1,0,3,2]"
+#define DPP_X2 "quad_perm:[2,3,0,1]"
+#define DPP_X3 "quad_perm:[3,2,1,0]"
+#define DPP_X7 "row_half_mirror"
+#define DPP_X8 "row_ror:8"
+#define DPP_X15 "row_mirror"
 // sum over the 64 positions k = 4 l16 + j of a ray in wave_sum's association; every lane of the row gets the total
 __device__ __forceinline__ float r2o_row_sum64(float a0, float a1, float a2, float a3) {
     a0 += X8(a0); a1 += X8(a1); a2 += X8(a2); a3 += X8(a3);  // k ^ 32
@@ -543,6 +549,37 @@ __device__ __forceinline__ void r2o_tail16(float (&v)[16]) { r2o_inlane<8>(v); r
 #define R2O_TAKE(v_, p_, upper_) { const float pp = (p_);                                                   \
     const unsigned long long c = __builtin_amdgcn_ballot_w64(pp < (v_)) ^ (upper_);                          \
     (v_) = __builtin_amdgcn_inverse_ballot_w64(c) ? pp : (v_); }
+// Cross-lane steps whose "upper" lanes are whole DPP BANKS (lane bits 2, 3 of the row: partners lane ^ 4, lane ^ 8, and the mirror
+// steps lane ^ 7, lane ^ 15) need no compare-select at all (round 6): v_min_f32_dpp writes the lower banks, v_max_f32_dpp the upper
+// ones — the DPP bank_mask disables the other lanes' writes — both reading the partner through their DPP operand: two VALU
+// instructions per element, into fresh registers, instead of a DPP move + compare + select (lane ^ 4: two moves).  (VOPC has no
+// DPP form on gfx9, so the steps inside a bank — lane ^ 1, ^ 2, ^ 3 — keep the move + v_cmp + s_xor + v_cndmask form.)
+// (hand-placed s_nop 1: a VALU write of a register needs two wait states before a DPP read of it, and the hazard recogniser does
+// not look into inline asm.)
+#define R2O_ASM_BANK1(O, A, B, LO, HI, BLO, BHI)                                                          \
+    "v_min_f32_dpp %" #O ", %" #A ", %" #B " " LO " row_mask:0xf bank_mask:" BLO "\n\t"                  \
+    "v_max_f32_dpp %" #O ", %" #A ", %" #B " " HI " row_mask:0xf bank_mask:" BHI "\n\t"
+// x[r] <-> the same register of the partner lane (r = 0 .. 7)
+#define R2O_ASM_BANK_XOR8(x, LO, HI, BLO, BHI) { float t_[8];                                                                             \
+    asm volatile("s_nop 1\n\t" R2O_ASM_BANK1(0, 8, 8, LO, HI, BLO, BHI) R2O_ASM_BANK1(1, 9, 9, LO, HI, BLO, BHI)                           \
+                 R2O_ASM_BANK1(2, 10, 10, LO, HI, BLO, BHI) R2O_ASM_BANK1(3, 11, 11, LO, HI, BLO, BHI)                                     \
+                 R2O_ASM_BANK1(4, 12, 12, LO, HI, BLO, BHI) R2O_ASM_BANK1(5, 13, 13, LO, HI, BLO, BHI)                                     \
+                 R2O_ASM_BANK1(6, 14, 14, LO, HI, BLO, BHI) R2O_ASM_BANK1(7, 15, 15, LO, HI, BLO, BHI)                                     \
+                 : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]), "=&v"(t_[4]), "=&v"(t_[5]), "=&v"(t_[6]), "=&v"(t_[7])           \
+                 : "v"((x)[0]), "v"((x)[1]), "v"((x)[2]), "v"((x)[3]), "v"((x)[4]), "v"((x)[5]), "v"((x)[6]), "v"((x)[7]));               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) (x)[r_] = t_[r_]; }
+// x[r] <-> register 7 - r of the partner lane
+#define R2O_ASM_BANK_MIRROR8(x, CTRL, BLO, BHI) { float t_[8];                                                                            \
+    asm volatile("s_nop 1\n\t" R2O_ASM_BANK1(0, 15, 8, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(1, 14, 9, CTRL, CTRL, BLO, BHI)                 \
+                 R2O_ASM_BANK1(2, 13, 10, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(3, 12, 11, CTRL, CTRL, BLO, BHI)                             \
+                 R2O_ASM_BANK1(4, 11, 12, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(5, 10, 13, CTRL, CTRL, BLO, BHI)                             \
+                 R2O_ASM_BANK1(6, 9, 14, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(7, 8, 15, CTRL, CTRL, BLO, BHI)                               \
+                 : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]), "=&v"(t_[4]), "=&v"(t_[5]), "=&v"(t_[6]), "=&v"(t_[7])           \
+                 : "v"((x)[0]), "v"((x)[1]), "v"((x)[2]), "v"((x)[3]), "v"((x)[4]), "v"((x)[5]), "v"((x)[6]), "v"((x)[7]));               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) (x)[r_] = t_[r_]; }
+// static form (the merge's first step): lower half min, upper half max, partner = DPP(other register) — new values into fresh registers
+#define R2O_ASM_MINMAX_DPP(OP, CTRL, out, own, other)                                                                      \
+    asm volatile("s_nop 1\n\t" OP " %0, %2, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=&v"(out) : "v"(own), "v"(other))
 #define R2O_MIRROR16(F, UPPER) { float q[16];                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) q[r] = F(v[15 - r]);                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) R2O_TAKE(v[r], q[r], UPPER) }
@@ -557,8 +594,11 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
                                                                     float* __restrict__ z_samples, float* __restrict__ z_all,
                                                                     float* __restrict__ z_std, int64_t R) {
     constexpr int S = 64, NI = 128, NB = S - 1, NW = S - 2;
-    __shared__ float s_cdf[16][64];
-    __shared__ float s_bins[16][64];
+    // (row stride 68 words: the four rays of a wave — and the two of a 32-lane LDS group — read the SAME index of their tables in the
+    // first steps of the search; at stride 64 those are 4 addresses in one bank.  PMC, round 6: 68 % of the kernel's LDS cycles were
+    // bank conflicts)
+    __shared__ __attribute__((aligned(16))) float s_cdf[16][68];
+    __shared__ __attribute__((aligned(16))) float s_bins[16][68];
     const int lane = threadIdx.x & 63, l16 = lane & 15, slot = threadIdx.x >> 4;
     int64_t ray = (int64_t)blockIdx.x * 16 + slot;
     const bool live = ray < R;  // rows past the end run on a clamped ray (they meet the block barrier) and store nothing
@@ -664,21 +704,30 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
             r2o_inlane8<1>(sm);                                                                        // k = 2
             r2o_inlane8<3>(sm); r2o_inlane8<1>(sm);                                                    // k = 4
             r2o_inlane8<7>(sm); r2o_inlane8<2>(sm); r2o_inlane8<1>(sm);                                // k = 8
-            R2O_MIRROR8(X1, u0) r2o_tail8(sm);                                                         // k = 16
-            R2O_MIRROR8(X3, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);                                        // k = 32
-            R2O_MIRROR8(X7, u2) R2O_XOR8(X2, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);                       // k = 64
-            R2O_MIRROR8(X15, u3) R2O_XOR8(X4, u2) R2O_XOR8(X2, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);     // k = 128
+            R2O_MIRROR8(X1, u0) r2o_tail8(sm);                                                                      // k = 16
+            R2O_MIRROR8(X3, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);                                                     // k = 32
+            R2O_ASM_BANK_MIRROR8(sm, "row_half_mirror", "0x5", "0xa") R2O_XOR8(X2, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);  // k = 64
+            R2O_ASM_BANK_MIRROR8(sm, "row_mirror", "0x3", "0xc") R2O_ASM_BANK_XOR8(sm, "row_shl:4", "row_shr:4", "0x5", "0xa")
+            R2O_XOR8(X2, u1) R2O_XOR8(X1, u0) r2o_tail8(sm);                                                        // k = 128
         }
         // merge: position P = 128 half + 8 l16 + r; half 0 = the sorted samples, half 1 = [z ascending, +inf x 64]
         float v[16] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], sm[6], sm[7], za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
         {   // P <-> P ^ 255: the other half, lane ^ 15, register 7 - r; the lower half keeps the smaller
-            float qa[8], qb[8];
+            float nv[16];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { qa[r] = X15(v[15 - r]); qb[r] = X15(v[7 - r]); }
+            for (int r = 0; r < 8; ++r) {
+                R2O_ASM_MINMAX_DPP("v_min_f32_dpp", DPP_X15, nv[r], v[r], v[15 - r]);
+                R2O_ASM_MINMAX_DPP("v_max_f32_dpp", DPP_X15, nv[8 + r], v[8 + r], v[7 - r]);
+            }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { v[r] = r2o_min(v[r], qa[r]); v[8 + r] = r2o_max(v[8 + r], qb[r]); }
+            for (int r = 0; r < 16; ++r) v[r] = nv[r];
         }
-        R2O_XOR16(X8, u3) R2O_XOR16(X4, u2) R2O_XOR16(X2, u1) R2O_XOR16(X1, u0)      // P ^ 64, 32, 16, 8: lane ^ 8, 4, 2, 1
+        {   // P ^ 64, 32: lane ^ 8, lane ^ 4 (bank steps); P ^ 16, 8: lane ^ 2, lane ^ 1
+            float* lo = v; float* hi = v + 8;
+            R2O_ASM_BANK_XOR8(lo, "row_ror:8", "row_ror:8", "0x3", "0xc") R2O_ASM_BANK_XOR8(hi, "row_ror:8", "row_ror:8", "0x3", "0xc")
+            R2O_ASM_BANK_XOR8(lo, "row_shl:4", "row_shr:4", "0x5", "0xa") R2O_ASM_BANK_XOR8(hi, "row_shl:4", "row_shr:4", "0x5", "0xa")
+            R2O_XOR16(X2, u1) R2O_XOR16(X1, u0)
+        }
         r2o_inlane<4>(v); r2o_inlane<2>(v); r2o_inlane<1>(v);                        // P ^ 4, 2, 1: inside each half of the lane
         if (live) {  // lane l16: z_all[8 l16 .. + 7] and, of the upper half, z_all[128 + 8 l16 .. + 7] (l16 < 8: 192 depths)
             float* out = z_all + ray * (S + NI) + 8 * l16;
@@ -720,6 +769,10 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
 #undef R2O_XOR16
 #undef R2O_MIRROR8
 #undef R2O_XOR8
+#undef R2O_ASM_BANK1
+#undef R2O_ASM_BANK_XOR8
+#undef R2O_ASM_BANK_MIRROR8
+#undef R2O_ASM_MINMAX_DPP
 
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
