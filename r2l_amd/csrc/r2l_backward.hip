@@ -298,33 +298,57 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
             f32x4 gb[DW_DEPTH], ab[DW_DEPTH];
 #pragma unroll
             for (int k = 0; k < DW_DEPTH; ++k) ld(k, gb[k], ab[k]);
+#ifdef DW_SCHED_V1  // rounds 1 - 5 (A/B builds): the buffer a k-step consumed is refilled BEHIND its 16 MFMAs
             int64_t s = 0;
             // hipcc drains vmcnt to 0 at every loop header, which exposes the full HBM latency of the newest load (~2 us):
             // long trips amortise it (one drain per 2048 / 1024 / 512 MFMAs)
-            for (; s + DW_LONG_TRIP <= nfull; s += DW_LONG_TRIP) {
-#pragma unroll
-                for (int k = 0; k < DW_LONG_TRIP; ++k) {
-                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
-                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+#define DW_TRIPS(TRIP)                                                                       \
+            for (; s + TRIP <= nfull; s += TRIP) {                                           \
+                _Pragma("unroll") for (int k = 0; k < TRIP; ++k) {                           \
+                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);                               \
+                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);                \
+                    __builtin_amdgcn_sched_barrier(0);                                       \
+                }                                                                            \
             }
-            for (; s + 64 <= nfull; s += 64) {
-#pragma unroll
-                for (int k = 0; k < 64; ++k) {
-                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
-                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+#else
+            // Round 6.  With one wave per SIMD nothing else fills the issue port, and the round-5 loop put a k-step's two loads, its
+            // clamp (a 64-bit VALU compare + three scalar ops) and the four bias adds in a lump BEHIND its 16 MFMAs (they could not go
+            // earlier: the loads overwrite the operands those MFMAs read): ~130 issue cycles against the 64 the last MFMA covers —
+            // the matrix pipe idled ~11 % of the kernel (PMC: 88.9 % busy at 2.39 GHz, 1152 cycles per k-step instead of 1024).
+            // Now the buffer consumed ONE K-STEP AGO is refilled under this k-step's MFMAs (same look-ahead: three k-steps), the
+            // clamp is one s_min_i32; the loads issue in the shadow of the previous k-step's last MFMA, the bias adds among this one's.  (The first k-step
+            // of a segment refills the last prologue buffer with the data it already holds: one redundant load pair per segment.)
+            const int nfull32 = (int)nfull;
+            auto ldi = [&](int s32, f32x4& gv, f32x4& av) {
+                const int sc = s32 < nfull32 ? s32 : nfull32 - 1;
+                const unsigned so = (unsigned)sc * (2u * R2L_W * 4u);
+                gv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, gvo, so, 0));
+                av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avo, so, 0));
+            };
+            int s = 0;
+#if defined(DW_PIN_MODE) && DW_PIN_MODE == 1  // A/B: loads pinned among the first MFMAs
+#define DW_PIN __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+               __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#else
+#define DW_PIN
+#endif
+#define DW_TRIPS(TRIP)                                                                                                   \
+            for (; s + TRIP <= nfull32; s += TRIP) {                                                                     \
+                _Pragma("unroll") for (int k = 0; k < TRIP; ++k) {                                                       \
+                    ldi(s + k - 1 + DW_DEPTH, gb[(k + DW_DEPTH - 1) % DW_DEPTH], ab[(k + DW_DEPTH - 1) % DW_DEPTH]);     \
+                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);                                                           \
+                    DW_PIN                                                                                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                                   \
+                }                                                                                                        \
             }
-            for (; s + 32 <= nfull; s += 32) {
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
-                    ld(s + k + DW_DEPTH, gb[k % DW_DEPTH], ab[k % DW_DEPTH]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+#endif
+            DW_TRIPS(DW_LONG_TRIP)
+            DW_TRIPS(64)
+            DW_TRIPS(32)
+#undef DW_TRIPS
+#ifdef DW_PIN
+#undef DW_PIN
+#endif
             for (; s < nfull; ++s) {  // remainder: only the last, partial chunk at the end of N
                 f32x4 gv, av;
                 ld(s, gv, av);
