@@ -554,8 +554,8 @@ __device__ __forceinline__ void r2o_tail16(float (&v)[16]) { r2o_inlane<8>(v); r
 // ones — the DPP bank_mask disables the other lanes' writes — both reading the partner through their DPP operand: two VALU
 // instructions per element, into fresh registers, instead of a DPP move + compare + select (lane ^ 4: two moves).  (VOPC has no
 // DPP form on gfx9, so the steps inside a bank — lane ^ 1, ^ 2, ^ 3 — keep the move + v_cmp + s_xor + v_cndmask form.)
-// (hand-placed s_nop 1: a VALU write of a register needs two wait states before a DPP read of it, and the hazard recogniser does
-// not look into inline asm.)
+// (hand-placed s_nop 1 at both ends of a block: a VALU write of a register needs two wait states before a DPP read of it, and the
+// hazard recogniser does not look into inline asm — neither at what the block reads first nor at what it wrote last.)
 #define R2O_ASM_BANK1(O, A, B, LO, HI, BLO, BHI)                                                          \
     "v_min_f32_dpp %" #O ", %" #A ", %" #B " " LO " row_mask:0xf bank_mask:" BLO "\n\t"                  \
     "v_max_f32_dpp %" #O ", %" #A ", %" #B " " HI " row_mask:0xf bank_mask:" BHI "\n\t"
@@ -564,7 +564,7 @@ __device__ __forceinline__ void r2o_tail16(float (&v)[16]) { r2o_inlane<8>(v); r
     asm volatile("s_nop 1\n\t" R2O_ASM_BANK1(0, 8, 8, LO, HI, BLO, BHI) R2O_ASM_BANK1(1, 9, 9, LO, HI, BLO, BHI)                           \
                  R2O_ASM_BANK1(2, 10, 10, LO, HI, BLO, BHI) R2O_ASM_BANK1(3, 11, 11, LO, HI, BLO, BHI)                                     \
                  R2O_ASM_BANK1(4, 12, 12, LO, HI, BLO, BHI) R2O_ASM_BANK1(5, 13, 13, LO, HI, BLO, BHI)                                     \
-                 R2O_ASM_BANK1(6, 14, 14, LO, HI, BLO, BHI) R2O_ASM_BANK1(7, 15, 15, LO, HI, BLO, BHI)                                     \
+                 R2O_ASM_BANK1(6, 14, 14, LO, HI, BLO, BHI) R2O_ASM_BANK1(7, 15, 15, LO, HI, BLO, BHI) "s_nop 1"                           \
                  : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]), "=&v"(t_[4]), "=&v"(t_[5]), "=&v"(t_[6]), "=&v"(t_[7])           \
                  : "v"((x)[0]), "v"((x)[1]), "v"((x)[2]), "v"((x)[3]), "v"((x)[4]), "v"((x)[5]), "v"((x)[6]), "v"((x)[7]));               \
     _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) (x)[r_] = t_[r_]; }
@@ -573,13 +573,29 @@ __device__ __forceinline__ void r2o_tail16(float (&v)[16]) { r2o_inlane<8>(v); r
     asm volatile("s_nop 1\n\t" R2O_ASM_BANK1(0, 15, 8, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(1, 14, 9, CTRL, CTRL, BLO, BHI)                 \
                  R2O_ASM_BANK1(2, 13, 10, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(3, 12, 11, CTRL, CTRL, BLO, BHI)                             \
                  R2O_ASM_BANK1(4, 11, 12, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(5, 10, 13, CTRL, CTRL, BLO, BHI)                             \
-                 R2O_ASM_BANK1(6, 9, 14, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(7, 8, 15, CTRL, CTRL, BLO, BHI)                               \
+                 R2O_ASM_BANK1(6, 9, 14, CTRL, CTRL, BLO, BHI) R2O_ASM_BANK1(7, 8, 15, CTRL, CTRL, BLO, BHI) "s_nop 1"                     \
                  : "=&v"(t_[0]), "=&v"(t_[1]), "=&v"(t_[2]), "=&v"(t_[3]), "=&v"(t_[4]), "=&v"(t_[5]), "=&v"(t_[6]), "=&v"(t_[7])           \
                  : "v"((x)[0]), "v"((x)[1]), "v"((x)[2]), "v"((x)[3]), "v"((x)[4]), "v"((x)[5]), "v"((x)[6]), "v"((x)[7]));               \
     _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) (x)[r_] = t_[r_]; }
-// static form (the merge's first step): lower half min, upper half max, partner = DPP(other register) — new values into fresh registers
-#define R2O_ASM_MINMAX_DPP(OP, CTRL, out, own, other)                                                                      \
-    asm volatile("s_nop 1\n\t" OP " %0, %2, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=&v"(out) : "v"(own), "v"(other))
+// static form (the merge's first step: P <-> P ^ 255): the lower half (registers a[0..7]) keeps the smaller of a[r] and the partner
+// lane's b[7 - r], the upper half (b[0..7]) the larger of b[r] and the partner's a[7 - r] — one DPP instruction per element, new
+// values into fresh registers
+#define R2O_ASM_MM1(OP, O, A, B) OP " %" #O ", %" #A ", %" #B " row_mirror row_mask:0xf bank_mask:0xf\n\t"
+#define R2O_ASM_MERGE_MIRROR(na, nb, a, b)                                                                                                \
+    asm volatile("s_nop 1\n\t" R2O_ASM_MM1("v_min_f32_dpp", 0, 23, 8) R2O_ASM_MM1("v_min_f32_dpp", 1, 22, 9)                               \
+                 R2O_ASM_MM1("v_min_f32_dpp", 2, 21, 10) R2O_ASM_MM1("v_min_f32_dpp", 3, 20, 11)                                           \
+                 R2O_ASM_MM1("v_min_f32_dpp", 4, 19, 12) R2O_ASM_MM1("v_min_f32_dpp", 5, 18, 13)                                           \
+                 R2O_ASM_MM1("v_min_f32_dpp", 6, 17, 14) R2O_ASM_MM1("v_min_f32_dpp", 7, 16, 15) "s_nop 1"                                 \
+                 : "=&v"((na)[0]), "=&v"((na)[1]), "=&v"((na)[2]), "=&v"((na)[3]), "=&v"((na)[4]), "=&v"((na)[5]), "=&v"((na)[6]), "=&v"((na)[7]) \
+                 : "v"((a)[0]), "v"((a)[1]), "v"((a)[2]), "v"((a)[3]), "v"((a)[4]), "v"((a)[5]), "v"((a)[6]), "v"((a)[7]),                 \
+                   "v"((b)[0]), "v"((b)[1]), "v"((b)[2]), "v"((b)[3]), "v"((b)[4]), "v"((b)[5]), "v"((b)[6]), "v"((b)[7]));               \
+    asm volatile("s_nop 1\n\t" R2O_ASM_MM1("v_max_f32_dpp", 0, 15, 16) R2O_ASM_MM1("v_max_f32_dpp", 1, 14, 17)                             \
+                 R2O_ASM_MM1("v_max_f32_dpp", 2, 13, 18) R2O_ASM_MM1("v_max_f32_dpp", 3, 12, 19)                                           \
+                 R2O_ASM_MM1("v_max_f32_dpp", 4, 11, 20) R2O_ASM_MM1("v_max_f32_dpp", 5, 10, 21)                                           \
+                 R2O_ASM_MM1("v_max_f32_dpp", 6, 9, 22) R2O_ASM_MM1("v_max_f32_dpp", 7, 8, 23) "s_nop 1"                                   \
+                 : "=&v"((nb)[0]), "=&v"((nb)[1]), "=&v"((nb)[2]), "=&v"((nb)[3]), "=&v"((nb)[4]), "=&v"((nb)[5]), "=&v"((nb)[6]), "=&v"((nb)[7]) \
+                 : "v"((a)[0]), "v"((a)[1]), "v"((a)[2]), "v"((a)[3]), "v"((a)[4]), "v"((a)[5]), "v"((a)[6]), "v"((a)[7]),                 \
+                   "v"((b)[0]), "v"((b)[1]), "v"((b)[2]), "v"((b)[3]), "v"((b)[4]), "v"((b)[5]), "v"((b)[6]), "v"((b)[7]))
 #define R2O_MIRROR16(F, UPPER) { float q[16];                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) q[r] = F(v[15 - r]);                       \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) R2O_TAKE(v[r], q[r], UPPER) }
@@ -713,14 +729,11 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
         // merge: position P = 128 half + 8 l16 + r; half 0 = the sorted samples, half 1 = [z ascending, +inf x 64]
         float v[16] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], sm[6], sm[7], za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
         {   // P <-> P ^ 255: the other half, lane ^ 15, register 7 - r; the lower half keeps the smaller
-            float nv[16];
+            float na[8], nb[8];
+            float* lo = v; float* hi = v + 8;
+            R2O_ASM_MERGE_MIRROR(na, nb, lo, hi);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                R2O_ASM_MINMAX_DPP("v_min_f32_dpp", DPP_X15, nv[r], v[r], v[15 - r]);
-                R2O_ASM_MINMAX_DPP("v_max_f32_dpp", DPP_X15, nv[8 + r], v[8 + r], v[7 - r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = nv[r];
+            for (int r = 0; r < 8; ++r) { v[r] = na[r]; v[8 + r] = nb[r]; }
         }
         {   // P ^ 64, 32: lane ^ 8, lane ^ 4 (bank steps); P ^ 16, 8: lane ^ 2, lane ^ 1
             float* lo = v; float* hi = v + 8;
@@ -772,7 +785,8 @@ __global__ __launch_bounds__(256) void r2l_sample_pdf_sort16_kernel(const float*
 #undef R2O_ASM_BANK1
 #undef R2O_ASM_BANK_XOR8
 #undef R2O_ASM_BANK_MIRROR8
-#undef R2O_ASM_MINMAX_DPP
+#undef R2O_ASM_MM1
+#undef R2O_ASM_MERGE_MIRROR
 
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
