@@ -395,6 +395,8 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
         rgbs.append(rgb)
         if gt_imgs is not None:
             gt = gt_imgs[i].to(rgb.device, non_blocking=True)
+            if gt.shape[:2] != rgb.shape[:2]:  # --render_factor (teacher branch): the reference CROPS the target, main.py:329-333
+                gt = gt[:rgb.shape[0], :rgb.shape[1]].contiguous()
             mse = img2mse(rgb, gt)
             sq_err.append(mse)
             psnrs.append(mse2psnr(mse))
@@ -407,6 +409,9 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     if teacher is not None:
         from .render import render
         H, W, focal = teacher["hwf"]
+        rf = teacher.get("render_factor", 0)
+        if rf != 0:  # "Render downsampled for speed" (main.py:197-201); the R2L branch's sampler is built for the full frame
+            H, W, focal = int(H / rf), int(W / rf), focal / rf
         # a whole frame per launch on the GPU (as create_data.main: --chunk is a memory work-around of the op-by-op path)
         chunk = max(int(teacher["chunk"]), H * W) if on_gpu else int(teacher["chunk"])
         for i in mine:
@@ -506,7 +511,7 @@ def main(argv=None):
     if is_teacher:
         kwargs_test = create_nerf_teacher(args, device, logger, near, far)
         model, point_sampler = kwargs_test["network_fn"], None
-        teacher = dict(hwf=(H, W, focal), chunk=args.chunk, render_kwargs=kwargs_test)
+        teacher = dict(hwf=(H, W, focal), chunk=args.chunk, render_kwargs=kwargs_test, render_factor=args.render_factor)
         history = {"start": 0, "best_psnr": 0, "best_psnr_step": 0}
         r2l_config = apply_arithmetic(args, device, logger, teachers=(model, kwargs_test["network_fine"]))
     else:
@@ -540,7 +545,7 @@ def main(argv=None):
         else:
             rgbs, misc = render_path(video_poses, model, point_sampler, device, logger, savedir=logger.gen_img_path,
                                      rank=rank, world=world, teacher=teacher)
-        n_rays = rgbs.shape[0] * H * W if rgbs.numel() else 0
+        n_rays = rgbs.numel() // 3 if rgbs.numel() else 0  # (frames x rendered pixels: --render_factor shrinks the teacher's frames)
         dt = time.time() - t_
         logger.info("Rendered %d frames (%d rays) in %.2fs on rank %d = %.0f rays/s incl. I/O; frames in %s" %
                     (rgbs.shape[0], n_rays, dt, rank, n_rays / max(dt, 1e-9), logger.gen_img_path))

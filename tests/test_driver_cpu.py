@@ -117,6 +117,13 @@ def test_teacher_render_only_cpu_plumbing(tmp_path, monkeypatch):
     # novel-pose video of the teacher
     out = driver.main(common + ["--render_only", "--n_pose_video", "3", "--experiment_name", "Video__NeRF__cpu"])
     assert out["rgbs"].shape == (3, 6, 6, 3) and out["video_path"].endswith("_pose3.avi")
+    # --render_factor 2 ("render downsampled for speed", main.py:197-201): H, W, focal halved, the target CROPPED to the frame (:329-333)
+    out = driver.main(common + ["--render_only", "--render_test", "--render_factor", "2", "--experiment_name", "Half__NeRF__cpu"])
+    assert out["rgbs"].shape == (2, 3, 3, 3)
+    ref = oracle_teacher_frame(csd, fsd, poses[i_split[2][0]], 3, 3, float(hwf[2]) / 2)
+    assert (out["rgbs"][0] - ref).abs().max().item() < 1e-5
+    assert abs(out["misc"]["test_psnr_v2"].item() - np.mean([O.mse2psnr(O.img2mse(oracle_teacher_frame(
+        csd, fsd, poses[i], 3, 3, float(hwf[2]) / 2), gts[i][:3, :3])).item() for i in i_split[2]])) < 1e-3
     with pytest.raises(NotImplementedError, match="TRAINING"):
         driver.main(common)
 
