@@ -90,8 +90,10 @@ def main(argv=None):
     logger = Logger(args, rank)
     rng = np.random.RandomState(1000003 * rank)  # per-rank pose / focal / shuffle stream
 
+    scene = None
     if os.path.exists(os.path.join(args.datadir, "transforms_train.json")):
-        _, _, _, hwf, _ = D.load_blender_data(args.datadir, args.half_res, args.testskip)
+        scene = D.load_blender_data(args.datadir, args.half_res, args.testskip)
+        hwf = scene[3]
         H, W, focal = int(hwf[0]), int(hwf[1]), float(hwf[2])
     else:  # intrinsics of the 400x400 lego setting when no scene directory is present (main.py:927 comment)
         H, W, focal = 400, 400, 555.5555155968841
@@ -99,6 +101,18 @@ def main(argv=None):
     coarse, fine = create_teacher(args, device)
     apply_arithmetic(args, device, logger, teachers=(coarse, fine))  # --r2l_precision: the teacher kernels' arithmetic
     kwargs = teacher_render_kwargs(args, coarse, fine)
+    if args.test_teacher:
+        # "Testing teacher..." (create_data.py:723-741): the test views through render_path with render_kwargs_test (perturb =
+        # --perturb_test, raw_noise_std = 0), Loss / PSNR logged before any data is generated; frames sharded over the ranks
+        from .driver import render_path
+        if not args.teacher_ckpt or scene is None:
+            raise SystemExit("--test_teacher needs --teacher_ckpt and a scene directory (--datadir) with test views")
+        images, poses, _, _, i_split = scene
+        images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:]) if args.white_bkgd else images[..., :3]
+        kw_test = dict(kwargs, perturb=args.perturb_test, raw_noise_std=0., near=near, far=far)
+        _, misc = render_path(poses[i_split[2]], coarse, None, device, logger, gt_imgs=images[i_split[2]], rank=rank, world=world,
+                              teacher=dict(hwf=(H, W, focal), chunk=args.chunk, render_kwargs=kw_test, render_factor=args.render_factor))
+        logger.info("Teacher test: Loss %.4f PSNR %.4f" % (misc["test_loss"].item(), misc["test_psnr"].item()))
 
     datadir_new = args.datadir_kd.split(":")[-1]
     if rank == 0:

@@ -26,9 +26,21 @@ def test_create_data_then_train(tmp_path, monkeypatch):
     kd = str(tmp_path / "pseudo")
     out = create_data.main(["--create_data", "rand", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir",
                             scene, "--teacher_ckpt", str(tmp_path / "teacher.tar"), "--n_pose_kd", "3",
-                            "--create_data_chunk", "2", "--datadir_kd", scene + ":" + kd, "--experiment_name", "cd"])
+                            "--create_data_chunk", "2", "--datadir_kd", scene + ":" + kd, "--experiment_name", "cd",
+                            "--test_teacher", "--testskip", "1"])  # (create_data.py:723-741: the test views first, Loss / PSNR logged)
     files = sorted(os.listdir(kd))
     assert len(files) == 3 and out["n_rays"] == 3 * 4096
+    log = open(os.path.join(out["logger"].log_path, "log.txt")).read()
+    line = [l for l in log.splitlines() if "Teacher test: Loss" in l]
+    assert len(line) == 1
+    from r2l_amd import data
+    from tests.test_driver_cpu import oracle_teacher_frame
+    imgs, poses, _, hwf, i_split = data.load_blender_data(scene, True, 1)
+    imgs = torch.as_tensor(imgs)
+    gts = imgs[..., :3] * imgs[..., -1:] + (1. - imgs[..., -1:])
+    mse = np.mean([O.img2mse(oracle_teacher_frame(csd, fsd, poses[i], 64, 64, float(hwf[2])), gts[i]).item() for i in i_split[2]])
+    got = [float(v) for v in line[0].split("Teacher test: Loss ")[1].replace("PSNR", "").split()]
+    assert abs(got[0] - mse) < 2e-4 and abs(got[1] + 10. * np.log10(mse)) < 2e-3, (line[0], mse)
     rows = np.load(os.path.join(kd, files[0]))
     assert rows.shape == (4096, 9) and rows.dtype == np.float32
     assert np.all(np.isfinite(rows)) and rows[:, 6:].min() >= -1e-4 and rows[:, 6:].max() <= 1.0 + 1e-4
