@@ -270,9 +270,9 @@ class _FrameWriter:
     Rounds 1 - 3 encoded with PIL in Python threads: ~15 ms per 400x400 PNG with the GIL held around zlib, which made the
     test-set loop encoder-bound (6.5 ms/frame against 4.5 without images, profiles/r03_e2e_render.txt)."""
 
-    # With 9 frames per launch 18 images arrive at once: the pinned staging slots must cover two groups, or save() blocks on the
-    # encoders before the next group's render is launched.
-    def __init__(self, device, workers=None, slots=4 * POSES_PER_LAUNCH + 4, level=1):
+    # With 9 frames per launch 27 images arrive at once (frame, target, error): the pinned staging slots must cover two groups, or
+    # save() blocks on the encoders before the next group's render is launched.
+    def __init__(self, device, workers=None, slots=6 * POSES_PER_LAUNCH + 4, level=1):
         from . import _lib
         self._lib, self.lib = _lib, _lib.load()
         self.device, self.slots = device, slots
@@ -405,6 +405,9 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             writer.save(rgb, os.path.join(savedir, "%03d.png" % i))
             if gt_imgs is not None:
                 writer.save(gt_imgs[i], os.path.join(savedir, "%03d_gt.png" % i))
+                # |rgb - gt| as an image, as the reference saves it beside every test frame (main.py:330, 342-344)
+                gt_dev = gt_imgs[i].to(rgb.device, non_blocking=True)
+                writer.save((rgb - gt_dev[:rgb.shape[0], :rgb.shape[1]]).abs(), os.path.join(savedir, "%03d_error.png" % i))
 
     if teacher is not None:
         from .render import render

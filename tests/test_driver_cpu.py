@@ -54,7 +54,7 @@ def test_render_only_cpu_plumbing(tmp_path, monkeypatch):
     assert rgbs.shape == (2, 6, 6, 3)  # half_res of the 12x12 test views
     assert np.isfinite(misc["test_psnr"].item()) and np.isfinite(misc["test_psnr_v2"].item())
     pngs = sorted(f for f in os.listdir(out["logger"].gen_img_path) if f.endswith(".png"))
-    assert pngs == ["000.png", "000_gt.png", "001.png", "001_gt.png"]
+    assert pngs == ["000.png", "000_error.png", "000_gt.png", "001.png", "001_error.png", "001_gt.png"]
     assert out["video_path"].endswith(".avi")  # the reference writes the video of the test frames too (main.py:1096-1097)
     # the frame equals the oracle's evaluation of the same weights on the same pose
     from r2l_amd import data
@@ -112,7 +112,7 @@ def test_teacher_render_only_cpu_plumbing(tmp_path, monkeypatch):
         psnrs.append(O.mse2psnr(O.img2mse(ref, gts[i])).item())
     assert abs(misc["test_psnr_v2"].item() - np.mean(psnrs)) < 1e-3
     pngs = sorted(f for f in os.listdir(out["logger"].gen_img_path) if f.endswith(".png"))
-    assert pngs == ["000.png", "000_gt.png", "001.png", "001_gt.png"]
+    assert pngs == ["000.png", "000_error.png", "000_gt.png", "001.png", "001_error.png", "001_gt.png"]
     assert out["video_path"].endswith(".avi")  # the reference writes the video of the test frames too (main.py:1096-1097)
     # novel-pose video of the teacher
     out = driver.main(common + ["--render_only", "--n_pose_video", "3", "--experiment_name", "Video__NeRF__cpu"])

@@ -186,7 +186,7 @@ def test_cli_teacher_render_test_vs_oracle(tmp_path):
                 assert (rgbs[k] - refs[k]).abs().max().item() < 1e-4, (prec, k)
             assert abs(misc["test_psnr_v2"].item() - want_psnr) < 1e-3 and abs(misc["test_ssim"].item() - want_ssim) < 1e-4
             pngs = sorted(f for f in os.listdir(out["logger"].gen_img_path) if f.endswith(".png"))
-            assert pngs == ["000.png", "000_gt.png", "001.png", "001_gt.png"]
+            assert pngs == ["000.png", "000_error.png", "000_gt.png", "001.png", "001_error.png", "001_gt.png"]
             assert "_SERVER000-20260101-000000_iter200000_" in os.path.basename(out["video_path"])
         out = driver.main(common + ["--n_pose_video", "3", "--experiment_name", "Video__NeRF"])
         assert out["rgbs"].shape == (3, 32, 32, 3) and out["video_path"].endswith("_pose3.avi")
