@@ -385,7 +385,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
     teacher kernels); `model` = render_kwargs['network_fn'], `point_sampler` unused."""
     model.eval()
     mine = list(range(rank, len(poses), world))
-    rgbs, sq_err, psnrs, ssims, events = [], [], [], [], []
+    rgbs, sq_err, psnrs, ssims, events, errors = [], [], [], [], [], []
     if savedir is not None:
         os.makedirs(savedir, exist_ok=True)  # every rank writes its own frames: none may rely on rank 0's mkdir
     writer = _FrameWriter.shared(device, workers=int(os.environ.get("R2L_PNG_WORKERS", "0")) or None) if savedir is not None else None
@@ -397,6 +397,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             gt = gt_imgs[i].to(rgb.device, non_blocking=True)
             if gt.shape[:2] != rgb.shape[:2]:  # --render_factor (teacher branch): the reference CROPS the target, main.py:329-333
                 gt = gt[:rgb.shape[0], :rgb.shape[1]].contiguous()
+            errors.append((rgb - gt).abs())  # misc['errors'] (main.py:330, 386): this rank's frames; main() writes their video
             mse = img2mse(rgb, gt)
             sq_err.append(mse)
             psnrs.append(mse2psnr(mse))
@@ -406,8 +407,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
             if gt_imgs is not None:
                 writer.save(gt_imgs[i], os.path.join(savedir, "%03d_gt.png" % i))
                 # |rgb - gt| as an image, as the reference saves it beside every test frame (main.py:330, 342-344)
-                gt_dev = gt_imgs[i].to(rgb.device, non_blocking=True)
-                writer.save((rgb - gt_dev[:rgb.shape[0], :rgb.shape[1]]).abs(), os.path.join(savedir, "%03d_error.png" % i))
+                writer.save(errors[-1], os.path.join(savedir, "%03d_error.png" % i))
 
     if teacher is not None:
         from .render import render
@@ -476,6 +476,7 @@ def render_path(poses, model, point_sampler, device, logger, gt_imgs=None, saved
         misc["test_psnr"] = mse2psnr(misc["test_loss"].float()).squeeze()
         misc["test_psnr_v2"] = torch.tensor(stats[1] / max(stats[2], 1))
         misc["test_ssim"] = torch.tensor(stats[3] / max(stats[2], 1))
+        misc["errors"] = torch.stack(errors, 0) if errors else torch.empty(0)
     model.train()
     return rgbs, misc
 
@@ -554,6 +555,8 @@ def main(argv=None):
                     (rgbs.shape[0], n_rays, dt, rank, n_rays / max(dt, 1e-9), logger.gen_img_path))
         # (the reference writes the video of whichever frames it rendered — test views too, main.py:1096-1097)
         video_path = save_video(rgbs, logger, expid, iter_, args.video_tag, rank, world, device)
+        if "errors" in misc:  # (main.py:1098-1102: the |rgb - gt| frames as a second video)
+            save_video(misc["errors"], logger, expid, iter_, args.video_tag + "_error", rank, world, device)
         return {"misc": misc, "rgbs": rgbs, "logger": logger, "video_path": video_path, "r2l_config": r2l_config}
 
     if args.benchmark:
