@@ -1395,7 +1395,12 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         // small steps: two workgroups per layer, none across a layer boundary (one slab flush each, half the reduce): measured
         // at 4096 rays 97 + 16 us against 111 + 22 us for 251 workgroups; at 12 288 rays the full grid wins again (229 + 22
         // against 242 + 16)
-        if (N <= 6144 && 2 * (int64_t)a.n_layers <= wgs) wgs = 2 * (int64_t)a.n_layers;
+        // (that is the fp16 trio's kernel, which is bound by the slab traffic at this size; the fp32-MFMA / bf16x3 kernels are bound by
+        // their MFMAs — 32 units on 172 workgroups against 22 on 251 — and keep the full grid: round 6, profiles/r06_graded_step_ab.txt E)
+        if (trio16 && N <= 6144 && 2 * (int64_t)a.n_layers <= wgs) wgs = 2 * (int64_t)a.n_layers;
+        // the MFMA-bound kernels with the head / tail gradients beside them (small steps): an eighth of the CUs stays free for those,
+        // or they queue behind the persistent grid (4096 rays, fp32 family: 1.358 ms with 172 workgroups, 1.367 with 251, 1.317 with 224)
+        if (!trio16 && overlap && wgs > n_cu - n_cu / 8) wgs = n_cu - n_cu / 8;
         if (const char* e = getenv("R2L_DW_WGS")) {  // tuning knob (tools/small_prof.sh)
             const int64_t v = atoll(e);
             if (v >= a.n_layers && v <= wgs) wgs = v;
