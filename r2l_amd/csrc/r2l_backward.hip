@@ -1215,6 +1215,14 @@ extern "C" int r2l_backward_part(const float* rays_o, const float* rays_d, const
                                  grad_scale, dpre, gx, gt, sqerr_partial, grads, dw_slab, N, stream_, parts, layer_lo, layer_hi,
                                  nullptr);
 }
+// largest step whose head / tail gradients run beside the body's (R2L_DW_OVERLAP_MAX_RAYS: tuning knob, tools/run_ab.sh)
+static int64_t r2l_dw_overlap_max() {
+    static const int64_t v = [] {
+        const char* e = getenv("R2L_DW_OVERLAP_MAX_RAYS");
+        return e ? (int64_t)atoll(e) : (int64_t)R2L_COOPF_MAX_RAYS;
+    }();
+    return v;
+}
 extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, const float* t_rand, const float* ztab,
                                      const float* emb, const float* rgb, const float* target, const float* drgb,
                                      const float* save_x, const float* save_t,
@@ -1363,10 +1371,7 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         static thread_local hipStream_t side[16] = {nullptr};
         static thread_local hipEvent_t ev_fork[16], ev_join[16];
         static const bool overlap_off = r2l_env_on("R2L_NO_DW_OVERLAP");
-        static const int64_t overlap_max = [] {
-            const char* e = getenv("R2L_DW_OVERLAP_MAX_RAYS");  // (tuning knob: tools/run_ab.sh)
-            return e ? (int64_t)atoll(e) : (int64_t)R2L_COOPF_MAX_RAYS;
-        }();
+        const int64_t overlap_max = r2l_dw_overlap_max();
         int dev = 0;
         if (!overlap_off && (parts & R2L_BWD_BODY) && (parts & R2L_BWD_HEAD) && layer_hi > layer_lo && dw_slab != nullptr &&
             N <= overlap_max && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
@@ -1400,7 +1405,9 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         if (trio16 && N <= 6144 && 2 * (int64_t)a.n_layers <= wgs) wgs = 2 * (int64_t)a.n_layers;
         // the MFMA-bound kernels with the head / tail gradients beside them (small steps): an eighth of the CUs stays free for those,
         // or they queue behind the persistent grid (4096 rays, fp32 family: 1.358 ms with 172 workgroups, 1.367 with 251, 1.317 with 224)
-        if (!trio16 && overlap && wgs > n_cu - n_cu / 8) wgs = n_cu - n_cu / 8;
+        // (decided by the step size alone, not by whether THIS call overlaps: the staged form — body buckets in calls of their own —
+        // must cut the same work list as the one-call form, tests: staged with one bucket == one call, bit for bit)
+        if (!trio16 && N <= r2l_dw_overlap_max() && wgs > n_cu - n_cu / 8) wgs = n_cu - n_cu / 8;
         if (const char* e = getenv("R2L_DW_WGS")) {  // tuning knob (tools/small_prof.sh)
             const int64_t v = atoll(e);
             if (v >= a.n_layers && v <= wgs) wgs = v;
