@@ -326,18 +326,13 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
                 av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avo, so, 0));
             };
             int s = 0;
-#if defined(DW_PIN_MODE) && DW_PIN_MODE == 1  // A/B: loads pinned among the first MFMAs
-#define DW_PIN __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-               __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#else
-#define DW_PIN
-#endif
+            // (not pinned with sched_group_barrier: with [2 MFMA, 1 load] x 2 in front hipcc moved accumulators between VGPRs and AGPRs in
+            // every k-step — 7000 v_accvgpr moves per 128 k-steps)
 #define DW_TRIPS(TRIP)                                                                                                   \
             for (; s + TRIP <= nfull32; s += TRIP) {                                                                     \
                 _Pragma("unroll") for (int k = 0; k < TRIP; ++k) {                                                       \
                     ldi(s + k - 1 + DW_DEPTH, gb[(k + DW_DEPTH - 1) % DW_DEPTH], ab[(k + DW_DEPTH - 1) % DW_DEPTH]);     \
                     kstep(gb[k % DW_DEPTH], ab[k % DW_DEPTH]);                                                           \
-                    DW_PIN                                                                                               \
                     __builtin_amdgcn_sched_barrier(0);                                                                   \
                 }                                                                                                        \
             }
@@ -346,9 +341,6 @@ __global__ __launch_bounds__(256, 1) void r2l_dw_body_kernel(const R2LDwArgs a) 
             DW_TRIPS(64)
             DW_TRIPS(32)
 #undef DW_TRIPS
-#ifdef DW_PIN
-#undef DW_PIN
-#endif
             for (; s < nfull; ++s) {  // remainder: only the last, partial chunk at the end of N
                 f32x4 gv, av;
                 ld(s, gv, av);
