@@ -268,6 +268,58 @@ def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+def test_cli_render_two_ranks_cpu(tmp_path):
+    """`main.py --render_only --render_test` under torchrun with two gloo ranks on CPU (the rank-sharded test-set loop of the student
+    AND of the teacher, main.py:189-398 with its `model_name in ['nerf']` branch): frames poses[rank::2], metrics all-reduced, the
+    video gathered to rank 0 — the [TEST] line and the PNG / AVI bytes equal the single process's."""
+    from r2l_amd import driver
+    from r2l_amd.checkpoint import save_ckpt
+    from r2l_amd.options import parse_args
+    scene = str(tmp_path / "scene")
+    os.makedirs(scene)
+    make_scene(scene)
+    csd, fsd = O.make_teacher_state_dicts(5, 2, alpha_bias=0.5)
+    torch.save({"network_fn_state_dict": csd, "network_fine_state_dict": fsd}, str(tmp_path / "teacher.tar"))
+    stu = ["--model_name", "R2L", "--config", os.path.join(ROOT, "configs", "lego_noview.txt"), "--datadir", scene,
+           "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "6", "--use_residual", "--trial.ON", "--trial.body_arch",
+           "resmlp", "--testskip", "1"]
+    from model.nerf_raybased import NeRF_v3_2
+    torch.manual_seed(0)
+    save_ckpt(str(tmp_path / "student.tar"), 1, NeRF_v3_2(parse_args(stu), 1008, 3), {"state": {}, "param_groups": []}, 0., 0)
+    runs = {"student": stu + ["--pretrained_ckpt", str(tmp_path / "student.tar")],
+            "teacher": ["--model_name", "nerf", "--config", os.path.join(ROOT, "configs", "lego.txt"), "--datadir", scene,
+                        "--pretrained_ckpt", str(tmp_path / "teacher.tar"), "--testskip", "1"]}
+    env = {k: v for k, v in os.environ.items() if not k.startswith("R2L_")}
+    env.update(MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    cwd = os.getcwd()
+    for k, (name, args) in enumerate(runs.items()):
+        args = args + ["--render_only", "--render_test"]
+        os.chdir(tmp_path)
+        try:
+            import unittest.mock as mock
+            with mock.patch.object(torch.cuda, "is_available", lambda: False):
+                one = driver.main(args + ["--experiment_name", "one_" + name])
+        finally:
+            os.chdir(cwd)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(29621 + k), os.path.join(ROOT, "main.py")] + args +
+                           ["--experiment_name", "two_" + name], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        out = r.stdout + r.stderr
+        assert r.returncode == 0, out[-3000:]
+        want = "[TEST] TestPSNR %.4f TestPSNRv2 %.4f TestSSIM %.4f" % (one["misc"]["test_psnr"].item(), one["misc"]["test_psnr_v2"].item(),
+                                                                      one["misc"]["test_ssim"].item())
+        assert want in out, (want, [l for l in out.splitlines() if "[TEST]" in l])
+
+        def files(tag):
+            hits = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs
+                          if f.endswith((".png", ".avi")) and os.sep + tag + "_" + name + "_" in dp)
+            return {os.path.basename(f): open(f, "rb").read() for f in hits}
+        a, b = files("one"), files("two")
+        assert len(a) == 8 and a.keys() == b.keys(), (sorted(a), sorted(b))  # 2 frames x (frame, target, error) + video + error video
+        for f in a:
+            assert a[f] == b[f], (name, f)
+
+
 WORKER8 = r"""
 import ctypes, os, sys, types
 sys.path.insert(0, %(root)r)
