@@ -1395,6 +1395,11 @@ extern "C" int r2l_backward_part_cfg(const float* rays_o, const float* rays_d, c
         // (that is the fp16 trio's kernel, which is bound by the slab traffic at this size; the fp32-MFMA / bf16x3 kernels are bound by
         // their MFMAs — 32 units on 172 workgroups against 22 on 251 — and keep the full grid: round 6, profiles/r06_graded_step_ab.txt E)
         if (trio16 && N <= 6144 && 2 * (int64_t)a.n_layers <= wgs) wgs = 2 * (int64_t)a.n_layers;
+        // above that, up to the largest step whose head / tail gradients run beside this kernel: 11/16 of the CUs.  On the full grid the
+        // head kernel (VALU-bound, 4 workgroups per ray slice) queues behind the persistent workgroups and the overlap is one in name
+        // only (12 288 rays: 1.251 ms with 251 workgroups = 1.285 with the overlap off; 1.231 with 176, 1.239 with 144: round 6,
+        // profiles/r06_small_step_dw_grid.txt); the kernel is HBM-bound, fewer workgroups cost it little
+        if (trio16 && N > 6144 && N <= r2l_dw_overlap_max() && wgs > n_cu * 11 / 16) wgs = n_cu * 11 / 16;
         // the MFMA-bound kernels with the head / tail gradients beside them (small steps): an eighth of the CUs stays free for those,
         // or they queue behind the persistent grid (4096 rays, fp32 family: 1.358 ms with 172 workgroups, 1.367 with 251, 1.317 with 224)
         // (decided by the step size alone, not by whether THIS call overlaps: the staged form — body buckets in calls of their own —
