@@ -239,7 +239,7 @@ class R2LTrainer:
         the current stream) and return the event that marks it done — or None: the caller launches it in line (large steps, where
         the body kernels fill the chip; R2L_NO_DW_OVERLAP=1; a stand-in engine without a device, tests/test_driver_cpu.py)."""
         dev = getattr(self.eng, "device", None)
-        if (n > self.HEAD_BESIDE_MAX_RAYS or os.environ.get("R2L_NO_DW_OVERLAP", "")[:1] not in ("", "0") or self.dw_slab is None
+        if (n > int(os.environ.get("R2L_HEAD_BESIDE_MAX_RAYS", self.HEAD_BESIDE_MAX_RAYS)) or os.environ.get("R2L_NO_DW_OVERLAP", "")[:1] not in ("", "0") or self.dw_slab is None
                 or not isinstance(dev, torch.device) or dev.type != "cuda"):
             return None
         if self._head_side is None:
