@@ -172,26 +172,7 @@ class R2LTrainer:
         eng = self.eng
         n = rays_o.shape[0]
         eng.ensure_packed(n)
-        # Small steps (round 6): the re-pack of the transposed stream (17 us; only the BACKWARD reads it) and the clearing of the flat
-        # gradient (7 us) run on a second stream beside the forward chain, which leaves CUs idle at these sizes; joined in front of the
-        # backward.  Same kernels on the same data: bit-identical.  (R2L_NO_PREP_OVERLAP=1: in line, the order of rounds 1 - 5.)
-        prep_done, dev = None, getattr(eng, "device", None)
-        if (n <= self.HEAD_BESIDE_MAX_RAYS * 2 and isinstance(dev, torch.device) and dev.type == "cuda"
-                and os.environ.get("R2L_NO_PREP_OVERLAP", "")[:1] in ("", "0")):
-            if self._head_side is None:
-                self._head_side = torch.cuda.Stream(device=dev)
-            main, side = torch.cuda.current_stream(), self._head_side
-            fork = torch.cuda.Event()
-            fork.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(fork)
-                self._pack_bwd(n)
-                if zero_grad:
-                    self.grads.zero_()
-                prep_done = torch.cuda.Event()
-                prep_done.record(side)
-        else:
-            self._pack_bwd(n)
+        self._pack_bwd(n)
         self._ensure_capacity(n)
         # opt-in (R2L_ADAM_PACK=1): steps of the default trio (both streams in the fp16x2 layout) get their re-pack from the optimizer
         # kernel (adam()).  Bit-identical and 23 us less kernel time per step (r2l_adam_pack_kernel 37 us against 60 for adam and
@@ -211,9 +192,7 @@ class R2LTrainer:
         if self.calibrate and not self._calibrated:
             self._calibrate(rays_o, rays_d, perturb, t_rand)
         rgb = eng.forward_rays(rays_o, rays_d, self.ps.z_vals, perturb, t_rand, save=(self.save_x, self.save_t))
-        if prep_done is not None:
-            torch.cuda.current_stream().wait_event(prep_done)
-        elif zero_grad:
+        if zero_grad:
             self.grads.zero_()
         shares = None
         if n_global is not None and not isinstance(n_global, int):
