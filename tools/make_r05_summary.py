@@ -1,9 +1,10 @@
-"""Regenerates profiles/r05_summary.md and the two tables at the head of DESIGN.md §4 from profiles/r05_bench.json (the bench line of
+"""Regenerates profiles/r05_summary.md and the two generated tables of DESIGN_NOTES.md §4 (the long form of DESIGN.md since round 6) from profiles/r05_bench.json (the bench line of
 tools/r05_profile.sh), r05_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same command) and r05_bench_pmc_summary.json
 (separate --pmc passes).  CPU only; run after copying a new profile run into profiles/."""
 import csv
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda f: os.path.join(ROOT, "profiles", f)
@@ -158,11 +159,14 @@ what a user of the library gets unless they ask for `precision = fp32_mfma`.  Bo
 ≤ 20 ms per frame).
 
 '''
-p = os.path.join(ROOT, "DESIGN.md")
-s = open(p).read()
-a = s.index("## 4. Roofline per kernel")
-b = s.index("On the 60 % target: the roofline fractions above price")
-open(p, "w").write(s[:a] + design_head + "\n".join(k) + "\n" + legs_head + "\n".join(t) + "\n" + legs_tail + s[b:])
+# The two tables live in DESIGN_NOTES.md §4 (the long form of DESIGN.md since round 6) and are FROZEN there: round 6 put its own delta
+# table in front of them, which this rewrite would drop.  `--rewrite-design-notes` regenerates them anyway (then restore the round-6 block).
+if "--rewrite-design-notes" in sys.argv:
+    p = os.path.join(ROOT, "DESIGN_NOTES.md")
+    s = open(p).read()
+    a = s.index("## 4. Roofline per kernel")
+    b = s.index("On the 60 % target: the roofline fractions above price")
+    open(p, "w").write(s[:a] + design_head + "\n".join(k) + "\n" + legs_head + "\n".join(t) + "\n" + legs_tail + s[b:])
 
 # ---------------------------------------------------------------------------------------------------------- profiles/r05_summary.md
 rows = [
