@@ -35,7 +35,8 @@
 // products for twice the stash traffic (still HBM-bound).  The ring unit is then a HALF tile (one k-step = 16 rays) of
 // [G hi | A hi | G mid | A mid] = 32 KiB, four units deep like the default kernel's four tiles (a DMA instruction moves 16
 // rays of two stage pieces either way), one barrier per k-step: the same 96 KiB in flight per CU and the same continuous
-// stream.  (First version: whole tiles of 64 KiB, two deep, vmcnt(0) per tile: 4.5 TB/s instead of 5.9.)
+// stream, its requests spread evenly over the k-step's MFMAs (round 6).  (First version: whole tiles of 64 KiB, two deep,
+// vmcnt(0) per tile: 4.5 TB/s; units requested in a lump behind the barrier: 4.9 - 5.0; one request per 6 MFMAs: 5.1 - 5.2.)
 // (A/B: -DDW16_NT streams the stash — read exactly once — past the caches: `nt` on the LDS-DMA loads of the exact kernel)
 #ifdef DW16_NT
 __device__ __forceinline__ void dw16_dma16_nt(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
@@ -45,11 +46,14 @@ __device__ __forceinline__ void dw16_dma16_nt(u32x4 rsrc, unsigned voff, unsigne
 #else
 #define DW16_DMA f3_dma16
 #endif
+#define DW16_SLOT(q) ((q) & 3)  // ring of four 32 KiB buffers (five = all 160 KiB of LDS measured no gain: profiles/r06_exact_dw_ab.txt)
 template <bool EXACT> struct Dw16Cfg {
     static constexpr int NB = 4;
     static constexpr unsigned STAGE_BYTES = 32768u;
 };
 
+#define DW16_WAIT_PRO() asm volatile("s_waitcnt vmcnt(24)" ::: "memory")   // the oldest of 4 x 8 requests landed
+#define DW16_WAIT_LOOP() asm volatile("s_waitcnt vmcnt(16)" ::: "memory")  // 2 x 8 requests behind the awaited one
 typedef short dw16_s16x4 __attribute__((ext_vector_type(4)));
 typedef short dw16_s16x8 __attribute__((ext_vector_type(8)));
 
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
             auto issue = [&](int q) {
                 const int qc = q < nunits ? q : nunits - 1;
                 const unsigned so = (unsigned)(qc >> 1) * (unsigned)DW16_OP_BYTES + wsrc + (unsigned)(qc & 1) * 256u;
-                const unsigned ld = img_lds + (unsigned)(q & (DW16_NB - 1)) * DW16_STAGE_BYTES + (unsigned)wave * 2048u;
+                const unsigned ld = img_lds + (unsigned)DW16_SLOT(q) * DW16_STAGE_BYTES + (unsigned)wave * 2048u;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {  // the wave's two piece pairs (pieces 4w + 2pr, 4w + 2pr + 1), 16 rays of each
                     const unsigned po = so + (unsigned)pr * 2048u, lp = ld + (unsigned)pr * 1024u;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
             };
             const unsigned gq = img_lds + rl + (unsigned)wo * 4096u, aq = img_lds + 8192u + rl + (unsigned)wi * 4096u;
             auto read = [&](Dw16Frags<EXACT>& R, int q) {
-                const unsigned bo = (unsigned)(q & (DW16_NB - 1)) * DW16_STAGE_BYTES;
+                const unsigned bo = (unsigned)DW16_SLOT(q) * DW16_STAGE_BYTES;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     R.g[e] = dw16_frag(gq + bo, (unsigned)e * 1024u);
@@ -179,22 +183,41 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     R.xm[e] = dw16_frag(aq + bo, 16384u + (unsigned)e * 1024u);
                 }
             };
-            auto mma = [&](const Dw16Frags<EXACT>& R) {  // small terms first
+            Dw16Frags<EXACT> R0, R1;
 #pragma unroll
-                for (int eo = 0; eo < 4; ++eo)
+            for (int q = 0; q < DW16_NB; ++q) issue(q);
+            DW16_WAIT_PRO();  // unit 0 landed ((NB - 1) x 8 loads behind it)
+            __syncthreads();
+            read(R0, 0);
+            // Steady state: the 8 requests of unit q + NB go out ONE AT A TIME, behind every 6th of the k-step's 48 MFMAs (round 6:
+            // in a lump behind the barrier the kernel took 3.52 ms per 98 304 rays, two per 12 MFMAs 3.42, one per 6 3.38; requesting
+            // the two 256-byte halves of a tile's 512-byte runs back to back instead: +8 %.  profiles/r06_exact_dw_ab.txt).  Unit q+1
+            // landed (the 16 requests of units q+2, q+3 behind it); behind the barrier everybody's share is visible and nobody reads
+            // unit q's buffer any more (its fragments are in registers): it goes to the DMA of unit q+NB.  MFMAs: small terms first.
+            auto issue_one = [&](int q, int k) {  // request k of 8: k = pr * 4 + {G hi, A hi, G mid, A mid}
+                const int qc = q < nunits ? q : nunits - 1;
+                const unsigned so = (unsigned)(qc >> 1) * (unsigned)DW16_OP_BYTES + wsrc + (unsigned)(qc & 1) * 256u;
+                const unsigned ld = img_lds + (unsigned)DW16_SLOT(q) * DW16_STAGE_BYTES + (unsigned)wave * 2048u;
+                const int pr = k >> 2, w = k & 3;
+                const unsigned po = so + (unsigned)pr * 2048u + ((w & 2) ? a.mid_off : 0u);
+                const unsigned lp = ld + (unsigned)pr * 1024u + (unsigned)w * 8192u;
+                if (w & 1) DW16_DMA(ars, dvoff, po, lp);
+                else DW16_DMA(grs, dvoff, po, lp);
+            };
+            auto mma_issue = [&](const Dw16Frags<EXACT>& R, int qn) {
+                issue_one(qn, 0);
 #pragma unroll
-                    for (int ei = 0; ei < 4; ++ei)
-                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.gm[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
-#pragma unroll
-                for (int eo = 0; eo < 4; ++eo)
-#pragma unroll
-                    for (int ei = 0; ei < 4; ++ei)
-                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.xm[ei], acc[eo][ei], 0, 0, 0);
-#pragma unroll
-                for (int eo = 0; eo < 4; ++eo)
-#pragma unroll
-                    for (int ei = 0; ei < 4; ++ei)
-                        acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+                for (int i = 0; i < 48; ++i) {
+                    const int grp = i >> 4, eo = (i >> 2) & 3, ei = i & 3;
+                    if (grp == 0) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.gm[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+                    else if (grp == 1) acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.xm[ei], acc[eo][ei], 0, 0, 0);
+                    else acc[eo][ei] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.g[eo], R.x[ei], acc[eo][ei], 0, 0, 0);
+                    if ((i + 1) % 6 == 0 && i + 1 < 48) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_one(qn, (i + 1) / 6);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 if (wi == 0) {  // db: hi and mid halves of the 8 rays of a gradient fragment, added up exactly in fp32
 #pragma unroll
                     for (int eo = 0; eo < 4; ++eo) {
@@ -206,25 +229,15 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                     }
                 }
             };
-            Dw16Frags<EXACT> R0, R1;
-#pragma unroll
-            for (int q = 0; q < DW16_NB; ++q) issue(q);
-            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // unit 0 landed (3 x 8 loads behind it)
-            __syncthreads();
-            read(R0, 0);
             for (int q = 0; q < nunits; q += 2) {
-                // unit q+1 landed (the 16 loads of units q+2, q+3 behind it); behind the barrier everybody's share is visible and
-                // nobody reads unit q's buffer any more (its fragments are in registers): it goes to the DMA of unit q+4
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                DW16_WAIT_LOOP();
                 __syncthreads();
-                issue(q + DW16_NB);
                 read(R1, q + 1);
-                mma(R0);
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                mma_issue(R0, q + DW16_NB);
+                DW16_WAIT_LOOP();
                 __syncthreads();
-                issue(q + 1 + DW16_NB);
                 read(R0, q + 2);
-                mma(R1);
+                mma_issue(R1, q + 1 + DW16_NB);
             }
         } else {
             // tile s of the segment -> ring buffer s & 3: 8 pieces per wave.  Tiles past the end are clamped to the last one
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
             auto issue = [&](int s) {
                 const int sc = s < ntiles ? s : ntiles - 1;
                 const unsigned so = (unsigned)sc * (unsigned)DW16_OP_BYTES + wsrc;
-                const unsigned ld = wdst + (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES;
+                const unsigned ld = wdst + (unsigned)DW16_SLOT(s) * DW16_STAGE_BYTES;
     #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const unsigned po = (unsigned)((i >> 1) * 2048 + (i & 1) * 256);
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                 }
             };
             auto read = [&](Dw16Frags<EXACT>& R, int s, int ks) {
-                const unsigned bo = (unsigned)(s & (DW16_NB - 1)) * DW16_STAGE_BYTES + (unsigned)ks * 1024u;
+                const unsigned bo = (unsigned)DW16_SLOT(s) * DW16_STAGE_BYTES + (unsigned)ks * 1024u;
                 const unsigned gp = gl + bo, ap = al + bo;
     #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -293,8 +306,7 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
             // prologue: tiles 0 .. NB-1 requested, tile 0 published (latency exposed once per segment)
     #pragma unroll
             for (int s = 0; s < DW16_NB; ++s) issue(s);
-            if (EXACT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // 2 tiles x 16 loads per wave
-            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // 4 tiles x 8
+            DW16_WAIT_PRO();  // tile 0 landed ((NB - 1) x 8 loads behind it)
             __syncthreads();
             read(R0, 0, 0);
             for (int s = 0; s < ntiles; ++s) {
@@ -302,9 +314,9 @@ __global__ __launch_bounds__(256, 1) void r2l_dw16_kernel(const R2LDwArgs a, con
                 mma(R0);
                 // tile s+1 landed (its 8 loads have the 16 of tiles s+2, s+3 behind them; EXACT: nothing behind its 16); behind the
                 // barrier everybody's share is visible and nobody reads the image of tile s any more (its fragments are in registers)
-                if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                DW16_WAIT_LOOP();
                 __syncthreads();
+                // (the 8 requests in a lump: spreading them over the second k-step's MFMAs, which pays in the EXACT kernel, measured 0 here)
                 issue(s + DW16_NB);
                 read(R0, s + 1, 0);
                 mma(R1);
