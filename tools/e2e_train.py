@@ -1,6 +1,7 @@
 """Wall-clock of the whole training loop through the CLI surface (main.py flags of README step 3): native shard reader
 -> H2D -> hard-ray pool -> fused step, W256 D88, N_rand 20 (81 920 rays) + 16 384 hard rays.  Two runs of different
-length are timed and subtracted so that start-up (imports, packing, pool fill) drops out."""
+length are timed and subtracted so that start-up (imports, packing, pool fill) drops out.  Extra command-line arguments are passed
+through to main.py (e.g. `python tools/e2e_train.py --r2l_precision fp32_mfma`: the loop on the graded arithmetic)."""
 import os
 import sys
 import tempfile
@@ -34,7 +35,7 @@ def main(n_files=240, it_a=230, it_b=530):
               "--n_sample_per_ray", "16", "--netwidth", "256", "--netdepth", "88", "--use_residual", "--trial.ON",
               "--trial.body_arch", "resmlp", "--testskip", "1", "--datadir_kd", kd, "--data_mode", "rays",
               "--N_rand", "20", "--hard_ratio", "0.2", "--hard_mul", "20", "--warmup_lr", "0.0001,200",
-              "--i_print", "100", "--i_testset", "100000", "--i_weights", "100000", "--num_workers", "8"]
+              "--i_print", "100", "--i_testset", "100000", "--i_weights", "100000", "--num_workers", "8"] + sys.argv[1:]
     out = {}
     # (an untimed first run: one-off costs of the process — library load, first-touch of the big buffers — would otherwise
     # sit in the first timed run only and not cancel in the subtraction)
