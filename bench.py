@@ -326,8 +326,8 @@ def raw2outputs_leg(device, steps, warmup, n_rays=32768):
                 "frac": tbs / 8.0, "frac_of_achievable_6.3": tbs / 6.3, "kernel": "r2l_sample_pdf_sort16_kernel",
                 "bound_note": "2308 B per ray would make it HBM-bound; round 6: the 128 samples are sorted and merged with the ascending "
                               "coarse depths (2816 compare-exchanges per ray instead of 4608; 1342 VALU instructions per wave of four rays "
-                              "instead of 1581) — the launch is one round of resident waves whose load, compute and store phases do "
-                              "not overlap (profiles/r06_sample_pdf_sort.txt)"}
+                              "instead of 1581) — VALU-issue bound end to end: 1342 x 4 cycles x 8 waves per SIMD = 18 us, first-load "
+                              "latency and the last stores around it; a staggered-start probe gained nothing (profiles/r06_sample_pdf_sort.txt)"}
 
     for S, need_w in ((64, True), (192, False)):
         r = measure(S, need_w, n_rays, 8 if S <= 64 else 4, max(20, steps))
